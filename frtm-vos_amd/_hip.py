@@ -1,0 +1,105 @@
+"""ctypes binding of libfrtm_hip.so (C ABI: include/frtm_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfrtm_hip.so')
+
+P, I, F, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(k, I) for k in ('B', 'Cin', 'Hin', 'Win', 'Cout', 'ksize', 'stride', 'pad',
+                                 'relu', 'out_transposed', 'splitk', 'tile')]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/frtm_hip.h
+SIGNATURES = {
+    'frtm_last_error': (ctypes.c_char_p, []),
+    'frtm_version': (I, []),
+    'frtm_device_info': (I, [P]),
+    'frtm_pixel_weights': (I, [P, I, I, I, I, F, P, P, P]),
+    'frtm_normal_build': (I, [P, I, P, I, I, I, I, I, F, P, I, P, P, P, P]),
+    'frtm_memory_next_slot': (I, [P, I, F, I, P, P]),
+    'frtm_memory_insert': (I, [P, P, I, P, P]),
+    'frtm_filter_scores': (I, [P, P, I, I, I, I, P, I, P]),
+    'frtm_stencil': (I, [P, P, P, P, I, I, I, P, P]),
+    'frtm_filter_wgrad': (I, [P, P, I, I, I, I, P, P]),
+    'frtm_filter_igrad': (I, [P, P, I, I, I, I, P, I, P]),
+    'frtm_vec_reduce_slabs': (I, [P, I, I, I, F, P, F, P, P]),
+    'frtm_cg_begin': (I, [P, P, P, I, I, F, F, I, P, P]),
+    'frtm_cg_direction': (I, [P, P, I, I, F, F, I, I, I, F, P, P, P]),
+    'frtm_cg_pq': (I, [P, P, P, I, P, P]),
+    'frtm_cg_update': (I, [P, P, P, P, P, I, I, F, F, I, I, I, P, P, P]),
+    'frtm_vec_axpy': (I, [P, F, P, I, P]),
+    'frtm_transpose2d': (I, [P, I, I, P, P]),
+    'frtm_conv_pack_weights': (I, [P, I, I, I, P, P, P]),
+    'frtm_conv2d': (I, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
+    'frtm_backbone_create': (I, [I, ctypes.POINTER(P)]),
+    'frtm_backbone_destroy': (I, [P]),
+    'frtm_backbone_num_convs': (I, [P]),
+    'frtm_backbone_conv_info': (I, [P, I, P]),
+    'frtm_backbone_set_conv': (I, [P, I, P, P, P, P]),
+    'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
+    'frtm_backbone_last_flops': (D, [P]),
+    'frtm_merge_masks': (I, [P, I, I, P]),
+    'frtm_count_above': (I, [P, I, I, F, P, P]),
+    'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libfrtm_hip.so once.  Raises if it has not been built (``python frtm-vos_amd/build.py``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libfrtm_hip.so not found at %s -- build it with `python frtm-vos_amd/build.py` '
+                               '(or __graft_entry__.build()); there is no non-HIP fallback' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'libfrtm_hip needs dense tensors'
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Calls an int-returning entry point on the current torch stream; raises on error."""
+    L = lib()
+    rc = getattr(L, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
+
+
+def call_nostream(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('%s: tensor is on %s; the FRTM hot path runs on the GPU only (no CPU fallback)' % (what, t.device))
+    if t.dtype != torch.float32 and t.dtype != torch.uint8:
+        raise TypeError('%s: expected float32/uint8, got %s' % (what, t.dtype))

@@ -1,0 +1,261 @@
+// ResNet trunk runtime (torchvision v1.5 topology) on top of the fp32 MFMA implicit-GEMM conv.
+// Reference call sites: model/feature_extractor.py:9-68.  The whole forward pass is ONE C call that
+// enqueues ~105 kernels on the caller's stream: no Python between the convs, weights and activation
+// buffers stay resident in HBM (288 GB: nothing is ever freed or re-packed per frame).
+#include <vector>
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+void frtm_conv_plan(int M, int Ntot, int nchunks, int* tile, int* splitk);
+
+struct ConvL {
+  int Cout, Cin, ks, stride, pad;
+  float* wT = nullptr; float* scale = nullptr; float* shift = nullptr; int* ktab = nullptr;
+  bool loaded = false;
+};
+struct BlockL { int conv[3]; int nconv; int ds; };   // conv indices (ds = -1: identity shortcut)
+
+struct frtm_backbone {
+  int arch = 0;
+  bool bottleneck = false;
+  std::vector<ConvL> convs;
+  std::vector<std::vector<BlockL>> stages;   // 4 stages
+  // activation arena
+  float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t buf_elems = 0;
+  float* ws = nullptr; size_t ws_elems = 0;
+  float* pack_tmp = nullptr; size_t pack_tmp_elems = 0;
+  double last_flops = 0.0;
+};
+
+__global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __restrict__ img, int HW, const float* __restrict__ sc,
+                                                       const float* __restrict__ bi, float* __restrict__ out, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % 3);
+    out[i] = sc[c] * (float)img[i] + bi[c];                  // feature_extractor.py:42
+  }
+}
+
+// 3x3 stride-2 pad-1 max pool (feature_extractor.py:53)
+__global__ __launch_bounds__(256) void k_maxpool3s2(const float* __restrict__ in, int Hin, int Win, int Ho, int Wo, float* __restrict__ out,
+                                                     size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const int oy = (int)((i / Wo) % Ho);
+    const size_t plane = i / ((size_t)Wo * Ho);
+    const float* ip = in + plane * (size_t)Hin * Win;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = oy * 2 - 1 + dy;
+      if ((unsigned)yy >= (unsigned)Hin) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = ox * 2 - 1 + dx;
+        if ((unsigned)xx < (unsigned)Win) m = fmaxf(m, ip[(size_t)yy * Win + xx]);
+      }
+    }
+    out[i] = m;
+  }
+}
+
+static int add_conv(frtm_backbone* bb, int Cout, int Cin, int ks, int stride) {
+  ConvL c;
+  c.Cout = Cout; c.Cin = Cin; c.ks = ks; c.stride = stride; c.pad = ks / 2;
+  bb->convs.push_back(c);
+  return (int)bb->convs.size() - 1;
+}
+
+static int ensure(float** p, size_t* have, size_t need) {
+  if (*have >= need) return FRTM_OK;
+  if (*p) FRTM_HIP(hipFree(*p));
+  *p = nullptr; *have = 0;
+  FRTM_HIP(hipMalloc((void**)p, need * sizeof(float)));
+  *have = need;
+  return FRTM_OK;
+}
+
+static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const float* in, const float* residual, int relu, float* out,
+                    int* Ho, int* Wo, hipStream_t st) {
+  ConvL& c = bb->convs[idx];
+  if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
+  frtm_conv_desc d;
+  d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = c.pad;
+  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0;
+  *Ho = (Hin + 2 * c.pad - c.ks) / c.stride + 1;
+  *Wo = (Win + 2 * c.pad - c.ks) / c.stride + 1;
+  const size_t need = (size_t)FRTM_CONV_MAX_SPLITK * c.Cout * B * (*Ho) * (*Wo);
+  // split-K is only chosen for small outputs; size the workspace for what the planner will pick
+  int tile = 0, splitk = 0;
+  frtm_conv_plan(c.Cout, B * (*Ho) * (*Wo), ceil_div(c.Cin * c.ks * c.ks, 32), &tile, &splitk);
+  if (splitk > 1) {
+    const size_t w = (size_t)splitk * c.Cout * B * (*Ho) * (*Wo);
+    (void)need;
+    int rc = ensure(&bb->ws, &bb->ws_elems, w);
+    if (rc) return rc;
+  }
+  d.tile = tile; d.splitk = splitk;
+  bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
+  return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, bb->ws, st);
+}
+
+extern "C" {
+
+int frtm_backbone_create(int arch, frtm_backbone_t** out) {
+  FRTM_CHECK_ARG(out, "frtm_backbone_create: null output");
+  int nb[4];
+  bool bott;
+  switch (arch) {
+    case 18: nb[0] = 2; nb[1] = 2; nb[2] = 2; nb[3] = 2; bott = false; break;
+    case 34: nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; bott = false; break;
+    case 50: nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; bott = true; break;
+    case 101: nb[0] = 3; nb[1] = 4; nb[2] = 23; nb[3] = 3; bott = true; break;
+    default: frtm_set_error("frtm_backbone_create: unknown arch resnet%d", arch); return FRTM_ERR_ARG;
+  }
+  frtm_backbone* bb = new frtm_backbone();
+  bb->arch = arch; bb->bottleneck = bott;
+  add_conv(bb, 64, 3, 7, 2);                                  // conv1 (+bn1)
+  int inpl = 64;
+  const int exp = bott ? 4 : 1;
+  bb->stages.resize(4);
+  for (int s = 0; s < 4; ++s) {
+    const int planes = 64 << s;
+    for (int b = 0; b < nb[s]; ++b) {
+      const int stride = (b == 0 && s > 0) ? 2 : 1;
+      BlockL bl;
+      if (bott) {                                             // v1.5: the stride sits on the 3x3
+        bl.conv[0] = add_conv(bb, planes, inpl, 1, 1);
+        bl.conv[1] = add_conv(bb, planes, planes, 3, stride);
+        bl.conv[2] = add_conv(bb, planes * 4, planes, 1, 1);
+        bl.nconv = 3;
+      } else {
+        bl.conv[0] = add_conv(bb, planes, inpl, 3, stride);
+        bl.conv[1] = add_conv(bb, planes, planes, 3, 1);
+        bl.conv[2] = -1;
+        bl.nconv = 2;
+      }
+      bl.ds = (b == 0 && (stride != 1 || inpl != planes * exp)) ? add_conv(bb, planes * exp, inpl, 1, stride) : -1;
+      bb->stages[s].push_back(bl);
+      inpl = planes * exp;
+    }
+  }
+  *out = bb;
+  return FRTM_OK;
+}
+
+int frtm_backbone_destroy(frtm_backbone_t* bb) {
+  if (!bb) return FRTM_OK;
+  for (auto& c : bb->convs) {
+    if (c.wT) (void)hipFree(c.wT);
+    if (c.scale) (void)hipFree(c.scale);
+    if (c.shift) (void)hipFree(c.shift);
+    if (c.ktab) (void)hipFree(c.ktab);
+  }
+  for (auto& b : bb->buf) if (b) (void)hipFree(b);
+  if (bb->ws) (void)hipFree(bb->ws);
+  if (bb->pack_tmp) (void)hipFree(bb->pack_tmp);
+  delete bb;
+  return FRTM_OK;
+}
+
+int frtm_backbone_num_convs(const frtm_backbone_t* bb) { return bb ? (int)bb->convs.size() : 0; }
+
+int frtm_backbone_conv_info(const frtm_backbone_t* bb, int idx, int* out6) {
+  FRTM_CHECK_ARG(bb && out6 && idx >= 0 && idx < (int)bb->convs.size(), "frtm_backbone_conv_info: bad index %d", idx);
+  const ConvL& c = bb->convs[idx];
+  out6[0] = c.Cout; out6[1] = c.Cin; out6[2] = c.ks; out6[3] = c.stride; out6[4] = c.pad; out6[5] = 0;
+  for (auto& st : bb->stages) for (auto& bl : st) if (bl.conv[bl.nconv - 1] == idx) out6[5] = 1;
+  return FRTM_OK;
+}
+
+int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, const float* bn_scale, const float* bn_shift,
+                           frtm_stream_t stream) {
+  FRTM_CHECK_ARG(bb && w_oihw && bn_scale && bn_shift && idx >= 0 && idx < (int)bb->convs.size(), "frtm_backbone_set_conv: bad argument");
+  ConvL& c = bb->convs[idx];
+  const size_t K = (size_t)c.Cin * c.ks * c.ks;
+  hipStream_t st = (hipStream_t)stream;
+  if (!c.wT) {
+    FRTM_HIP(hipMalloc((void**)&c.wT, K * c.Cout * sizeof(float)));
+    FRTM_HIP(hipMalloc((void**)&c.scale, c.Cout * sizeof(float)));
+    FRTM_HIP(hipMalloc((void**)&c.shift, c.Cout * sizeof(float)));
+    if (c.ks > 1) FRTM_HIP(hipMalloc((void**)&c.ktab, K * 3 * sizeof(int)));
+  }
+  int rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, c.ks, c.wT, c.ktab, stream);
+  if (rc) return rc;
+  FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  FRTM_HIP(hipMemcpyAsync(c.shift, bn_shift, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  c.loaded = true;
+  return FRTM_OK;
+}
+
+double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
+
+int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
+                          const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
+                          int stop_after_layer, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(bb && image_u8 && norm_scale3 && norm_bias3 && B > 0 && H >= 32 && W >= 32, "frtm_backbone_forward: bad argument");
+  FRTM_CHECK_ARG(stop_after_layer >= 1 && stop_after_layer <= 5, "frtm_backbone_forward: stop_after_layer must be 1..5");
+  hipStream_t st = (hipStream_t)stream;
+  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
+  const size_t need = (size_t)B * 64 * Hs * Ws;                 // the stem output is the largest activation
+  if (bb->buf_elems < need) {
+    for (auto& b : bb->buf) {
+      if (b) FRTM_HIP(hipFree(b));
+      b = nullptr;
+      FRTM_HIP(hipMalloc((void**)&b, need * sizeof(float)));
+    }
+    bb->buf_elems = need;
+  }
+  bb->last_flops = 0.0;
+  float* norm = bb->buf[0];
+  const size_t npx = (size_t)B * 3 * H * W;
+  k_normalize_u8<<<(int)min((npx + 255) / 256, (size_t)4096), 256, 0, st>>>(image_u8, H * W, norm_scale3, norm_bias3, norm, npx);
+  FRTM_LAUNCH_CHECK();
+  int h1, w1;
+  int rc = run_conv(bb, 0, B, H, W, norm, nullptr, 1, bb->buf[1], &h1, &w1, st);   // conv1 + bn1 + relu
+  if (rc) return rc;
+  const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
+  float* x = layer1 ? layer1 : bb->buf[2];
+  const size_t np = (size_t)B * 64 * Hp * Wp;
+  k_maxpool3s2<<<(int)min((np + 255) / 256, (size_t)4096), 256, 0, st>>>(bb->buf[1], h1, w1, Hp, Wp, x, np);
+  FRTM_LAUNCH_CHECK();
+  int ch = Hp, cw = Wp;
+  float* taps[4] = {layer2, layer3, layer4, layer5};
+  // scratch rotation: x lives in buf[2] or buf[3] (or a tap); t1,t2,t3 in buf[0],buf[1],buf[4]; buf[5] spare
+  for (int s = 0; s < 4 && (s + 2) <= stop_after_layer; ++s) {
+    const auto& blocks = bb->stages[s];
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const BlockL& bl = blocks[b];
+      const bool last = (b + 1 == blocks.size());
+      float* outp = (last && taps[s]) ? taps[s] : ((x == bb->buf[2]) ? bb->buf[3] : bb->buf[2]);
+      float* t1 = bb->buf[0];
+      float* t2 = bb->buf[1];
+      float* t3 = bb->buf[4];
+      int ho, wo, h2, w2, hd, wd;
+      const float* idn = x;
+      if (bl.ds >= 0) {
+        rc = run_conv(bb, bl.ds, B, ch, cw, x, nullptr, 0, t3, &hd, &wd, st);
+        if (rc) return rc;
+        idn = t3;
+      }
+      if (bl.nconv == 3) {
+        rc = run_conv(bb, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &ho, &wo, st);
+        if (rc) return rc;
+        rc = run_conv(bb, bl.conv[1], B, ho, wo, t1, nullptr, 1, t2, &h2, &w2, st);
+        if (rc) return rc;
+        rc = run_conv(bb, bl.conv[2], B, h2, w2, t2, idn, 1, outp, &ho, &wo, st);
+        if (rc) return rc;
+      } else {
+        rc = run_conv(bb, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &h2, &w2, st);
+        if (rc) return rc;
+        rc = run_conv(bb, bl.conv[1], B, h2, w2, t1, idn, 1, outp, &ho, &wo, st);
+        if (rc) return rc;
+      }
+      ch = ho; cw = wo;
+      x = outp;
+    }
+  }
+  return FRTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,690 @@
+// Target-model ("discriminator") kernels for gfx950: everything the per-frame update and the
+// CG inner loop touch.  All of it is HBM/L2-bandwidth-bound fp32 work, so the
+// rules here are coalesced 64-lane row access, LDS for the shared 30x54 maps, wave-shuffle
+// reductions with a fixed summation order (deterministic, no float atomics).
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// hinge pixel weights  (model/discriminator.py:120-150)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hinge_weights(float px, float HW, float tf, float& wf, float& wb) {
+  if (tf < 0.f) { wf = 1.f; wb = 1.f; return; }
+  float af = px / HW;
+  if (px < 10.f) af = tf;                 // :130-131
+  const float tfe = (af > tf) ? af : tf;  // :133-134
+  wf = tfe / af;                          // :136
+  wb = (1.f - tfe) / (1.f - af);          // :137
+}
+
+template <bool U8>
+__device__ __forceinline__ float load_label(const void* p, size_t i) {
+  if (U8) return (float)((const unsigned char*)p)[i];
+  return ((const float*)p)[i];
+}
+
+// partial[n][part] = sum over a slice of the sample of (threshold ? y>0.5 : y)
+template <bool U8, bool THRESH>
+__global__ __launch_bounds__(256) void k_label_sum(const void* __restrict__ y, int HW, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int n = blockIdx.y, part = blockIdx.x;
+  const size_t base = (size_t)n * HW;
+  const int per = (HW + FRTM_PX_PARTS - 1) / FRTM_PX_PARTS;
+  const int lo = part * per, hi = min(HW, lo + per);
+  float acc = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    float v = load_label<U8>(y, base + i);
+    if (THRESH) v = v > 0.5f ? 1.f : 0.f;
+    acc += v;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[n * FRTM_PX_PARTS + part] = acc;
+}
+
+__device__ __forceinline__ float sum_parts(const float* partial, int n) {
+  float px = 0.f;
+  for (int i = 0; i < FRTM_PX_PARTS; ++i) px += partial[n * FRTM_PX_PARTS + i];
+  return px;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void k_pixel_weights_map(const void* __restrict__ y, int HW, float tf,
+                                                            const float* __restrict__ partial, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  float wf, wb;
+  hinge_weights(sum_parts(partial, n), (float)HW, tf, wf, wb);
+  const size_t base = (size_t)n * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const float v = load_label<U8>(y, base + i);
+    out[base + i] = sqrtf(wf * v + wb * (1.f - v));      // :150-151
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Low-res normal equations: one wave per feature-grid cell (i,j) gathers the ~32x32 image pixels
+// whose bilinear support touches it.  ATen taps: src=max(scale*(d+.5)-.5,0), i0=(int)src,
+// i1=i0+(i0<n-1), l1=src-i0, l0=1-l1  (upsample_bilinear2d, align_corners=False).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void taps(int d, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  float src = __fsub_rn(__fmul_rn(scale, (float)d + 0.5f), 0.5f);   // no fma contraction: same rounding as ATen's scalar code
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__device__ __forceinline__ float tap_w(int k, int i0, int i1, float l0, float l1) {
+  return (k == i0 ? l0 : 0.f) + (k == i1 ? l1 : 0.f);
+}
+
+template <bool U8>
+__global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ labels, const float* __restrict__ pw, int H, int W, int h, int w, float tf,
+                                                       const float* __restrict__ partial, const int* __restrict__ slot_dev,
+                                                       int slot_host, float* __restrict__ Bmem, float* __restrict__ cmem) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int cell = blockIdx.x * 4 + wid;
+  if (cell >= h * w) return;
+  const int ci = cell / w, cj = cell % w;
+  float wf = 1.f, wb = 1.f;
+  if (!pw) hinge_weights(sum_parts(partial, n), (float)(H * W), tf, wf, wb);
+  const float* pwn = pw ? pw + (size_t)n * H * W : nullptr;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  // conservative pixel window of cell (ci,cj): source coordinate in [ci-1, ci+1)
+  const float fy = (float)H / (float)h, fx = (float)W / (float)w;
+  int Y0 = (int)floorf(fy * ((float)ci - 0.5f) - 0.5f) - 1, Y1 = (int)ceilf(fy * ((float)ci + 1.5f) - 0.5f) + 1;
+  int X0 = (int)floorf(fx * ((float)cj - 0.5f) - 0.5f) - 1, X1 = (int)ceilf(fx * ((float)cj + 1.5f) - 0.5f) + 1;
+  if (ci == 0) Y0 = 0;
+  if (cj == 0) X0 = 0;
+  if (ci == h - 1) Y1 = H;
+  if (cj == w - 1) X1 = W;
+  Y0 = max(Y0, 0); X0 = max(X0, 0); Y1 = min(Y1, H); X1 = min(X1, W);
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  const unsigned char* lb8 = (const unsigned char*)labels + (size_t)n * H * W;
+  const float* lbf = (const float*)labels + (size_t)n * H * W;
+  for (int Y = Y0 + (lane >> 5); Y < Y1; Y += 2) {
+    int yi0, yi1; float yl0, yl1;
+    taps(Y, sy, h, yi0, yi1, yl0, yl1);
+    const float wyc = tap_w(ci, yi0, yi1, yl0, yl1);
+    if (wyc == 0.f) continue;
+    const float wy0 = tap_w(ci - 1, yi0, yi1, yl0, yl1), wy2 = tap_w(ci + 1, yi0, yi1, yl0, yl1);
+    for (int X = X0 + (lane & 31); X < X1; X += 32) {
+      int xi0, xi1; float xl0, xl1;
+      taps(X, sx, w, xi0, xi1, xl0, xl1);
+      const float wxc = tap_w(cj, xi0, xi1, xl0, xl1);
+      if (wxc == 0.f) continue;
+      const float wx0 = tap_w(cj - 1, xi0, xi1, xl0, xl1), wx2 = tap_w(cj + 1, xi0, xi1, xl0, xl1);
+      const float lab = U8 ? (float)lb8[(size_t)Y * W + X] : lbf[(size_t)Y * W + X];
+      const float ys = lab > 0.5f ? 1.f : 0.f;
+      float w2 = wf * ys + wb * (1.f - ys);              // pw^2
+      if (pwn) { const float pv = pwn[(size_t)Y * W + X]; w2 = pv * pv; }
+      const float m = w2 * wyc * wxc;
+      const float my0 = m * wy0, myc = m * wyc, my2 = m * wy2;
+      acc[0] += my0 * wx0; acc[1] += my0 * wxc; acc[2] += my0 * wx2;
+      acc[3] += myc * wx0; acc[4] += myc * wxc; acc[5] += myc * wx2;
+      acc[6] += my2 * wx0; acc[7] += my2 * wxc; acc[8] += my2 * wx2;
+      acc[9] += m * lab;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+    const int slot = (slot_dev ? slot_dev[0] : slot_host) + n;
+    float* B = Bmem + (size_t)slot * 9 * h * w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B[(size_t)k * h * w + cell] = acc[k];
+    cmem[(size_t)slot * h * w + cell] = acc[9];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Memory.update_sample_weights on the device (model/memory.py:65-92).  One wave.
+// state[0] = previous replace index (-1 = None), state[1] = index chosen by this call.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state) {
+  const int lane = threadIdx.x;
+  int r_ind;
+  if (num_zero || lr == 1.f) {
+    for (int i = lane; i < cap; i += 64) sw[i] = (i == 0) ? 1.f : 0.f;
+    r_ind = 0;
+  } else {
+    // argmin, ties -> lowest index (CPU torch.min semantics, memory.py:80)
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < cap; i += 64) {
+      const float v = sw[i];
+      if (v < best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    r_ind = bi;
+    const int prev = state[0];
+    if (prev < 0) {
+      for (int i = lane; i < cap; i += 64) sw[i] = (i == r_ind) ? lr : sw[i] / (1.f - lr);    // :84-86
+    } else {
+      const float pv = sw[prev];
+      if (lane == 0) sw[r_ind] = pv / (1.f - lr);                                              // :88
+    }
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = lane; i < cap; i += 64) s += sw[i];
+  s = wave_sum(s);
+  for (int i = lane; i < cap; i += 64) sw[i] = sw[i] / s;                                      // :90
+  if (lane == 0) { state[0] = r_ind; state[1] = r_ind; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_memory_insert(const T* __restrict__ src, T* __restrict__ dst_base, int len,
+                                                        const int* __restrict__ slot) {
+  T* dst = dst_base + (size_t)slot[0] * len;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3 filter scores.  Block = 4 waves: the same 64 consecutive pixels, 4 channel quarters; LDS sum.
+// Reads X exactly once (coalesced rows; the 9 shifted taps of a row hit L1).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__ X, const float* __restrict__ f, int C, int h, int w,
+                                                        float* __restrict__ out, int accumulate) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hw = h * w;
+  const int p = blockIdx.x * 64 + lane;
+  const bool live = p < hw;
+  const int py = live ? p / w : 0, px = live ? p % w : 0;
+  bool ok[9]; int off[9];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = py + dy - 1, xx = px + dx - 1;
+      const bool v = live && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+      ok[dy * 3 + dx] = v;
+      off[dy * 3 + dx] = v ? yy * w + xx : 0;
+    }
+  const int cper = (C + 3) / 4;
+  const int c0 = wid * cper, c1 = min(C, c0 + cper);
+  const float* Xn = X + (size_t)n * C * hw;
+  float acc = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    const float* Xc = Xn + (size_t)c * hw;
+    const float* fc = f + c * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float v = Xc[off[k]];
+      acc += (ok[k] ? v : 0.f) * fc[k];
+    }
+  }
+  red[wid][lane] = acc;
+  __syncthreads();
+  if (wid == 0 && live) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float* o = out + (size_t)n * hw + p;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+
+// t = sw[n] * (B s - c): elementwise with a 3x3 neighbourhood of s.
+__global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ B, const float* __restrict__ c, const float* __restrict__ sw,
+                                                  const float* __restrict__ s, int h, int w, float* __restrict__ t) {
+  const int n = blockIdx.y, hw = h * w;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int py = p / w, px = p % w;
+  const float* Bn = B + (size_t)n * 9 * hw;
+  const float* sn = s + (size_t)n * hw;
+  float acc = 0.f;
+#pragma unroll
+  for (int di = 0; di < 3; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 3; ++dj) {
+      const int yy = py + di - 1, xx = px + dj - 1;
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) acc += Bn[(size_t)(di * 3 + dj) * hw + p] * sn[yy * w + xx];
+    }
+  if (c) acc -= c[(size_t)n * hw + p];
+  t[(size_t)n * hw + p] = sw[n] * acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Filter weight gradient.  g[c,dy,dx] = sum_q X[c,q] * t[q - (dy-1,dx-1)]: every X element is read
+// once (coalesced) and multiplied with the 9 shifted values of t, which sits zero-padded in LDS.
+// Block = (sample n, 16 channels): 4 waves x 4 channels, 36 accumulators per lane, then wave sums.
+// ------------------------------------------------------------------------------------------
+#define WG_CH 4
+__global__ __launch_bounds__(256) void k_filter_wgrad(const float* __restrict__ X, const float* __restrict__ t, int C, int h, int w,
+                                                       float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];      // (h+2) x (w+2), zero border
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hw = h * w, wp = w + 2;
+  for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
+    const int yy = i / wp - 1, xx = i % wp - 1;
+    tl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? t[(size_t)n * hw + yy * w + xx] : 0.f;
+  }
+  __syncthreads();
+  const int cbase = blockIdx.x * (4 * WG_CH) + wid * WG_CH;
+  if (cbase >= C) return;
+  const float* Xc[WG_CH];
+#pragma unroll
+  for (int k = 0; k < WG_CH; ++k) Xc[k] = X + ((size_t)n * C + min(cbase + k, C - 1)) * hw;
+  float acc[WG_CH][9];
+#pragma unroll
+  for (int k = 0; k < WG_CH; ++k)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[k][j] = 0.f;
+  int qy = lane / w, qx = lane % w;
+  for (int q = lane; q < hw; q += 64) {
+    float tv[9];
+    const float* tc = tl + (qy + 1) * wp + (qx + 1);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) tv[dy * 3 + dx] = tc[-(dy - 1) * wp - (dx - 1)];
+#pragma unroll
+    for (int k = 0; k < WG_CH; ++k) {
+      const float xv = Xc[k][q];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[k][j] += xv * tv[j];
+    }
+    qx += 64;
+    while (qx >= w) { qx -= w; ++qy; }
+  }
+#pragma unroll
+  for (int k = 0; k < WG_CH; ++k)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[k][j] = wave_sum(acc[k][j]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < WG_CH; ++k)
+      if (cbase + k < C)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) partial[((size_t)n * C + cbase + k) * 9 + j] = acc[k][j];
+  }
+}
+
+// D[n,c,q] = sum_taps f[c,tap] * t[q - off(tap)]
+__global__ __launch_bounds__(256) void k_filter_igrad(const float* __restrict__ t, const float* __restrict__ f, int C, int h, int w,
+                                                       float* __restrict__ D, int pix_major) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];
+  const int n = blockIdx.y, hw = h * w, wp = w + 2;
+  for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
+    const int yy = i / wp - 1, xx = i % wp - 1;
+    tl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? t[(size_t)n * hw + yy * w + xx] : 0.f;
+  }
+  __syncthreads();
+  const int total = C * hw;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int c, q;
+    if (pix_major) { q = i / C; c = i % C; } else { c = i / hw; q = i % hw; }
+    const int qy = q / w, qx = q % w;
+    const float* tc = tl + (qy + 1) * wp + (qx + 1);
+    const float* fc = f + c * 9;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) acc += fc[dy * 3 + dx] * tc[-(dy - 1) * wp - (dx - 1)];
+    D[(size_t)n * total + i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CG vector steps.  FRTM_CG_BLOCKS blocks of 256 threads, contiguous slices, fixed-order sums.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slice(int n, int& lo, int& hi) {
+  const int per = (n + gridDim.x - 1) / gridDim.x;
+  lo = blockIdx.x * per;
+  hi = min(n, lo + per);
+}
+__device__ __forceinline__ float sum_partials(const float* partial, int stride, int which) {
+  float s = 0.f;
+  for (int i = 0; i < FRTM_CG_BLOCKS; ++i) s += partial[i * stride + which];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_vec_reduce_slabs(const float* __restrict__ slabs, int nslab, int stride, int len, float lam2,
+                                                           const float* __restrict__ p, float sign, float* __restrict__ q) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * stride + i];
+    if (p) s += lam2 * p[i];
+    q[i] = sign * s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cg_begin(const float* __restrict__ b, float* __restrict__ r, const float* __restrict__ r_prev,
+                                                   int n1, int n2, float invM1, float invM2, int has_p, float* __restrict__ partial) {
+  __shared__ float red[16];
+  int lo, hi; slice(n1 + n2, lo, hi);
+  float d0 = 0.f, d1 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float rv = b[i];
+    r[i] = rv;
+    const float z = rv * (i < n1 ? invM1 : invM2);
+    d0 += rv * z;
+    if (has_p) d1 += r_prev[i] * z;
+  }
+  d0 = block_sum(d0, red);
+  d1 = block_sum(d1, red);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = d0; partial[blockIdx.x * 2 + 1] = d1; }
+}
+
+__global__ __launch_bounds__(256) void k_cg_direction(const float* __restrict__ r, float* __restrict__ p, int n1, int n2, float invM1,
+                                                       float invM2, int has_p, int apply_dff, int fr, float dff, float* __restrict__ state,
+                                                       const float* __restrict__ partial) {
+  const float rho_new = sum_partials(partial, 2, 0);
+  float beta = 0.f;
+  if (has_p) {
+    const float rho2 = sum_partials(partial, 2, 1);
+    float rho1 = state[0];
+    if (apply_dff) rho1 = rho1 / dff;                        // optimizer.py:102-105 (may overflow to inf, literal)
+    const float v = fr ? rho_new / rho1 : (rho_new - rho2) / rho1;   // Fletcher-Reeves :124 | Polak-Ribiere :126-127
+    beta = (v < 0.f) ? 0.f : v;                              // clamp(0), NaN propagates like torch
+  }
+  int lo, hi; slice(n1 + n2, lo, hi);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float z = r[i] * (i < n1 ? invM1 : invM2);
+    p[i] = has_p ? (z + p[i] * beta) : z;                    // :120,130
+  }
+  // every block read state[0] above; only publish after all reads of THIS launch are done is not
+  // guaranteed across blocks, so rho goes to a different word and is rotated by k_cg_update/begin.
+  if (blockIdx.x == 0 && threadIdx.x == 0) { state[4] = rho_new; state[2] = beta; }
+}
+
+__global__ __launch_bounds__(256) void k_cg_pq(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ r, int n,
+                                                float* __restrict__ partial) {
+  __shared__ float red[16];
+  int lo, hi; slice(n, lo, hi);
+  float d = 0.f, e = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) { d += p[i] * q[i]; if (r) e += p[i] * r[i]; }
+  d = block_sum(d, red);
+  e = block_sum(e, red);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = d; partial[blockIdx.x * 2 + 1] = e; }
+}
+
+__global__ __launch_bounds__(256) void k_cg_update(float* __restrict__ x, float* __restrict__ r, float* __restrict__ r_prev,
+                                                    const float* __restrict__ p, const float* __restrict__ q, int n1, int n2, float invM1,
+                                                    float invM2, int first, int last, int std_alpha, float* __restrict__ state, float* __restrict__ partial) {
+  __shared__ float red[16];
+  __shared__ float sh_alpha;
+  // k_cg_direction left rho_new in state[4]; it is the rho of this iteration (optimizer.py:116)
+  if (threadIdx.x == 0) {
+    const float pq = sum_partials(partial, 2, 0);
+    const float rho = state[4];
+    sh_alpha = std_alpha ? rho / pq : sum_partials(partial, 2, 1) / pq;   // :135-138
+  }
+  __syncthreads();
+  const float alpha = sh_alpha;
+  __syncthreads();
+  int lo, hi; slice(n1 + n2, lo, hi);
+  float d0 = 0.f, d1 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float rv = r[i], pv = p[i];
+    r_prev[i] = rv;                                           // :141-142
+    x[i] = first ? pv * alpha : x[i] + pv * alpha;            // :145-148
+    float rn = rv;
+    if (!last) { rn = rv - q[i] * alpha; r[i] = rn; }         // :150-151
+    const float z = rn * (i < n1 ? invM1 : invM2);
+    d0 += rn * z;
+    d1 += rv * z;
+  }
+  d0 = block_sum(d0, red);
+  d1 = block_sum(d1, red);
+  __syncthreads();
+  // all blocks have consumed partial[*][0] (pq) only after this kernel ends, so the new dots go
+  // to a second bank and the host alternates banks between launches.
+  if (threadIdx.x == 0) {
+    float* nxt = partial + 2 * FRTM_CG_BLOCKS;
+    nxt[blockIdx.x * 2] = d0; nxt[blockIdx.x * 2 + 1] = d1;
+    if (blockIdx.x == 0) { state[0] = state[4]; state[1] = alpha; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vec_axpy(float* __restrict__ y, float a, const float* __restrict__ x, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(256) void k_transpose2d(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    tile[k][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = bx + k, r = by + tx;
+    if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tracker.track mask merge (model/tracker.py:214-221) and the "fewer than 10 px" count (disc :214)
+// ------------------------------------------------------------------------------------------
+#define MERGE_MAX 16
+__global__ __launch_bounds__(256) void k_merge_masks(float* __restrict__ masks, int K, int HW) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float p[MERGE_MAX];
+    float bg = INFINITY;
+    for (int k = 1; k < K; ++k) {
+      float v = masks[(size_t)k * HW + i];
+      v = fminf(fmaxf(v, 1e-7f), 1.f - 1e-7f);
+      p[k] = v;
+      bg = fminf(bg, 1.f - v);
+    }
+    p[0] = bg;                                               // :215
+    float mx = -INFINITY; int arg = 0;
+    for (int k = 0; k < K; ++k) { p[k] = p[k] / (1.f - p[k]); if (p[k] > mx) { mx = p[k]; arg = k; } }
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) { p[k] = expf(p[k] - mx); den += p[k]; }
+    for (int k = 0; k < K; ++k) masks[(size_t)k * HW + i] = (k == arg) ? p[k] / den : 0.f;   // :216-221
+  }
+}
+
+__global__ __launch_bounds__(256) void k_count_above(const float* __restrict__ masks, int HW, float thr, int* __restrict__ count) {
+  const int k = blockIdx.y;
+  int c = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) c += masks[(size_t)k * HW + i] > thr ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&count[k], c);   // integer atomics: order independent
+}
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+static thread_local char g_err[512] = "";
+void frtm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* frtm_last_error(void) { return g_err; }
+int frtm_version(void) { return 100; }
+
+int frtm_device_info(int* out) {
+  FRTM_CHECK_ARG(out, "frtm_device_info: null output");
+  int dev = 0;
+  FRTM_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t pr;
+  FRTM_HIP(hipGetDeviceProperties(&pr, dev));
+  out[0] = pr.multiProcessorCount;
+  int arch = 0;
+  if (sscanf(pr.gcnArchName, "gfx%d", &arch) != 1) arch = 0;
+  out[1] = arch;
+  out[2] = (int)pr.sharedMemPerBlock;
+  out[3] = pr.warpSize;
+  return FRTM_OK;
+}
+
+static int label_sum(const void* y, int u8, int thresh, int n, int HW, float* scratch, hipStream_t st) {
+  dim3 g(FRTM_PX_PARTS, n);
+  if (u8) { if (thresh) k_label_sum<true, true><<<g, 256, 0, st>>>(y, HW, scratch); else k_label_sum<true, false><<<g, 256, 0, st>>>(y, HW, scratch); }
+  else    { if (thresh) k_label_sum<false, true><<<g, 256, 0, st>>>(y, HW, scratch); else k_label_sum<false, false><<<g, 256, 0, st>>>(y, HW, scratch); }
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_pixel_weights(const void* y, int y_is_u8, int n, int H, int W, float tf, float* out, float* scratch, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(y && out && scratch && n > 0 && H > 0 && W > 0, "frtm_pixel_weights: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = label_sum(y, y_is_u8, 0, n, H * W, scratch, st);
+  if (rc) return rc;
+  dim3 g(min(ceil_div(H * W, 256), 512), n);
+  if (y_is_u8) k_pixel_weights_map<true><<<g, 256, 0, st>>>(y, H * W, tf, scratch, out);
+  else k_pixel_weights_map<false><<<g, 256, 0, st>>>(y, H * W, tf, scratch, out);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int n, int H, int W, int h, int w, float tf,
+                      const int* slot_dev, int slot_host, float* Bmem, float* cmem, float* scratch, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(labels && Bmem && cmem && scratch && n > 0, "frtm_normal_build: bad argument");
+  FRTM_CHECK_ARG(h >= 1 && w >= 1 && H >= h && W >= w, "frtm_normal_build: needs H>=h, W>=w (got %dx%d -> %dx%d)", h, w, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  if (!pw) {
+    int rc = label_sum(labels, labels_is_u8, 1, n, H * W, scratch, st);
+    if (rc) return rc;
+  }
+  dim3 g(ceil_div(h * w, 4), n);
+  if (labels_is_u8) k_normal_build<true><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem);
+  else k_normal_build<false><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_memory_next_slot(float* sw, int cap, float lr, int num_samp_is_zero, int* state, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(sw && state && cap > 0, "frtm_memory_next_slot: bad argument");
+  k_memory_next_slot<<<1, 64, 0, (hipStream_t)stream>>>(sw, cap, lr, num_samp_is_zero, state);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_memory_insert(const float* src, float* dst_base, int len, const int* slot_dev, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(src && dst_base && slot_dev && len > 0, "frtm_memory_insert: bad argument");
+  const bool vec = (len % 4 == 0) && (((size_t)src | (size_t)dst_base) % 16 == 0);
+  if (vec) k_memory_insert<float4><<<min(ceil_div(len / 4, 256), 256), 256, 0, (hipStream_t)stream>>>((const float4*)src, (float4*)dst_base, len / 4, slot_dev);
+  else k_memory_insert<float><<<min(ceil_div(len, 256), 256), 256, 0, (hipStream_t)stream>>>(src, dst_base, len, slot_dev);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w, float* out, int accumulate, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && f && out && N > 0 && C > 0 && h > 0 && w > 0, "frtm_filter_scores: bad argument");
+  dim3 g(ceil_div(h * w, 64), N);
+  k_filter_scores<<<g, 256, 0, (hipStream_t)stream>>>(X, f, C, h, w, out, accumulate);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_stencil(const float* B, const float* c, const float* sw, const float* s, int N, int h, int w, float* t, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(B && sw && s && t && N > 0, "frtm_stencil: bad argument");
+  dim3 g(ceil_div(h * w, 256), N);
+  k_stencil<<<g, 256, 0, (hipStream_t)stream>>>(B, c, sw, s, h, w, t);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && t && partial && N > 0 && C > 0, "frtm_filter_wgrad: bad argument");
+  const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_wgrad: feature grid %dx%d too large for the LDS tile", h, w);
+  dim3 g(ceil_div(C, 4 * WG_CH), N);
+  k_filter_wgrad<<<g, 256, lds, (hipStream_t)stream>>>(X, t, C, h, w, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_filter_igrad(const float* t, const float* f, int N, int C, int h, int w, float* D, int pix_major, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(t && f && D && N > 0 && C > 0, "frtm_filter_igrad: bad argument");
+  const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_igrad: feature grid %dx%d too large for the LDS tile", h, w);
+  dim3 g(min(ceil_div(C * h * w, 256 * 4), 64), N);
+  k_filter_igrad<<<g, 256, lds, (hipStream_t)stream>>>(t, f, C, h, w, D, pix_major);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_vec_reduce_slabs(const float* slabs, int nslab, int stride, int len, float lam2, const float* p, float sign, float* q,
+                          frtm_stream_t stream) {
+  FRTM_CHECK_ARG(slabs && q && nslab > 0 && len > 0, "frtm_vec_reduce_slabs: bad argument");
+  k_vec_reduce_slabs<<<min(ceil_div(len, 256), 512), 256, 0, (hipStream_t)stream>>>(slabs, nslab, stride, len, lam2, p, sign, q);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cg_begin(const float* b, float* r, const float* r_prev, int n1, int n2, float invM1, float invM2, int has_p, float* partial,
+                  frtm_stream_t stream) {
+  FRTM_CHECK_ARG(b && r && partial && n1 > 0 && n2 >= 0 && (!has_p || r_prev), "frtm_cg_begin: bad argument");
+  k_cg_begin<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(b, r, r_prev, n1, n2, invM1, invM2, has_p, partial + 2 * FRTM_CG_BLOCKS);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cg_direction(const float* r, float* p, int n1, int n2, float invM1, float invM2, int has_p, int apply_dff,
+                      int fletcher_reeves, float dff, float* state, const float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(r && p && state && partial, "frtm_cg_direction: bad argument");
+  k_cg_direction<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(r, p, n1, n2, invM1, invM2, has_p, apply_dff, fletcher_reeves, dff, state,
+                                                                    partial + 2 * FRTM_CG_BLOCKS);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cg_pq(const float* p, const float* q, const float* r, int n, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(p && q && partial && n > 0, "frtm_cg_pq: bad argument");
+  k_cg_pq<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(p, q, r, n, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const float* q, int n1, int n2, float invM1, float invM2,
+                   int first, int last, int standard_alpha, float* state, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(x && r && r_prev && p && q && state && partial, "frtm_cg_update: bad argument");
+  k_cg_update<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(x, r, r_prev, p, q, n1, n2, invM1, invM2, first, last, standard_alpha, state, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_vec_axpy(float* y, float a, const float* x, int n, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(y && x && n > 0, "frtm_vec_axpy: bad argument");
+  k_vec_axpy<<<min(ceil_div(n, 256), 512), 256, 0, (hipStream_t)stream>>>(y, a, x, n);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_transpose2d(const float* in, int rows, int cols, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(in && out && rows > 0 && cols > 0, "frtm_transpose2d: bad argument");
+  dim3 g(ceil_div(cols, 32), ceil_div(rows, 32));
+  k_transpose2d<<<g, 256, 0, (hipStream_t)stream>>>(in, rows, cols, out);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(masks && n_plus_1 >= 2 && n_plus_1 <= MERGE_MAX && HW > 0, "frtm_merge_masks: needs 2..%d mask planes, got %d", MERGE_MAX, n_plus_1);
+  k_merge_masks<<<min(ceil_div(HW, 256), 1024), 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(masks && count && n > 0 && HW > 0, "frtm_count_above: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  FRTM_HIP(hipMemsetAsync(count, 0, sizeof(int) * n, st));
+  dim3 g(min(ceil_div(HW, 256), 128), n);
+  k_count_above<<<g, 256, 0, st>>>(masks, HW, thr, count);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Model construction with the reference's hyper-parameters (evaluate.py:26-105).
+
+``Parameters(weights, fast, device).get_model()`` builds the Tracker exactly like the reference.
+Deviation, on purpose: the reference's __main__ parses --fast/--dev but never passes them on
+(evaluate.py:155 vs :28,46-51); here they take their documented meaning (README.md:108).
+"""
+import torch
+
+from .model.augmenter import ImageAugmenter
+from .model.feature_extractor import ResnetFeatureExtractor
+from .model.seg_network import SegNetwork
+from .model.tracker import Tracker
+
+
+class AttrDict(dict):
+    """dict with attribute access (easydict is not installed); supports ** and '.' like evaluate.py needs."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class Parameters:
+
+    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None):
+        self.device = device
+        self.weights = weights
+        self.num_aug = 5
+        self.train_skipping = 8
+        self.learning_rate = 0.1
+        if weights is not None:                                   # autodetect from the refiner checkpoint (:38-44)
+            self.in_channels = weights['refiner.TSE.layer4.reduce.0.weight'].shape[1]
+            if self.in_channels == 1024:
+                self.feature_extractor = 'resnet101'
+            elif self.in_channels == 256:
+                self.feature_extractor = 'resnet18'
+            else:
+                raise ValueError
+        else:
+            self.feature_extractor = feature_extractor or 'resnet101'
+            self.in_channels = {'resnet101': 1024, 'resnet50': 1024, 'resnet18': 256, 'resnet34': 256}[self.feature_extractor]
+        self.backbone_weights = backbone_weights
+        if fast:
+            self.init_iters, self.update_iters = (5, 10, 10, 10), (5,)
+        else:
+            self.init_iters, self.update_iters = (5, 10, 10, 10, 10), (10,)
+        self.aug_params = AttrDict(
+            num_aug=self.num_aug, min_px_count=1,
+            fg_aug_params=AttrDict(
+                rotation=[5, -5, 10, -10, 20, -20, 30, -30, 45, -45], fliplr=[False, False, False, False, True],
+                scale=[0.5, 0.7, 1.0, 1.5, 2.0, 2.5], skew=[(0.0, 0.0), (0.0, 0.0), (0.1, 0.1)],
+                blur_size=[0.0, 0.0, 0.0, 2.0], blur_angle=[0, 45, 90, 135]),
+            bg_aug_params=AttrDict(
+                tcenter=[(0.5, 0.5)], rotation=[0, 0, 0], fliplr=[False], scale=[1.0, 1.0, 1.2], skew=[(0.0, 0.0)],
+                blur_size=[0.0, 0.0, 1.0, 2.0, 5.0], blur_angle=[0, 45, 90, 135]))
+        self.disc_params = AttrDict(
+            layer='layer4', in_channels=self.in_channels, c_channels=96, out_channels=1,
+            init_iters=self.init_iters, update_iters=self.update_iters,
+            memory_size=80, train_skipping=self.train_skipping, learning_rate=self.learning_rate,
+            pixel_weighting=dict(method='hinge', tf=0.1),
+            filter_reg=(1e-4, 1e-2), precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=750,
+            device=self.device, update_filters=True)
+        self.refnet_params = AttrDict(layers=('layer5', 'layer4', 'layer3', 'layer2'), nchannels=64, use_batch_norm=True)
+
+    def get_model(self):
+        augmenter = ImageAugmenter(self.aug_params)
+        extractor = ResnetFeatureExtractor(self.feature_extractor, weights=self.backbone_weights).to(self.device)
+        self.disc_params.in_channels = extractor.get_out_channels()[self.disc_params.layer]
+        p = self.refnet_params
+        chans = {L: n for L, n in extractor.get_out_channels().items() if L in p.layers}
+        refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
+        if self.weights is None:
+            torch.manual_seed(1)                                   # seeded default init
+            refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
+        mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device)
+        if self.weights is not None:
+            mdl.load_state_dict(self.weights)
+        mdl.to(self.device)
+        return mdl

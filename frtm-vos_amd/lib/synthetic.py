@@ -1,0 +1,94 @@
+"""Synthetic video sequences with the interface of the reference's FileSequence (lib/datasets.py:16-90):
+iteration yields (image uint8 (3,H,W), labels uint8 (1,H,W) or [], new_object_ids), plus ``obj_ids``,
+``frame_names``, ``preload(device)``, ``__getitem__``.  No dataset exists on the build/GPU boxes, so
+bench.py and the tests run on these (low-pass random texture + textured rectangles moving
+2-6 px per frame; seeds recorded)."""
+import torch
+import torch.nn.functional as F
+
+
+class SyntheticSequence:
+
+    def __init__(self, name='synth', n_frames=40, size=(480, 854), n_objects=1, seed=1, late_object_at=None,
+                 device='cpu'):
+        self.name = name
+        self.obj_ids = list(range(1, n_objects + 1))
+        self.frame_names = ['%05d' % i for i in range(n_frames)]
+        self.size = size
+        self.late = late_object_at
+        g = torch.Generator().manual_seed(seed)
+        H, W = size
+        bg = torch.rand(1, 3, H + 8, W + 8, generator=g) * 255
+        bg = F.avg_pool2d(bg, 9, 1)[0]                                   # 9x9 box low-pass, (3,H,W)
+        frames, labels = [], []
+        objs = []
+        for k in range(n_objects):
+            oh = int(torch.randint(H // 8, H // 3, (1,), generator=g))
+            ow = int(torch.randint(W // 10, W // 4, (1,), generator=g))
+            y0 = int(torch.randint(0, H - oh, (1,), generator=g))
+            x0 = int(torch.randint(0, W - ow, (1,), generator=g))
+            vy = float(torch.randint(2, 7, (1,), generator=g)) * (1 if torch.rand(1, generator=g) > 0.5 else -1)
+            vx = float(torch.randint(2, 7, (1,), generator=g)) * (1 if torch.rand(1, generator=g) > 0.5 else -1)
+            tex = torch.rand(3, oh, ow, generator=g) * 255 * 0.5 + torch.rand(3, 1, 1, generator=g) * 127
+            objs.append([float(y0), float(x0), vy, vx, oh, ow, tex])
+        for t in range(n_frames):
+            im = bg.clone()
+            lb = torch.zeros(1, H, W, dtype=torch.uint8)
+            for k, o in enumerate(objs):
+                y, x, vy, vx, oh, ow, tex = o
+                yi, xi = int(round(y)), int(round(x))
+                im[:, yi:yi + oh, xi:xi + ow] = tex
+                lb[:, yi:yi + oh, xi:xi + ow] = k + 1
+                y, x = y + vy, x + vx
+                if y < 0 or y + oh >= H:
+                    vy = -vy
+                    y = min(max(y, 0), H - oh - 1)
+                if x < 0 or x + ow >= W:
+                    vx = -vx
+                    x = min(max(x, 0), W - ow - 1)
+                o[0], o[1], o[2], o[3] = y, x, vy, vx
+            frames.append(im.clamp(0, 255).to(torch.uint8))
+            labels.append(lb)
+        self.images = frames
+        self.gt = labels
+        self.device = device
+
+    def preload(self, device):
+        self.images = [im.to(device) for im in self.images]
+        self.gt = [lb.to(device) for lb in self.gt]
+        self.device = device
+
+    def __len__(self):
+        return len(self.images)
+
+    def start_frame(self, obj_id):
+        if self.late is not None and obj_id == self.obj_ids[-1]:
+            return self.late
+        return 0
+
+    def __getitem__(self, i):
+        new = [o for o in self.obj_ids if self.start_frame(o) == i]
+        if new:
+            lb = self.gt[i].clone()
+            keep = torch.zeros_like(lb, dtype=torch.bool)
+            for o in new:
+                keep |= lb == o
+            lb = lb * keep.to(lb.dtype)
+            return self.images[i], lb, new
+        return self.images[i], [], []
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class SyntheticDataset:
+    def __init__(self, name, sequences):
+        self.name = name
+        self.sequences = sequences
+
+    def __len__(self):
+        return len(self.sequences)
+
+    def __iter__(self):
+        return iter(self.sequences)

@@ -1,0 +1,263 @@
+"""Online discriminative target model (API of the reference's model/discriminator.py:11-227).
+
+Same public surface -- ``Discriminator(**disc_params)``, ``init(x, y)``, ``apply(ft)``,
+``update(train_y)``, ``compute_pixel_weights(y)``, state dict {project.weight, filter.weight} --
+but every tensor op is a hand-written gfx950 kernel reached through libfrtm_hip.so:
+
+  apply      1x1 projection = fp32 MFMA GEMM (frtm_conv2d) + fused 3x3 score kernel
+  update     memory insert = slot argmin + feature copy + low-res normal-equation build, no host sync
+  solver     explicit J^T J in low-resolution form:
+             A p = wgrad3x3(X, sw * B(X * p)) + lam^2 p,   b = -(wgrad3x3(X, sw*(B(X*w) - c)) + lam^2 w)
+             where B, c are the per-sample stencil/offset kept by model/memory.py.  The reference's
+             residual is full-resolution (discriminator.py:47-49); B = U^T W^2 U and c = U^T W^2 y fold
+             the bilinear up-sampling U and the pixel weights W into the 30x54 grid exactly.
+  init       joint problem over (project, filter): the two 1x1 GEMMs per operator application
+             (forward conv and weight gradient) run on the MFMA conv kernel, K = Cin resp. K = 5*h*w.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _hip as H
+from .. import ops
+from ..lib.tensorlist import TensorList
+from ..lib.utils import conv
+from .memory import Memory
+from .optimizer import GaussNewtonCG, MinimizationProblem
+
+
+class DiscriminatorLoss(MinimizationProblem):
+    """Least-squares problem over the sample memory with explicit HIP operators.
+
+    joint=False: variable [filter.weight (1,c,3,3)], data = memory.samples (projected features)
+    joint=True:  variables [project.weight (c,Cin,1,1), filter.weight], data = raw backbone features.
+    Flat vector layout used by the solver: [ project^T as (Cin,c) | filter as (c,9) ].
+    """
+
+    def __init__(self, memory: Memory, filter_regs, precond, filter_weight, project_weight=None):
+        super().__init__()
+        self.mem = memory
+        self.joint = project_weight is not None
+        self.w1, self.w2 = project_weight, filter_weight
+        self.filter_regs = TensorList([float(v) for v in filter_regs])
+        self.diag_M = TensorList([float(v) for v in precond])
+        assert len(filter_regs) == (2 if self.joint else 1)
+        cap = memory.capacity
+        C, h, w = memory.samples.shape[1:]
+        self.h, self.w, self.hw = h, w, h * w
+        self.c = filter_weight.shape[1]
+        dev = memory.samples.device
+        self.s = torch.empty(cap, self.hw, device=dev)
+        self.t = torch.empty(cap, self.hw, device=dev)
+        self.partial = torch.empty(cap, self.c * 9, device=dev)
+        self.N = 0
+        if self.joint:
+            self.Cin = C
+            self.Z = torch.empty(cap, self.c, h, w, device=dev)
+            self.P = torch.empty(cap, self.c, h, w, device=dev)
+            self.D = torch.empty(cap, self.hw, self.c, device=dev)
+            self.Xt = torch.empty(cap, self.hw, C, device=dev)       # NHWC copy of the raw features
+            self.w1T = torch.empty(C, self.c, device=dev)
+            self.g1 = torch.empty(C * self.c, device=dev)
+            self._xt_for = None
+
+    # ---- protocol -----------------------------------------------------------------------
+    def initialize(self):
+        """Active samples = the first current_size slots (reference discriminator.py:38-43 selects
+        weight > 0; slots fill in index order and weights stay positive, so the two coincide)."""
+        self.N = self.mem.current_size
+        if self.joint and self._xt_for != (self.mem.samples.data_ptr(), self.N):
+            for n in range(self.N):
+                ops.transpose2d(self.mem.samples[n].view(self.Cin, self.hw), out=self.Xt[n])
+            self._xt_for = (self.mem.samples.data_ptr(), self.N)
+
+    def vector_layout(self):
+        if self.joint:
+            return self.Cin * self.c, self.c * 9, self.diag_M[0], self.diag_M[1]
+        return self.c * 9, 0, self.diag_M[0], 1.0
+
+    def views(self, flat):
+        if self.joint:
+            n1 = self.Cin * self.c
+            return TensorList([flat[:n1].view(self.Cin, self.c).t().reshape(self.c, self.Cin, 1, 1),
+                               flat[n1:].view(1, self.c, 3, 3)])
+        return TensorList([flat.view(1, self.c, 3, 3)])
+
+    # ---- operator pieces ----------------------------------------------------------------
+    def _stencil(self, with_c):
+        m = self.mem
+        H.call('frtm_stencil', H.ptr(m.normal_B), H.ptr(m.normal_c) if with_c else None, H.ptr(m.weights),
+               H.ptr(self.s), self.N, self.h, self.w, H.ptr(self.t))
+
+    def _filter_grad(self, feats, lam2, pvec, sign, out):
+        H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, H.ptr(self.partial))
+        H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N, self.c * 9, self.c * 9, lam2, pvec, sign, out)
+
+    def _project_grad(self, lam2, pvec, sign, out):
+        """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
+        H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)
+        ops.conv2d(self.Xt, self.D, self.c, out=self.g1, out_transposed=True, shape=(1, self.N * self.hw, 1, self.Cin))
+        H.call('frtm_vec_reduce_slabs', H.ptr(self.g1), 1, 0, self.Cin * self.c, lam2, pvec, sign, out)
+
+    def linearize(self, x, b):
+        """b <- -(J^T f(x) + lam^2 x)   (reference optimizer.py:80-85 via autograd)."""
+        N, c = self.N, self.c
+        if not self.joint:
+            ops.filter_scores(self.mem.samples, self.w2.data, out=self.s, n=N)
+            self._stencil(True)
+            self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b))
+            return
+        n1 = self.Cin * c
+        ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
+        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w))
+        ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
+        self._stencil(True)
+        self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
+        self._project_grad(self.filter_regs[0] ** 2, H.ptr(self.w1T), -1.0, H.ptr(b[:n1]))
+
+    def apply_A(self, p, q):
+        """q <- J^T J p + lam^2 p   (reference optimizer.py:155-157 via double backward)."""
+        N, c = self.N, self.c
+        if not self.joint:
+            ops.filter_scores(self.mem.samples, p, out=self.s, n=N)
+            self._stencil(False)
+            self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(p), 1.0, H.ptr(q))
+            return
+        n1 = self.Cin * c
+        p1, p2 = p[:n1], p[n1:]
+        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w))
+        ops.filter_scores(self.P, self.w2.data, out=self.s, n=N)
+        ops.filter_scores(self.Z, p2, out=self.s, n=N, accumulate=True)
+        self._stencil(False)
+        self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(p2), 1.0, H.ptr(q[n1:]))
+        self._project_grad(self.filter_regs[0] ** 2, H.ptr(p1), 1.0, H.ptr(q[:n1]))
+
+    def apply_step(self, x, step, delta):
+        """x += step * delta  (reference optimizer.py:89-90), un-transposing the projection part."""
+        c = self.c
+        if not self.joint:
+            H.call('frtm_vec_axpy', H.ptr(self.w2.data), step, H.ptr(delta), c * 9)
+            return
+        n1 = self.Cin * c
+        d1 = ops.transpose2d(delta[:n1].view(self.Cin, c))
+        H.call('frtm_vec_axpy', H.ptr(self.w1.data), step, H.ptr(d1), n1)
+        H.call('frtm_vec_axpy', H.ptr(self.w2.data), step, H.ptr(delta[n1:]), c * 9)
+
+    # ---- reference-style helpers (not on the hot path) ----------------------------------
+    def ip_input(self, a, b):
+        out = TensorList([x.reshape(-1) @ y.reshape(-1) for x, y in zip(a, b)])
+        total = sum(o.unsqueeze(0) for o in out)
+        return TensorList([total.clone() for _ in out])
+
+    def M1(self, x):
+        return x / self.diag_M
+
+
+class Discriminator(nn.Module):
+
+    def __init__(self, in_channels=1024, c_channels=96, out_channels=1,
+                 init_iters=(5, 10, 10, 10, 10), update_iters=(10,), update_filters=True,
+                 filter_reg=(1e-4, 1e-2), precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=75,
+                 memory_size=80, train_skipping=8, learning_rate=0.1,
+                 pixel_weighting=None, device=None, layer=None):
+        super().__init__()
+        if out_channels != 1:
+            raise ValueError('the target model scores one channel (reference evaluate.py:78)')
+        self.project = conv(in_channels, c_channels, 1, bias=False)
+        self.filter = conv(c_channels, out_channels, 3, bias=False)
+        self.layer = layer
+        self.init_iters = init_iters
+        self.update_iters = update_iters
+        self.filter_reg = filter_reg
+        self.precond = precond
+        self.direction_forget_factor = (1 - precond_lr) ** CG_forgetting_rate
+        self.train_skipping = train_skipping
+        self.learning_rate = learning_rate
+        self.memory_size = memory_size
+        self.pw_params = pixel_weighting
+        self.device = device
+        self.update_filters = update_filters
+        self.to(device)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.frame_num = 0
+        self.update_optimizer = None
+        self.current_sample = None
+        self.memory = None
+        self._w1T = None
+        self._w1T_key = None
+
+    # ---- projection weights in GEMM layout ------------------------------------------------
+    def _project_T(self):
+        w = self.project.weight
+        key = (w.data_ptr(), w._version)
+        if self._w1T is None or self._w1T_key != key:
+            self._w1T = ops.transpose2d(w.data.view(w.shape[0], w.shape[1]))
+            self._w1T_key = key
+        return self._w1T
+
+    def _invalidate(self):
+        self._w1T_key = None
+
+    def forward(self, x):
+        cft = ops.conv2d(x.contiguous(), self._project_T(), self.project.out_channels)
+        return ops.filter_scores(cft, self.filter.weight.data)
+
+    def _tf(self):
+        if self.pw_params is None or self.pw_params.get('method', 'none') == 'none':
+            return -1.0
+        assert self.pw_params['method'] == 'hinge'
+        return float(self.pw_params['tf'])
+
+    def compute_pixel_weights(self, y):
+        """(N,1,H,W) labels in {0,1} -> hinge pixel weights (reference discriminator.py:107-152)."""
+        H.require_gpu(y, 'compute_pixel_weights')
+        return ops.pixel_weights(y, self._tf())
+
+    def init(self, x, y):
+        """x: (K,Cin,h,w) features of the augmented first frame; y: (K,1,H,W) masks (reference :154-199)."""
+        H.require_gpu(x, 'Discriminator.init')
+        x = x.detach().float().contiguous()
+        K = x.shape[0]
+        dev = x.device
+        # joint fit of (project, filter) on the K raw samples
+        mem0 = Memory(K, x.shape[-3:], y.shape[-3:], dev, self.learning_rate, pixel_weighting=self.pw_params)
+        mem0.initialize(x, y)
+        problem = DiscriminatorLoss(mem0, self.filter_reg, self.precond, self.filter.weight, self.project.weight)
+        optimizer = GaussNewtonCG(problem, TensorList([self.project.weight, self.filter.weight]), fletcher_reeves=False,
+                                  standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
+        optimizer.run(self.init_iters)
+        self._invalidate()
+        xp = ops.conv2d(x, self._project_T(), self.project.out_channels)        # re-project (:178)
+        # memory + filter-only problem used for the rest of the sequence
+        memory = Memory(self.memory_size, xp.shape[-3:], y.shape[-3:], dev, self.learning_rate,
+                        pixel_weighting=self.pw_params)
+        memory.initialize(xp, y)
+        problem = DiscriminatorLoss(memory, self.filter_reg[1:], self.precond[1:], self.filter.weight)
+        optimizer = GaussNewtonCG(problem, TensorList([self.filter.weight]), fletcher_reeves=False,
+                                  standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
+        optimizer.run(self.update_iters)
+        self.memory = memory
+        self.update_optimizer = optimizer
+
+    def apply(self, ft):
+        """Per-frame scoring (reference :201-206)."""
+        H.require_gpu(ft, 'Discriminator.apply')
+        self.frame_num += 1
+        cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels)
+        self.current_sample = cft
+        return ops.filter_scores(cft, self.filter.weight.data)
+
+    def update(self, train_y, num_positive=None):
+        """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
+        ``num_positive``: optional pre-computed count of pixels > 0.5 (the tracker batches that
+        test for all objects into one device->host copy); otherwise it is evaluated here."""
+        if not self.update_filters or self.current_sample is None:
+            return
+        if num_positive is None:
+            num_positive = int(ops.count_above(train_y.reshape(1, -1)).item())
+        if num_positive < 10:
+            return
+        self.memory.update(self.current_sample, train_y)     # soft mask as label, weights from (y > 0.5)  (:217-219)
+        if self.frame_num % self.train_skipping != 0:
+            return
+        self.update_optimizer.run(self.update_iters)

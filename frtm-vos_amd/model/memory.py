@@ -1,0 +1,130 @@
+"""Sample memory of the target model (API of the reference's model/memory.py:4-92).
+
+MI355X layout.  The reference keeps, per slot, the projected features AND the full-resolution
+label and pixel-weight maps (2 x 1.64 MB per slot at 480p) and streams them through every CG
+iteration.  Here each slot keeps the features plus the *low-resolution normal equations* of its
+label/pixel-weight pair:
+
+    normal_B[slot] (9,h,w) = U^T diag(pw^2) U  as a 3x3 stencil,     normal_c[slot] (h,w) = U^T (pw^2 * label)
+
+built once per insert by one HIP kernel (``frtm_normal_build``); the CG loop never touches a
+full-resolution tensor.  Sample weights live on the device and the replacement index never
+comes back to the host (``frtm_memory_next_slot``): no ``.item()`` sync (reference memory.py:80-81).
+
+``keep_hires=True`` additionally stores ``labels`` / ``pixel_weights`` like the reference
+(debugging / API completeness; not read by the solver).
+"""
+import torch
+
+from .. import _hip as H
+
+
+class Memory:
+
+    def __init__(self, capacity, feature_size, labels_size, device, learning_rates, grid_size=None,
+                 pixel_weighting=None, keep_hires=False):
+        """
+        :param capacity:        number of slots
+        :param feature_size:    (C,h,w) of a stored feature map
+        :param labels_size:     (1,H,W) of the label image
+        :param learning_rates:  sample-weight learning rate (0.1 in evaluate.py:34)
+        :param grid_size:       (h,w) of the score grid the labels are compared on (default: feature grid)
+        :param pixel_weighting: dict(method='hinge', tf=...) or None; used when update()/initialize() are
+                                called without an explicit pixel-weight tensor
+        """
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise RuntimeError('Memory lives on the GPU (got device %s); there is no CPU path' % device)
+        self.samples = torch.zeros(capacity, *feature_size, device=dev)
+        self.weights = torch.zeros(capacity, device=dev)
+        self.grid = tuple(grid_size) if grid_size is not None else tuple(feature_size[-2:])
+        self.labels_size = tuple(labels_size)
+        self.normal_B = torch.zeros(capacity, 9, *self.grid, device=dev)
+        self.normal_c = torch.zeros(capacity, *self.grid, device=dev)
+        self.keep_hires = keep_hires
+        if keep_hires:
+            self.labels = torch.zeros(capacity, *labels_size, device=dev)
+            self.pixel_weights = torch.zeros(capacity, *labels_size, device=dev)
+        self.pw_params = pixel_weighting
+        self._capacity = capacity
+        self.current_size = 0
+        self.device = dev
+        self.learning_rates = learning_rates
+        self._slot = torch.tensor([-1, -1], dtype=torch.int32, device=dev)   # {previous_replace_ind, last index}
+        self._have_prev = False
+        self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
+
+    @property
+    def capacity(self):
+        return self._capacity
+
+    @property
+    def previous_replace_ind(self):
+        """Host view of the last replaced slot (synchronises; the hot path never reads it)."""
+        return int(self._slot[0].item()) if self._have_prev else None
+
+    def _tf(self):
+        p = self.pw_params
+        if p is None or p.get('method', 'none') == 'none':
+            return -1.0
+        assert p['method'] == 'hinge'
+        return float(p['tf'])
+
+    def clear(self):
+        self.current_size = 0
+        self.weights.zero_()
+
+    def _build_normals(self, labels, pixel_weights, n, slot_dev, slot_host):
+        Hh, Ww = self.labels_size[-2:]
+        lab = labels.reshape(n, Hh, Ww)
+        if lab.dtype != torch.uint8:
+            lab = lab.float()
+        lab = lab.contiguous()
+        pw = None if pixel_weights is None else pixel_weights.reshape(n, Hh, Ww).float().contiguous()
+        H.call('frtm_normal_build', H.ptr(lab), int(lab.dtype == torch.uint8), H.ptr(pw), n, Hh, Ww,
+               self.grid[0], self.grid[1], self._tf(), slot_dev, slot_host,
+               H.ptr(self.normal_B), H.ptr(self.normal_c), H.ptr(self._scratch))
+        return lab, pw
+
+    def initialize(self, init_features, init_labels, pixel_weights=None):
+        """Reference memory.py:33-48.  pixel_weights=None: hinge weights are computed inside the kernel."""
+        K = init_features.shape[0]
+        assert init_labels.shape[0] == K and K <= self._capacity
+        self.samples[:K] = init_features.detach()
+        w = torch.full((K,), 1.0 / K, device=self.device)
+        w[0] = 2.0 / K
+        self.weights[:K] = w / w.sum()
+        lab, pw = self._build_normals(init_labels, pixel_weights, K, None, 0)
+        if self.keep_hires:
+            self.labels[:K] = lab.float().view(K, *self.labels_size)
+            self.pixel_weights[:K] = (pw if pw is not None else self._hires_pw(lab)).view(K, *self.labels_size)
+        self.current_size = K
+
+    def _hires_pw(self, lab):
+        n = lab.shape[0]
+        out = torch.empty(lab.shape, device=self.device, dtype=torch.float32)
+        ys = (lab.float() > 0.5).float().contiguous()
+        H.call('frtm_pixel_weights', H.ptr(ys), 0, n, lab.shape[-2], lab.shape[-1], self._tf(), H.ptr(out), H.ptr(self._scratch))
+        return out
+
+    def update_sample_weights(self, previous_replace_ind=None):
+        """Reference memory.py:65-92, on the device.  Returns nothing: the chosen slot stays in ``self._slot``."""
+        H.call('frtm_memory_next_slot', H.ptr(self.weights), self._capacity, float(self.learning_rates),
+               int(self.current_size == 0), H.ptr(self._slot))
+        self._have_prev = True
+
+    def insert_at(self, slot_dev_ptr, ft, labels, pixel_weights):
+        """Reference memory.py:50-57; the slot is a device-resident index."""
+        ft = ft.detach().contiguous()
+        H.call('frtm_memory_insert', H.ptr(ft), H.ptr(self.samples), ft.numel(), slot_dev_ptr)
+        lab, pw = self._build_normals(labels, pixel_weights, 1, slot_dev_ptr, 0)
+        if self.keep_hires:
+            H.call('frtm_memory_insert', H.ptr(lab.float().contiguous()), H.ptr(self.labels), lab.numel(), slot_dev_ptr)
+            pwt = pw if pw is not None else self._hires_pw(lab)
+            H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self.pixel_weights), pwt.numel(), slot_dev_ptr)
+
+    def update(self, features, labels, pixel_weights=None):
+        """Reference memory.py:59-63."""
+        self.update_sample_weights()
+        self.insert_at(self._slot[1:].data_ptr(), features, labels, pixel_weights)
+        self.current_size = min(self.current_size + 1, self._capacity)

@@ -1,0 +1,160 @@
+"""Gauss-Newton / conjugate-gradient solver (API of the reference's model/optimizer.py:5-160).
+
+The reference obtains b = -J^T f0 and A p = J^T J p through ``torch.autograd.grad``
+double-backward (optimizer.py:84,155-157) and runs the CG recurrences as dozens of tiny
+TensorList ops with Python in between.  Here
+
+ * the problem supplies explicit operators (``linearize`` -> b, ``apply_A`` -> q) that are a
+   handful of fused HIP kernels each (see model/discriminator.py / csrc/target_model.hip);
+ * all CG vectors (b, r, r_prev, p, q, delta) are slices of ONE flat device buffer and every
+   scalar (rho, alpha, beta, <p,q>) stays on the device: ``run()`` enqueues kernels only and
+   never synchronises;
+ * the literal recurrences are kept, including their quirks:
+   ``rho /= direction_forget_factor`` at the start of every run_CG once a direction exists
+   (fp32, may overflow to inf => beta = 0), Polak-Ribiere beta clamped at 0, the skipped
+   residual update on the last iteration, CG state carried across run() calls.
+"""
+import torch
+
+from .. import _hip as H
+from ..lib.tensorlist import TensorList
+
+
+class MinimizationProblem:
+    """Protocol of a least-squares problem handled by GaussNewtonCG.
+
+    HIP-backed problems implement:
+      initialize()                  refresh views of the training data (reference discriminator.py:38-43)
+      vector_layout() -> (n1, n2, diagM1, diagM2)   lengths / preconditioner of the two parameter parts
+      linearize(x, b)               b <- -(J^T f(x) + lam^2 x)   (flat device vector)
+      apply_A(p, q)                 q <- J^T J p + lam^2 p
+      apply_step(x, step, delta)    x += step * delta (handles the internal layout)
+      views(flat) -> TensorList     flat vector reshaped like the variables
+    """
+
+    def __call__(self, x: TensorList) -> TensorList:
+        raise NotImplementedError
+
+    def ip_input(self, a, b):
+        return sum(a.view(-1) @ b.view(-1))
+
+    def M1(self, x):
+        return x
+
+
+class GaussNewtonCG:
+
+    def __init__(self, problem: MinimizationProblem, variable: TensorList, cg_eps=0.0, fletcher_reeves=True,
+                 standard_alpha=True, direction_forget_factor=0, step_alpha=1.0):
+        for need in ('vector_layout', 'linearize', 'apply_A', 'apply_step'):
+            if not hasattr(problem, need):
+                raise TypeError('GaussNewtonCG needs a problem with explicit HIP operators (missing %s); '
+                                'see MinimizationProblem' % need)
+        self.fletcher_reeves = fletcher_reeves
+        self.standard_alpha = standard_alpha
+        self.direction_forget_factor = direction_forget_factor
+        self.problem = problem
+        self.x = variable
+        self.cg_eps = cg_eps
+        self.step_alpha = step_alpha
+        self.residuals = torch.zeros(0)
+        self.external_losses = []
+        self.internal_losses = []
+        self.gradient_mags = torch.zeros(0)
+        self._n = None
+        self._has_p = False
+        self._buf = None
+
+    # ---- device state -------------------------------------------------------------------
+    def _alloc(self):
+        n1, n2, m1, m2 = self.problem.vector_layout()
+        n = n1 + n2
+        if self._buf is not None and self._n == n:
+            return
+        dev = self.x[0].device
+        self._n, self._n1, self._n2 = n, n1, n2
+        self._buf = torch.zeros(6, n, device=dev)           # b, r, r_prev, p, q, delta
+        self._state = torch.zeros(8, device=dev)
+        self._state[0] = 1.0                                # rho = ones(1)  (optimizer.py:29)
+        self._partial = torch.zeros(4 * 64, device=dev)
+        self._has_p = False
+
+    @property
+    def b(self):
+        return None if self._buf is None else self.problem.views(self._buf[0])
+
+    @property
+    def p(self):
+        return self.problem.views(self._buf[3]) if self._has_p else None
+
+    @property
+    def r_prev(self):
+        return self.problem.views(self._buf[2]) if self._has_p else None
+
+    @property
+    def rho(self):
+        return torch.ones(1) if self._buf is None else self._state[0:1]
+
+    def clear_temp(self):
+        pass
+
+    def reset_state(self):
+        self._has_p = False
+        if self._buf is not None:
+            self._state[0] = 1.0
+
+    # ---- solver ---------------------------------------------------------------------------
+    def run(self, num_cg_iter, num_gn_iter=None):
+        self.problem.initialize()
+        if isinstance(num_cg_iter, int):
+            if num_gn_iter is None:
+                raise ValueError('Must specify number of GN iter if CG iter is constant')
+            num_cg_iter = [num_cg_iter] * num_gn_iter
+        if len(num_cg_iter) == 0:
+            return None
+        self._alloc()
+        for n in num_cg_iter:
+            self.run_GN_iter(n)
+        return self.external_losses, self.internal_losses, self.residuals
+
+    def run_GN_iter(self, num_cg_iter):
+        self.problem.linearize(self.x, self._buf[0])
+        if num_cg_iter > 0:
+            self.run_CG(num_cg_iter)
+            self.problem.apply_step(self.x, float(self.step_alpha), self._buf[5])
+        self.step_alpha = min(self.step_alpha * 1.2, 1.0)
+
+    def run_CG(self, num_iter, x=None, eps=0.0):
+        if x is not None:
+            raise NotImplementedError('warm-started CG (x != None) is never used by the reference call sites')
+        pr = self.problem
+        n1, n2, m1, m2 = pr.vector_layout()
+        im1, im2 = 1.0 / m1, (1.0 / m2 if n2 else 1.0)
+        b, r, r_prev, p, q, dx = [H.ptr(self._buf[i]) for i in range(6)]
+        st, part = H.ptr(self._state), H.ptr(self._partial)
+        dff = float(self.direction_forget_factor)
+        if dff == 0:
+            self.reset_state()
+        apply_dff = int(self._has_p and dff != 0)
+        fr = int(self.fletcher_reeves)
+        H.call('frtm_cg_begin', b, r, r_prev, n1, n2, im1, im2, int(self._has_p and not fr), part)
+        for ii in range(num_iter):
+            H.call('frtm_cg_direction', r, p, n1, n2, im1, im2, int(self._has_p), apply_dff if ii == 0 else 0, fr,
+                   dff if dff != 0 else 1.0, st, part)
+            self._has_p = True
+            pr.apply_A(self._buf[3], self._buf[4])
+            H.call('frtm_cg_pq', p, q, None if self.standard_alpha else r, n1 + n2, part)
+            H.call('frtm_cg_update', dx, r, r_prev, p, q, n1, n2, im1, im2, int(ii == 0), int(ii == num_iter - 1),
+                   int(self.standard_alpha), st, part)
+        return pr.views(self._buf[5]), []
+
+    def A(self, x):
+        """q = J^T J x + lam^2 x for a TensorList / flat vector in the problem's layout."""
+        self._alloc()
+        q = torch.empty(self._n, device=self._buf.device)
+        flat = x if torch.is_tensor(x) else torch.cat([t.reshape(-1) for t in x])
+        self.problem.apply_A(flat.contiguous(), q)
+        return self.problem.views(q)
+
+    def ip(self, a, b):
+        return self.problem.ip_input(a, b)

@@ -1,0 +1,170 @@
+"""Sequence tracker (API of the reference's model/tracker.py:16-227).
+
+Same control flow per frame -- backbone -> per-object coarse score -> refinement -> soft-max merge ->
+per-object memory/filter update -- with the device work re-laid out for one MI355X:
+ * one native trunk call per frame; during ``initialize`` the trunk stops after the tap the
+   discriminator reads (the reference also runs resnet.layer4 there for nothing);
+ * all objects go through the refiner in one batched pass; the object-independent half of it is
+   computed once per frame;
+ * merge (clamp / background / soft-max / arg-max, tracker.py:214-221) is one HIP kernel, in place;
+ * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for
+   all objects by one kernel and ONE small device->host copy per frame instead of a sync per object.
+"""
+from time import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..lib.utils import AverageMeter
+from .discriminator import Discriminator
+
+
+class TargetObject:
+
+    def __init__(self, obj_id, disc_params, **kwargs):
+        self.object_id = obj_id
+        self.discriminator = Discriminator(**disc_params)
+        self.disc_layer = disc_params.layer
+        self.start_frame = None
+        self.start_mask = None
+        self.index = -1
+        for key, val in kwargs.items():
+            setattr(self, key, val)
+
+    def initialize(self, ft, mask):
+        self.discriminator.init(ft[self.disc_layer], mask)
+
+    def classify(self, ft):
+        return self.discriminator.apply(ft)
+
+
+class Tracker(nn.Module):
+
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device):
+        super().__init__()
+        self.augmenter = augmenter
+        self.augment = augmenter.augment_first_frame
+        self.disc_params = disc_params
+        self.feature_extractor = feature_extractor
+        self.refiner = refiner
+        for m in self.refiner.parameters():
+            m.requires_grad_(False)
+        self.refiner.eval()
+        self.device = device
+        self.first_frames = []
+        self.current_frame = 0
+        self.current_masks = None
+        self.num_objects = 0
+        self.targets = dict()
+
+    def clear(self):
+        self.first_frames = []
+        self.current_frame = 0
+        self.current_masks = None
+        self.num_objects = 0
+
+    # ------------------------------------------------------------------------------------
+    def run_dataset(self, dataset, out_path, speedrun=False, restart=None, writer=None):
+        """Reference tracker.py:68-101.  ``writer(path, label_image)`` stores a palette PNG; default: the
+        package's own imwrite_indexed (lib/image.py of the reference is I/O, out of the hot path)."""
+        if writer is None:
+            from ..lib.image import imwrite_indexed as writer
+        out_path.mkdir(exist_ok=True, parents=True)
+        dset_fps = AverageMeter()
+        print('Evaluating', dataset.name)
+        restarted = False
+        for sequence in dataset:
+            if restart is not None and not restarted:
+                if sequence.name != restart:
+                    continue
+                restarted = True
+            sequence.preload(self.device)
+            self.clear()
+            outputs, seq_fps = self.run_sequence(sequence, speedrun)
+            dset_fps.update(seq_fps)
+            dst = out_path / sequence.name
+            dst.mkdir(exist_ok=True)
+            for lb, f in zip(outputs, sequence.frame_names):
+                writer(dst / (f + '.png'), lb)
+        print('Average frame rate: %.2f fps' % dset_fps.avg)
+        return dset_fps.avg
+
+    def run_sequence(self, sequence, speedrun=False):
+        """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included."""
+        self.eval()
+        self.object_ids = sequence.obj_ids
+        self.current_frame = 0
+        self.targets = dict()
+        N = 0
+        object_ids = torch.tensor([0] + list(sequence.obj_ids), dtype=torch.uint8, device=self.device)
+        if speedrun:
+            image, labels, obj_ids = sequence[0]
+            self.initialize(image.to(self.device), labels.to(self.device), sequence.obj_ids)
+            self.track(image.to(self.device))
+            torch.cuda.synchronize()
+            self.targets = dict()
+        outputs = []
+        t0 = time()
+        for i, (image, labels, new_objects) in enumerate(sequence):
+            old_objects = set(self.targets.keys())
+            image = image.to(self.device)
+            if len(new_objects) > 0:
+                labels = labels.to(self.device)
+                self.initialize(image, labels, new_objects)
+            if len(old_objects) > 0:
+                self.track(image)
+                masks = self.current_masks
+                if len(sequence.obj_ids) == 1:
+                    labels = object_ids[(masks[1:2] > 0.5).long()]
+                else:                                                   # tracker.py:146-150 (merge of merged masks)
+                    labels = object_ids[ops.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]
+            if isinstance(labels, list) and len(labels) == 0:
+                labels = image.new_zeros(1, *image.shape[-2:])
+            outputs.append(labels)
+            self.current_frame += 1
+            N += 1
+        torch.cuda.synchronize()
+        T = time() - t0
+        return outputs, N / T
+
+    # ------------------------------------------------------------------------------------
+    def initialize(self, image, labels, new_objects):
+        """Reference tracker.py:165-191."""
+        self.current_masks = torch.zeros((len(self.targets) + len(new_objects) + 1, *image.shape[-2:]), device=self.device)
+        for obj_id in new_objects:
+            mask = (labels == obj_id).byte()
+            target = TargetObject(obj_id=obj_id, index=len(self.targets) + 1, disc_params=self.disc_params,
+                                  start_frame=self.current_frame, start_mask=mask)
+            self.targets[obj_id] = target
+            torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept:
+            np.random.seed(0)                  # augmentation draws are identical for every object
+            im, msk = self.augment(image, mask)
+            ft = self.feature_extractor(im, [target.disc_layer])
+            target.initialize(ft, msk)
+            self.current_masks[target.index] = mask
+        return self.current_masks
+
+    def track(self, image):
+        """Reference tracker.py:193-227."""
+        im_size = image.shape[-2:]
+        features = self.feature_extractor(image)
+        active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
+        if active:
+            scores = torch.cat([t.classify(features[t.disc_layer]) for t in active])       # (n,1,h,w)
+            y = torch.sigmoid(self.refiner(scores, features, im_size))                       # (n,1,H,W)
+            for k, t in enumerate(active):
+                self.current_masks[t.index] = y[k, 0]
+        for t1 in active:                                                                    # :208-212
+            for t2 in self.targets.values():
+                if t2 is not t1 and t2.start_frame == self.current_frame:
+                    self.current_masks[t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+        ops.merge_masks_(self.current_masks)                                                 # :214-221
+        if active and self.disc_params.update_filters:
+            idx = torch.tensor([t.index for t in active], device=self.device)
+            counts = ops.count_above(self.current_masks[idx]).tolist()                       # one D2H per frame
+            for t, n_pos in zip(active, counts):
+                t.discriminator.update(self.current_masks[t.index].unsqueeze(0).unsqueeze(0), num_positive=n_pos)
+        return self.current_masks

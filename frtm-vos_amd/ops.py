@@ -1,0 +1,90 @@
+"""Thin tensor-level wrappers over the C ABI (include/frtm_hip.h).  Every function enqueues HIP
+kernels on the current torch stream and returns torch tensors that own the device memory."""
+import ctypes
+
+import torch
+
+from . import _hip as H
+
+_workspaces = {}
+
+
+def workspace(device, elems):
+    """Grow-only fp32 scratch per device (split-K partials)."""
+    w = _workspaces.get(device)
+    if w is None or w.numel() < elems:
+        w = torch.empty(int(elems), device=device, dtype=torch.float32)
+        _workspaces[device] = w
+    return w
+
+
+def pack_weights(w_oihw):
+    """(Cout,Cin,k,k) -> wT [Cin*k*k, Cout] (+ ktab for k > 1).  See frtm_conv_pack_weights."""
+    w = w_oihw.detach().float().contiguous()
+    Cout, Cin, k, _ = w.shape
+    wT = torch.empty(Cin * k * k, Cout, device=w.device)
+    ktab = torch.empty(Cin * k * k * 3, device=w.device, dtype=torch.int32) if k > 1 else None
+    H.call('frtm_conv_pack_weights', H.ptr(w), Cout, Cin, k, H.ptr(wT), H.ptr(ktab))
+    return wT, ktab
+
+
+def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=None, residual=None, relu=False,
+           out=None, out_transposed=False, splitk=0, tile=0, shape=None):
+    """fp32 MFMA implicit-GEMM convolution.  x: (B,Cin,H,W) dense (or any dense buffer when ``shape``
+    = (B,Cin,H,W) is given explicitly); wT: [Cin*k*k, Cout].  Returns (B,Cout,Ho,Wo) (or (B,Ho*Wo,Cout)
+    when out_transposed)."""
+    B, Cin, Hin, Win = shape if shape is not None else x.shape
+    Ho = (Hin + 2 * pad - ksize) // stride + 1
+    Wo = (Win + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho * Wo, Cout) if out_transposed else (B, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile))
+    ws = workspace(x.device, 32 * Cout * B * Ho * Wo) if splitk != 1 else None
+    H.call('frtm_conv2d', ctypes.byref(d), H.ptr(x), H.ptr(wT), H.ptr(ktab), H.ptr(scale), H.ptr(shift),
+           H.ptr(residual), H.ptr(out), H.ptr(ws))
+    return out
+
+
+def filter_scores(X, f, out=None, accumulate=False, n=None):
+    """(N,C,h,w) x (1,C,3,3) -> (N,1,h,w)."""
+    N = X.shape[0] if n is None else n
+    C, h, w = X.shape[1:]
+    if out is None:
+        out = torch.empty(N, 1, h, w, device=X.device)
+    H.call('frtm_filter_scores', H.ptr(X), H.ptr(f), N, C, h, w, H.ptr(out), int(accumulate))
+    return out
+
+
+def transpose2d(x2d, out=None):
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty(cols, rows, device=x2d.device)
+    H.call('frtm_transpose2d', H.ptr(x2d), rows, cols, H.ptr(out))
+    return out
+
+
+def pixel_weights(y, tf):
+    """Discriminator.compute_pixel_weights (hinge).  y (N,1,H,W) uint8/float in {0,1}."""
+    y = y.contiguous()
+    if y.dtype != torch.uint8:
+        y = y.float()
+    N, _, Hh, Ww = y.shape
+    out = torch.empty(N, 1, Hh, Ww, device=y.device)
+    scratch = torch.empty(N * 32, device=y.device)
+    H.call('frtm_pixel_weights', H.ptr(y), int(y.dtype == torch.uint8), N, Hh, Ww, float(tf), H.ptr(out), H.ptr(scratch))
+    return out
+
+
+def merge_masks_(masks):
+    """Tracker.track merge, in place on (n_obj+1,H,W)."""
+    K, Hh, Ww = masks.shape
+    H.call('frtm_merge_masks', H.ptr(masks), K, Hh * Ww)
+    return masks
+
+
+def count_above(masks, thr=0.5):
+    """Per-plane pixel count above thr -> int32 (n) device tensor (no sync)."""
+    m = masks.reshape(masks.shape[0], -1)
+    cnt = torch.empty(m.shape[0], dtype=torch.int32, device=masks.device)
+    H.call('frtm_count_above', H.ptr(m), m.shape[0], m.shape[1], float(thr), H.ptr(cnt))
+    return cnt

@@ -1,0 +1,185 @@
+/* libfrtm_hip -- C ABI of the MI355X-native FRTM hot path (gfx950 HIP kernels).
+ *
+ * The reference (andr345/frtm-vos) is pure Python on PyTorch and has NO native interface for
+ * this path (its only native file, lib/_npp/nppig.cpp, wraps NVIDIA NPP image warps for the
+ * augmenter).  Every device op of the hot path is an ATen/cuDNN launch issued from Python.
+ * This header therefore defines the boundary a maintainer of the reference would bind
+ * (ctypes stub: INTEGRATION.md); each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless the name ends in _host; tensors are dense fp32,
+ *    NCHW, exactly as PyTorch lays them out (tensor.data_ptr()).
+ *  - every function takes a hipStream_t (as void*) and never synchronises.
+ *  - return value: 0 = ok, <0 = error; frtm_last_error() returns the message (thread local).
+ *  - nothing here allocates per call; scratch buffers are passed in (sizes documented).
+ */
+#ifndef FRTM_HIP_H
+#define FRTM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* frtm_stream_t;            /* hipStream_t */
+typedef struct frtm_backbone frtm_backbone_t;
+
+const char* frtm_last_error(void);
+int frtm_version(void);
+/* Device properties of the current device: out[0]=CU count, out[1]=gfx arch number (950),
+ * out[2]=LDS bytes per workgroup, out[3]=wavefront size. */
+int frtm_device_info(int* out4_host);
+
+/* ------------------------------------------------------------------------------------------
+ * Target model ("discriminator"), per-frame pieces
+ * ------------------------------------------------------------------------------------------ */
+
+/* Discriminator.compute_pixel_weights, method 'hinge' (model/discriminator.py:107-152).
+ * y: (n,1,H,W) labels in {0,1}, uint8 if y_is_u8 else fp32.  out: (n,1,H,W) fp32.
+ * tf < 0 selects "no weighting" (all ones, :114-115).  scratch: >= n*FRTM_PX_PARTS floats. */
+#define FRTM_PX_PARTS 32
+int frtm_pixel_weights(const void* y, int y_is_u8, int n, int H, int W, float tf,
+                       float* out, float* scratch, frtm_stream_t stream);
+
+/* Low-resolution normal equations of one memory sample (replaces storing the hi-res label and
+ * pixel-weight maps of model/memory.py:15-16 and the hi-res work of DiscriminatorLoss.__call__,
+ * model/discriminator.py:45-49, inside the CG loop):
+ *     B = U^T diag(pw^2) U   (a 3x3 stencil on the h x w grid, 9 maps)      c = U^T (pw^2 * label)
+ * with U = bilinear up-sampling (h,w)->(H,W), align_corners=False, and pw the hinge pixel weight
+ * of ys = (label > 0.5) (discriminator.py:217-218).  labels: (n,1,H,W) uint8 or fp32 (soft).
+ * Results go to slots slot..slot+n-1 of Bmem (cap,9,h,w) and cmem (cap,h,w); if slot_dev != NULL
+ * the first slot index is read from that device int32 (Memory.update's argmin, memory.py:80),
+ * otherwise slot_host is used.  tf < 0: pw = 1.  pw != NULL: explicit (n,1,H,W) pixel weights are used
+ * instead of the hinge rule (Memory.update's generic signature, memory.py:59).
+ * scratch: >= n*FRTM_PX_PARTS floats. */
+int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int n, int H, int W, int h, int w,
+                      float tf, const int* slot_dev, int slot_host, float* Bmem, float* cmem,
+                      float* scratch, frtm_stream_t stream);
+
+/* Memory.update_sample_weights (model/memory.py:65-92) on the device, no host sync.
+ * sw: (cap) sample weights, updated in place.  state: device int32[2] = {previous_replace_ind or -1,
+ * replace index written by this call}.  num_samp_is_zero / lr as in the reference. */
+int frtm_memory_next_slot(float* sw, int cap, float lr, int num_samp_is_zero, int* state,
+                          frtm_stream_t stream);
+
+/* Copy one sample (len floats) into slot state[1] of a (cap,len) buffer (Memory.insert_at, memory.py:50-57). */
+int frtm_memory_insert(const float* src, float* dst_base, int len, const int* slot_dev, frtm_stream_t stream);
+
+/* 3x3 filter scores (Discriminator.filter, model/discriminator.py:82,205; C1 of SURVEY 2.3):
+ * out[n,y,x] (+)= sum_c sum_{dy,dx} X[n,c,y+dy-1,x+dx-1] * f[c,dy,dx].  X (N,C,h,w), f (1,C,3,3). */
+int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w,
+                       float* out, int accumulate, frtm_stream_t stream);
+
+/* t[n,i,j] = sw[n] * ( sum_{di,dj} B[n,(di,dj),i,j] * s[n,i+di,j+dj]  -  (c ? c[n,i,j] : 0) ).
+ * This is U^T W^2 (U s - y) of the reference residual (discriminator.py:47-49) in low-res form. */
+int frtm_stencil(const float* B, const float* c, const float* sw, const float* s, int N, int h, int w,
+                 float* t, frtm_stream_t stream);
+
+/* Filter weight gradient, per-sample partials (the conv backward of optimizer.py:84,155-157):
+ * partial[n, c*9+dy*3+dx] = sum_{y,x} X[n,c,y+dy-1,x+dx-1] * t[n,y,x]. */
+int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w,
+                      float* partial, frtm_stream_t stream);
+
+/* Input gradient of the 3x3 filter: D[n,c,y,x] = sum_{dy,dx} f[c,dy,dx] * t[n,y-dy+1,x-dx+1].
+ * pix_major != 0 writes D as (n, h*w, C) instead of (n, C, h*w). */
+int frtm_filter_igrad(const float* t, const float* f, int N, int C, int h, int w,
+                      float* D, int pix_major, frtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conjugate-gradient vector steps (model/optimizer.py:98-153), scalars stay on the device.
+ * Vectors are flat fp32 of length n = n1 + n2 (two parameter tensors; n2 may be 0); the
+ * preconditioner M1 (discriminator.py:63-64) divides part k by diagM[k].
+ * state: device float[8]: [0]=rho [1]=alpha [2]=beta [3]=pq [4]=rho_new [5]=rho2.
+ * partial: device float[>= 4*FRTM_CG_BLOCKS] (two banks of per-block dot partials).
+ * ------------------------------------------------------------------------------------------ */
+#define FRTM_CG_BLOCKS 64
+/* q = sign * ( sum_k slabs[k*stride + i] + lam2 * p[i] ),  i < len   (sign = +1 / -1) */
+int frtm_vec_reduce_slabs(const float* slabs, int nslab, int stride, int len, float lam2, const float* p,
+                          float sign, float* q, frtm_stream_t stream);
+/* r = b; partial dots of rho_new=<r,M^-1 r> and (has_p) rho2=<r_prev,M^-1 r>   (optimizer.py:107-117) */
+int frtm_cg_begin(const float* b, float* r, const float* r_prev, int n1, int n2, float invM1, float invM2,
+                  int has_p, float* partial, frtm_stream_t stream);
+/* beta = clamp((rho_new-rho2)/rho1, 0); p = z + beta p  (or p = z when !has_p); rho <- rho_new.
+ * apply_dff != 0: rho1 = rho / dff first (optimizer.py:102-105). */
+int frtm_cg_direction(const float* r, float* p, int n1, int n2, float invM1, float invM2, int has_p,
+                      int apply_dff, int fletcher_reeves, float dff, float* state, const float* partial,
+                      frtm_stream_t stream);
+/* partial dots of <p,q> (optimizer.py:133) and, if r != NULL, <p,r> (non-standard alpha, :138) */
+int frtm_cg_pq(const float* p, const float* q, const float* r, int n, float* partial, frtm_stream_t stream);
+/* alpha = rho/pq; r_prev = r; x = first ? alpha p : x + alpha p; if(!last) r -= alpha q; then the
+ * partial dots for the next direction (optimizer.py:135-151,113-127). */
+int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const float* q, int n1, int n2,
+                   float invM1, float invM2, int first, int last, int standard_alpha, float* state,
+                   float* partial, frtm_stream_t stream);
+/* y += a * x */
+int frtm_vec_axpy(float* y, float a, const float* x, int n, frtm_stream_t stream);
+/* out[c*rows + r] = in[r*cols + c]  (small 2-D transpose, rows x cols -> cols x rows) */
+int frtm_transpose2d(const float* in, int rows, int cols, float* out, frtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA implicit-GEMM convolution  (every conv of the ResNet trunk, feature_extractor.py:50-65;
+ * the 1x1 projection, discriminator.py:81,203; the init-problem GEMMs)
+ *   out[img, m, oy, ox] = epilogue( sum_{ci,kh,kw} wT[(ci,kh,kw), m] * in[img, ci, oy*s-pad+kh, ox*s-pad+kw] )
+ *   epilogue: (* scale[m] + shift[m])?  (+ residual)?  relu?
+ * wT: weights pre-transposed to [K = Cin*kh*kw][M = Cout] (see frtm_conv_pack_weights).
+ * ktab: int32[K*3] = {ci, kh, kw} built by frtm_conv_pack_weights; may be NULL for 1x1 convs.
+ * out_transposed: write out[img, pix, m] instead of out[img, m, pix].
+ * splitk: 0 = auto, 1 = none, >1: partial sums go through `workspace` (>= splitk*Cout*B*Ho*Wo floats;
+ *         FRTM_CONV_MAX_SPLITK bounds the auto choice) and a second kernel applies the epilogue.
+ * The init-problem weight gradient g1[c,ci] = sum_{img,pix} D[img,pix,c] * X[img,pix,ci] is the same
+ * call with B=1, Cin = n_img*h*w, "pixels" = ci, wT = D (pixel-major) and in = X in NHWC.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int B, Cin, Hin, Win, Cout, ksize, stride, pad;
+  int relu, out_transposed;
+  int splitk;              /* 0 = auto */
+  int tile;                /* 0 = auto, else FRTM_TILE_* */
+} frtm_conv_desc;
+#define FRTM_CONV_MAX_SPLITK 32
+#define FRTM_TILE_64x64 1
+#define FRTM_TILE_32x64 2
+#define FRTM_TILE_128x64 3
+int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize,
+                           float* wT, int* ktab, frtm_stream_t stream);
+int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,
+                const float* scale, const float* shift, const float* residual, float* out,
+                float* workspace, frtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone: torchvision-topology ResNet trunk (model/feature_extractor.py:9-68), weights resident.
+ * arch: 18, 34, 50, 101.  Parameters are uploaded per conv in forward order with their eval-mode
+ * BatchNorm folded to (scale, shift).  forward() takes the uint8 image batch and writes the
+ * requested taps (NULL = not wanted) as dense NCHW fp32.
+ * ------------------------------------------------------------------------------------------ */
+int frtm_backbone_create(int arch, frtm_backbone_t** out_host);
+int frtm_backbone_destroy(frtm_backbone_t* bb);
+int frtm_backbone_num_convs(const frtm_backbone_t* bb);
+/* Shape of conv #idx in forward order: out6 = {Cout, Cin, ksize, stride, pad, has_residual_input} */
+int frtm_backbone_conv_info(const frtm_backbone_t* bb, int idx, int* out6_host);
+int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, const float* bn_scale,
+                           const float* bn_shift, frtm_stream_t stream);
+int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W,
+                          const float* norm_scale3, const float* norm_bias3,
+                          float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
+                          int stop_after_layer, frtm_stream_t stream);
+/* FLOPs (2*MAC over all convs) of the last forward() call. */
+double frtm_backbone_last_flops(const frtm_backbone_t* bb);
+
+/* ------------------------------------------------------------------------------------------
+ * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).
+ * ------------------------------------------------------------------------------------------ */
+int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream);
+/* count[k] = #pixels with masks[k] > 0.5   (the early-out test of discriminator.py:214), int32[n] */
+int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, frtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Affine warp of C planes (replaces lib/_npp/nppig.cpp:48-104 = NVIDIA NPP nppiWarpAffine_*, called from
+ * lib/image.py:53).  fwd6_host: HOST float[6], the forward 2x3 transform (source -> destination), as
+ * cv2.warpAffine / NPP take it.  mode: 0 nearest, 1 bilinear, 2 bicubic.  Outside pixels become 0.
+ * ------------------------------------------------------------------------------------------ */
+int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd,
+                     const float* fwd6_host, int mode, frtm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRTM_HIP_H */

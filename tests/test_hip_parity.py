@@ -1,0 +1,390 @@
+"""GPU parity: every HIP kernel of the hot path (reached through the C ABI / the Python API mirror)
+against the CPU oracle and the fixtures recorded from the reference.  All tests need a real MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+PW = dict(method='hinge', tf=0.1)
+DEV = 'cuda:0'
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from frtm_vos_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------ pixel weights / normals
+def test_pixel_weights_g1(golden, ops):
+    g = golden('g1_pixel_weights')
+    w = ops.pixel_weights(T(g['masks']).to(DEV), 0.1)
+    assert (w.cpu() - T(g['weights'])).abs().max() < 1e-6
+    wf = ops.pixel_weights(T(g['masks']).float().to(DEV), 0.1)
+    assert torch.equal(w, wf)
+    ones = ops.pixel_weights(T(g['masks']).to(DEV), -1.0)
+    assert torch.all(ones == 1)
+
+
+@pytest.mark.parametrize('H,W,h,w', [(48, 70, 6, 9), (480, 854, 30, 54), (64, 64, 64, 64), (37, 53, 5, 7)])
+def test_normal_build(H, W, h, w):
+    from frtm_vos_amd.model.memory import Memory
+    g = gen(H * W)
+    n = 3
+    soft = torch.rand(n, 1, H, W, generator=g)
+    soft[0, :, : H // 2] *= 0.3
+    soft[1] = (soft[1] > 0.97).float() * soft[1]                 # sparse: < 10 % foreground
+    soft[2] = 0                                                  # empty -> px < 10
+    feats = torch.zeros(n, 2, h, w)
+    mem = Memory(4, (2, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+    mem.initialize(feats.to(DEV), soft.to(DEV))
+    pw = O.pixel_weights((soft > 0.5).float(), PW)
+    B, c = O.lowres_normal(pw, soft, (h, w))
+    assert rel(mem.normal_B[:n], B) < 2e-5
+    assert rel(mem.normal_c[:n], c) < 2e-5
+    # explicit pixel-weight tensor + uint8 labels
+    lab8 = (soft > 0.5).to(torch.uint8)
+    pwx = torch.rand(n, 1, H, W, generator=g) + 0.5
+    mem2 = Memory(4, (2, h, w), (1, H, W), DEV, 0.1, pixel_weighting=None)
+    mem2.initialize(feats.to(DEV), lab8.to(DEV), pwx.to(DEV))
+    B2, c2 = O.lowres_normal(pwx, lab8.float(), (h, w))
+    assert rel(mem2.normal_B[:n], B2) < 2e-5 and rel(mem2.normal_c[:n], c2) < 2e-5
+
+
+def test_memory_weights_g2(golden):
+    from frtm_vos_amd.model.memory import Memory
+    g = golden('g2_memory')
+    for cap in (80, 8):
+        m = Memory(cap, (1, 2, 2), (1, 8, 8), DEV, 0.1, pixel_weighting=PW)
+        m.initialize(torch.zeros(5, 1, 2, 2, device=DEV), torch.zeros(5, 1, 8, 8, device=DEV))
+        assert (m.weights.cpu() - T(g['w%d' % cap][0])).abs().max() < 1e-7
+        for t in range(100):
+            marker = torch.full((1, 1, 2, 2), float(t + 1), device=DEV)
+            m.update(marker, torch.zeros(1, 1, 8, 8, device=DEV))
+            assert m.previous_replace_ind == int(g['ind%d' % cap][t]), (cap, t)
+            assert (m.weights.cpu() - T(g['w%d' % cap][t + 1])).abs().max() < 2e-7, (cap, t)
+            assert float(m.samples[int(g['ind%d' % cap][t]), 0, 0, 0]) == t + 1
+        assert m.current_size == min(105, cap)
+
+
+# ------------------------------------------------------------------------------------------ small filter kernels
+@pytest.mark.parametrize('N,C,h,w', [(7, 8, 6, 9), (3, 96, 30, 54), (1, 5, 3, 3), (2, 13, 17, 65)])
+def test_filter_kernels(ops, N, C, h, w):
+    from frtm_vos_amd import _hip as H
+    g = gen(N * C)
+    X = torch.randn(N, C, h, w, generator=g)
+    f = torch.randn(1, C, 3, 3, generator=g)
+    t = torch.randn(N, 1, h, w, generator=g)
+    Xd, fd, td = X.to(DEV), f.to(DEV), t.to(DEV)
+    s = ops.filter_scores(Xd, fd)
+    assert rel(s, O.conv3x3(X, f)) < 1e-5
+    s2 = ops.filter_scores(Xd, fd, out=s.clone(), accumulate=True)
+    assert rel(s2, 2 * O.conv3x3(X, f)) < 1e-5
+    part = torch.empty(N, C * 9, device=DEV)
+    H.call('frtm_filter_wgrad', H.ptr(Xd), H.ptr(td), N, C, h, w, H.ptr(part))
+    assert rel(part.sum(0).view(1, C, 3, 3), O.conv3x3_wgrad(X, t)) < 2e-5
+    D = torch.empty(N, C, h, w, device=DEV)
+    H.call('frtm_filter_igrad', H.ptr(td), H.ptr(fd), N, C, h, w, H.ptr(D), 0)
+    assert rel(D, O.conv3x3_igrad(t, f)) < 1e-5
+    Dp = torch.empty(N, h * w, C, device=DEV)
+    H.call('frtm_filter_igrad', H.ptr(td), H.ptr(fd), N, C, h, w, H.ptr(Dp), 1)
+    assert torch.equal(Dp.permute(0, 2, 1).reshape(N, C, h, w), D)
+    Bm = torch.randn(N, 9, h, w, generator=g)
+    cc = torch.randn(N, h, w, generator=g)
+    sw = torch.rand(N, generator=g)
+    out = torch.empty(N, h * w, device=DEV)
+    sflat = t[:, 0].contiguous()
+    H.call('frtm_stencil', H.ptr(Bm.to(DEV)), H.ptr(cc.to(DEV)), H.ptr(sw.to(DEV)), H.ptr(sflat.to(DEV)), N, h, w, H.ptr(out))
+    ref = (O.stencil_apply(Bm, sflat) - cc) * sw[:, None, None]
+    assert rel(out.view(N, h, w), ref) < 1e-5
+
+
+def test_transpose_and_axpy(ops):
+    x = torch.randn(96, 1024, generator=gen(1)).to(DEV)
+    assert torch.equal(ops.transpose2d(x), x.t().contiguous())
+    y = torch.randn(37, 5, generator=gen(2)).to(DEV)
+    assert torch.equal(ops.transpose2d(y), y.t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------ MFMA conv
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (1, 64, 30, 54, 256, 1, 1, 0),
+    (1, 256, 30, 54, 64, 1, 1, 0),
+    (2, 32, 15, 27, 48, 3, 1, 1),
+    (1, 3, 64, 96, 64, 7, 2, 3),
+    (1, 128, 31, 53, 128, 3, 2, 1),
+    (1, 256, 30, 54, 512, 1, 2, 0),
+    (5, 40, 6, 9, 96, 1, 1, 0),
+    (1, 100, 9, 11, 33, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('tile,splitk', [(0, 0), (1, 1), (2, 1), (3, 1), (2, 3), (1, 4)])
+def test_conv2d(ops, case, tile, splitk):
+    B, Cin, H, W, Cout, k, s, p = case
+    g = gen(Cin * Cout + k)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    res = torch.randn(ref.shape, generator=g)
+    wT, ktab = ops.pack_weights(w.to(DEV))
+    out = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, tile=tile, splitk=splitk)
+    assert rel(out, ref) < 2e-5
+    out2 = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, scale=scale.to(DEV), shift=shift.to(DEV),
+                      residual=res.to(DEV), relu=True, tile=tile, splitk=splitk)
+    ref2 = F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    assert rel(out2, ref2) < 2e-5
+    out3 = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, out_transposed=True, tile=tile, splitk=splitk)
+    assert rel(out3, ref.flatten(2).transpose(1, 2)) < 2e-5
+
+
+def test_conv_as_weight_gradient(ops):
+    """g1[c,ci] = sum_{n,pix} D[n,pix,c] X[n,pix,ci]: the init problem's second GEMM (K = N*h*w)."""
+    g = gen(9)
+    N, hw, Cin, c = 5, 1620, 256, 96
+    D = torch.randn(N, hw, c, generator=g)
+    X = torch.randn(N, hw, Cin, generator=g)
+    ref = torch.einsum('npc,npk->ck', D.double(), X.double()).float()
+    out = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin))
+    assert rel(out.view(c, Cin), ref) < 3e-5
+    outT = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin), out_transposed=True)
+    assert rel(outT.view(Cin, c), ref.t()) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------ backbone
+@pytest.mark.parametrize('name,size,B', [('resnet18', (96, 128), 2), ('resnet101', (64, 96), 1), ('resnet18', (480, 854), 1),
+                                         ('resnet50', (75, 101), 1)])
+def test_backbone_vs_oracle(name, size, B):
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    P = O.resnet_random_params(name, seed=3)
+    ext = ResnetFeatureExtractor(name, weights=P).to(DEV)
+    img = torch.randint(0, 256, (B, 3) + size, dtype=torch.uint8, generator=gen(5))
+    ref = O.resnet_forward(name, P, img)
+    out = ext(img.to(DEV))
+    assert list(out.keys()) == ['layer1', 'layer2', 'layer3', 'layer4', 'layer5']
+    for L in ref:
+        assert out[L].shape == ref[L].shape, (L, out[L].shape, ref[L].shape)
+        assert rel(out[L], ref[L]) < 2e-4, (name, L, rel(out[L], ref[L]))
+    only4 = ext(img.to(DEV), ['layer4'])
+    assert list(only4.keys()) == ['layer4'] and torch.equal(only4['layer4'], out['layer4'])
+    if B == 1:
+        single = ext(img[0].to(DEV), ['layer2'])                  # (3,H,W) broadcasts to batch 1 (reference :42)
+        assert torch.equal(single['layer2'], out['layer2'])
+    assert ext.get_out_channels()['layer4'] == ref['layer4'].shape[1]
+
+
+# ------------------------------------------------------------------------------------------ solver vs reference fixtures
+def _hip_memory_from(g, tag, cap, dims):
+    from frtm_vos_amd.model.memory import Memory
+    c, h, w, H, W = dims
+    mem = Memory(cap, (c, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+    n = int((g[tag + '_sw0'] > 0).sum())
+    mem.samples[:] = T(g[tag + '_samples0']).to(DEV)
+    mem._build_normals(T(g[tag + '_labels0'][:n]).to(DEV), T(g[tag + '_pw0'][:n]).to(DEV), n, None, 0)
+    mem.weights[:] = T(g[tag + '_sw0']).to(DEV)
+    mem.current_size = n
+    mem._slot[0] = n - 1
+    mem._have_prev = True
+    return mem
+
+
+def test_update_problem_g3(golden):
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    g = golden('g3_update')
+    c, h, w, H, W, cap = [int(v) for v in g['dims']]
+    for tag in ('a', 'b'):
+        rate = int(g[tag + '_rate'])
+        mem = _hip_memory_from(g, tag, cap, (c, h, w, H, W))
+        wv = torch.nn.Parameter(T(g[tag + '_w0']).clone().to(DEV), requires_grad=False)
+        prob = DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv)
+        opt = GaussNewtonCG(prob, TensorList([wv]), fletcher_reeves=False, standard_alpha=True,
+                            direction_forget_factor=(1 - 0.1) ** rate)
+        prob.initialize()
+        opt._alloc()
+        prob.linearize(opt.x, opt._buf[0])
+        assert rel(opt.b[0], T(g[tag + '_b'])) < 5e-5
+        for p, Ap in zip(T(g[tag + '_p']), T(g[tag + '_Ap'])):
+            assert rel(opt.A(TensorList([p.to(DEV)]))[0], Ap) < 5e-5
+        opt.run((10,))
+        assert rel(wv, T(g[tag + '_filters'][0])) < 2e-3, tag
+        for t in range(3):
+            mem.update(T(g[tag + '_ins_x'][t:t + 1]).to(DEV), T(g[tag + '_ins_y'][t:t + 1]).to(DEV),
+                       T(g[tag + '_ins_pw'][t:t + 1]).to(DEV))
+            assert (mem.weights.cpu() - T(g[tag + '_sws'][t + 1])).abs().max() < 1e-6
+            opt.run((10,))
+            assert rel(wv, T(g[tag + '_filters'][t + 1])) < 5e-3, (tag, t)
+        assert opt.p is not None and opt.rho.numel() == 1
+
+
+def test_init_problem_g4(golden):
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    g = golden('g4_init')
+    cin, c, h, w, H, W = [int(v) for v in g['dims']]
+    x, y = T(g['x']).to(DEV), T(g['y']).to(DEV)
+    for tag, iters in (('fast', (5, 10, 10, 10)), ('full', (5, 10, 10, 10, 10))):
+        mem = Memory(5, (cin, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+        mem.initialize(x, y)
+        w1 = torch.nn.Parameter(T(g['w1_0']).clone().to(DEV), requires_grad=False)
+        w2 = torch.nn.Parameter(T(g['w2_0']).clone().to(DEV), requires_grad=False)
+        prob = DiscriminatorLoss(mem, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)
+        opt = GaussNewtonCG(prob, TensorList([w1, w2]), fletcher_reeves=False, standard_alpha=True,
+                            direction_forget_factor=0.9 ** 750)
+        if tag == 'fast':
+            prob.initialize()
+            opt._alloc()
+            prob.linearize(opt.x, opt._buf[0])
+            b = opt.b
+            assert rel(b[0], T(g['b1'])) < 5e-5 and rel(b[1], T(g['b2'])) < 5e-5
+            for p1, p2, a1, a2 in zip(T(g['p1']), T(g['p2']), T(g['Ap1']), T(g['Ap2'])):
+                flat = torch.cat([p1.view(c, cin).t().reshape(-1), p2.reshape(-1)]).to(DEV)
+                q = opt.A(flat)
+                assert rel(q[0], a1) < 5e-5 and rel(q[1], a2) < 5e-5
+        opt.run(iters)
+        assert rel(w1, T(g[tag + '_w1'])) < 5e-3, tag
+        assert rel(w2, T(g[tag + '_w2'])) < 5e-3, tag
+
+
+def test_discriminator_g5(golden):
+    """init -> (apply, update) x 17 against the reference recording.  Gates as in tests/test_oracle_golden.py:
+    objective value tight, scores at the algorithm's own fp32 noise floor (see that file's docstring)."""
+    from frtm_vos_amd.model.discriminator import Discriminator
+    from tests.test_oracle_golden import _init_loss
+    g = golden('g5_disc')
+    cin, c, h, w, H, W, cap = [int(v) for v in g['dims']]
+    d = Discriminator(in_channels=cin, c_channels=c, init_iters=(5, 10, 10, 10), update_iters=(5,), CG_forgetting_rate=750,
+                      memory_size=cap, pixel_weighting=PW, device=DEV, layer='layer4')
+    d.project.weight.data.copy_(T(g['w1_0']))
+    d.filter.weight.data.copy_(T(g['w2_0']))
+    x, y = T(g['x']), T(g['y'])
+    d.init(x.to(DEV), y.to(DEV))
+    l_ref = _init_loss(x, y, T(g['w1_init']), T(g['w2_init']))
+    l_hip = _init_loss(x, y, d.project.weight.detach().cpu(), d.filter.weight.detach().cpu())
+    assert abs(l_hip - l_ref) / l_ref < 2e-3
+    for t in range(17):
+        s = d.apply(T(g['fts'][t:t + 1]).to(DEV))
+        d.update(T(g['ys'][t:t + 1]).to(DEV))
+        assert s.shape == (1, 1, h, w)
+        assert (s.cpu() - T(g['scores'][t:t + 1])).abs().max() < 0.06, t
+        assert (d.memory.weights.cpu() - T(g['sws'][t])).abs().max() < 1e-6, t
+    assert d.frame_num == 17 and set(d.state_dict().keys()) == {'project.weight', 'filter.weight'}
+
+
+def test_short_horizon_matches_oracle_tightly(golden):
+    """Three CG steps from identical state: HIP vs oracle within 1e-4 (before rounding chaos sets in)."""
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    g = golden('g3_update')
+    c, h, w, H, W, cap = [int(v) for v in g['dims']]
+    mem = _hip_memory_from(g, 'a', cap, (c, h, w, H, W))
+    wv = torch.nn.Parameter(T(g['a_w0']).clone().to(DEV), requires_grad=False)
+    opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=False,
+                        direction_forget_factor=0.9 ** 750)
+    opt.run((3,))
+    om = O.MemoryRef(cap, (c, h, w), (1, H, W), 0.1)
+    om.samples[:], om.labels[:], om.pixel_weights[:], om.weights[:] = (T(g['a_samples0']), T(g['a_labels0']), T(g['a_pw0']),
+                                                                      T(g['a_sw0']))
+    ow = T(g['a_w0']).clone()
+    oo = O.GaussNewtonCGRef(O.UpdateProblemRef(om, 1e-2, 1e-2), [ow], fletcher_reeves=False, direction_forget_factor=0.9 ** 750)
+    oo.run((3,))
+    assert rel(wv, ow) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ merge / tracker
+def test_merge_and_count(ops):
+    g = gen(11)
+    for K in (2, 3, 6):
+        m = torch.rand(K, 48, 70, generator=g)
+        m[1, :5] = 0.0
+        m[1, 5:10] = 1.0
+        ref = O.merge_masks(m.clone())
+        out = ops.merge_masks_(m.clone().to(DEV))
+        assert (out.cpu() - ref).abs().max() < 1e-6
+        cnt = ops.count_above(m.to(DEV)).cpu()
+        assert torch.equal(cnt.long(), (m > 0.5).flatten(1).sum(1))
+
+
+def test_tracker_mask_flow_g6(golden):
+    """Tracker.initialize / track with stand-in extractor + refiner, replaying the reference recording."""
+    from frtm_vos_amd.model.tracker import Tracker
+    from frtm_vos_amd.evaluate import AttrDict
+    g = golden('g6_tracker')
+    cin, c, h, w, H, W = [int(v) for v in g['dims']]
+
+    class Ext:
+        def __call__(self, im, layers=None):
+            B = im.shape[0] if im.dim() == 4 else 1
+            return {'layer4': torch.relu(torch.randn(B, cin, h, w, generator=gen(1))).to(DEV)}
+
+    class Aug:
+        def augment_first_frame(self, im, lb):
+            return im.unsqueeze(0).repeat(2, 1, 1, 1), lb.unsqueeze(0).repeat(2, 1, 1, 1)
+
+    class Ref(torch.nn.Module):
+        def __init__(self, logits):
+            super().__init__()
+            self.logits, self.k = logits, 0
+
+        def forward(self, s, features, im_size):
+            n = s.shape[0]
+            z = self.logits[self.k:self.k + n]
+            self.k += n
+            return z
+
+    for tag in ('one', 'two', 'five', 'late'):
+        ids = [int(v) for v in g[tag + '_ids']]
+        late = int(g[tag + '_late'])
+        labels = T(g[tag + '_labels']).to(DEV)
+        dp = AttrDict(layer='layer4', in_channels=cin, c_channels=c, out_channels=1, init_iters=(2, 3), update_iters=(2,),
+                      memory_size=8, train_skipping=8, learning_rate=0.1, pixel_weighting=PW, filter_reg=(1e-4, 1e-2),
+                      precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=750, device=DEV, update_filters=False)
+        trk = Tracker(Aug(), Ext(), dp, Ref(T(g[tag + '_logits']).to(DEV)), DEV)
+        trk.eval()
+        trk.object_ids, trk.current_frame, trk.targets = ids, 0, dict()
+        image = torch.zeros(3, H, W, dtype=torch.uint8, device=DEV)
+        first = [i for i in ids if not (late >= 0 and i == ids[-1])]
+        for t in range(4):
+            old = set(trk.targets.keys())
+            if t == 0:
+                trk.initialize(image, labels, first)
+            elif t == late:
+                trk.initialize(image, labels, [ids[-1]])
+            if old:
+                trk.track(image)
+            assert (trk.current_masks.cpu() - T(g['%s_masks%d' % (tag, t)])).abs().max() < 1e-6, (tag, t)
+            trk.current_frame += 1
+
+
+def test_warp_affine():
+    from frtm_vos_amd.lib.image import warp_affine
+    src = torch.rand(3, 40, 50, generator=gen(4)).to(DEV)
+    eye = np.eye(3)
+    for mode in ('nearest', 'bilinear', 'bicubic'):
+        assert (warp_affine(src, eye, (40, 50), mode) - src).abs().max() < 1e-5
+    shift = np.array([[1, 0, 3], [0, 1, 2], [0, 0, 1]], dtype=np.float64)
+    out = warp_affine(src, shift, (40, 50), 'bilinear')
+    assert (out[:, 2:, 3:] - src[:, :-2, :-3]).abs().max() < 1e-5 and float(out[:, :2].abs().max()) == 0
+    flip = np.array([[-1, 0, 49], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
+    assert (warp_affine(src, flip, (40, 50), 'nearest') - src.flip(-1)).abs().max() < 1e-6
