@@ -197,7 +197,19 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   FRTM_CHECK_ARG(stop_after_layer >= 1 && stop_after_layer <= 5, "frtm_backbone_forward: stop_after_layer must be 1..5");
   hipStream_t st = (hipStream_t)stream;
   const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
-  const size_t need = (size_t)B * 64 * Hs * Ws;                 // the stem output is the largest activation
+  // arena element count = the largest activation of the pass (stem output, or a stage output when the
+  // frame size is odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2))
+  size_t need = (size_t)B * 64 * Hs * Ws;
+  {
+    int ah = (Hs + 1) / 2, aw = (Ws + 1) / 2;
+    const int exp = bb->bottleneck ? 4 : 1;
+    for (int s = 0; s < 4; ++s) {
+      if (s > 0) { ah = (ah + 1) / 2; aw = (aw + 1) / 2; }
+      need = max(need, (size_t)B * (64 << s) * exp * ah * aw);
+      need = max(need, (size_t)B * (64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
+    }
+    need = max(need, (size_t)B * 3 * H * W);
+  }
   if (bb->buf_elems < need) {
     for (auto& b : bb->buf) {
       if (b) FRTM_HIP(hipFree(b));

@@ -119,7 +119,8 @@ class Memory:
         H.call('frtm_memory_insert', H.ptr(ft), H.ptr(self.samples), ft.numel(), slot_dev_ptr)
         lab, pw = self._build_normals(labels, pixel_weights, 1, slot_dev_ptr, 0)
         if self.keep_hires:
-            H.call('frtm_memory_insert', H.ptr(lab.float().contiguous()), H.ptr(self.labels), lab.numel(), slot_dev_ptr)
+            labf = lab.float().contiguous()          # named: H.ptr() only takes the address
+            H.call('frtm_memory_insert', H.ptr(labf), H.ptr(self.labels), labf.numel(), slot_dev_ptr)
             pwt = pw if pw is not None else self._hires_pw(lab)
             H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self.pixel_weights), pwt.numel(), slot_dev_ptr)
 

@@ -107,7 +107,8 @@ def test_filter_kernels(ops, N, C, h, w):
     sw = torch.rand(N, generator=g)
     out = torch.empty(N, h * w, device=DEV)
     sflat = t[:, 0].contiguous()
-    H.call('frtm_stencil', H.ptr(Bm.to(DEV)), H.ptr(cc.to(DEV)), H.ptr(sw.to(DEV)), H.ptr(sflat.to(DEV)), N, h, w, H.ptr(out))
+    Bd, cd, swd, sd = Bm.to(DEV), cc.to(DEV), sw.to(DEV), sflat.to(DEV)      # keep alive: H.ptr() only takes the address
+    H.call('frtm_stencil', H.ptr(Bd), H.ptr(cd), H.ptr(swd), H.ptr(sd), N, h, w, H.ptr(out))
     ref = (O.stencil_apply(Bm, sflat) - cc) * sw[:, None, None]
     assert rel(out.view(N, h, w), ref) < 1e-5
 
@@ -373,7 +374,7 @@ def test_tracker_mask_flow_g6(golden):
                 trk.initialize(image, labels, [ids[-1]])
             if old:
                 trk.track(image)
-            assert (trk.current_masks.cpu() - T(g['%s_masks%d' % (tag, t)])).abs().max() < 1e-6, (tag, t)
+            assert (trk.current_masks.cpu() - T(g["%s_masks%d" % (tag, t)])).abs().max() < 5e-6, (tag, t)   # expf ulp
             trk.current_frame += 1
 
 
