@@ -1,0 +1,234 @@
+"""bench.py -- headline metric of BASELINE.json on synthetic data:
+
+    segmented frames / sec / GPU  (480p, ResNet101, full CG iterations)
+
+One "step" = one frame of a video sequence through the hot path (frame 0 = Tracker.initialize for every
+object: augmentation, 5 trunk passes, joint GN/CG fit; frames >= 1 = Tracker.track: trunk, per-object
+score + refinement, merge, memory insert, and every 8th frame a 10-iteration CG re-solve).  The timed region
+is the reference's own definition of FPS (model/tracker.py:130,159-161): N frames / wall-clock of the
+sequence loop, initialize() included, with a device sync on both sides.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+
+Workload = BASELINE.json configs[2] stand-in ("ResNet101 full-iteration optimizer, dv2017val multi-object"):
+one "dv2017-like" synthetic sequence per rank, 480x854, 2 objects (the DAVIS-2017 val mean), memory 80, c=96,
+random-init weights of the real architectures (no checkpoints / datasets exist on the box).
+N > 1: one process per GPU (torch.distributed, RCCL only for the barrier + max-reduce of the wall time);
+sequences are independent, so ranks never exchange data ("weak" scaling: one sequence per rank).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3          # MI355X fp32 MFMA dense peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=64, help='frames in the timed sequence (frame 0 = initialize)')
+    ap.add_argument('--warmup', type=int, default=8, help='untimed frames on a throw-away sequence')
+    ap.add_argument('--backbone', default='resnet101')
+    ap.add_argument('--objects', type=int, default=2)
+    ap.add_argument('--size', default='480x854')
+    ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=8)
+    return ap.parse_args()
+
+
+class StageTimer:
+    """HIP events on torch's current stream (the stream every frtm_* kernel is enqueued on)."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.spans.setdefault(name, []).append((e0, e1))
+            return out
+        return timed
+
+    def totals(self):
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.spans.items()}
+
+    def reset(self):
+        self.spans = {}
+
+
+def run_sequence(tracker, seq):
+    """The reference's per-sequence loop (model/tracker.py:130-157) without label decoding to PNG."""
+    tracker.current_frame = 0
+    tracker.targets = dict()
+    n = 0
+    for image, labels, new_objects in seq:
+        old = set(tracker.targets.keys())
+        if len(new_objects) > 0:
+            tracker.initialize(image, labels, new_objects)
+        if len(old) > 0:
+            tracker.track(image)
+        tracker.current_frame += 1
+        n += 1
+    return n
+
+
+def cpu_baseline(args, size, n_frames):
+    """The CPU oracle (oracle/cpu_ref.py, 'port') on the host cores: initialize + n_frames tracked frames,
+    1 object, same backbone / iteration schedule / refiner; augmentation replaced by 5 copies of frame 0."""
+    from oracle import cpu_ref as O
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    threads = min(16, os.cpu_count())         # more threads than that only adds contention to the oracle's einsums
+    torch.set_num_threads(threads)
+    seq = SyntheticSequence('cpu', n_frames + 1, size, 1, seed=3)
+    P = O.resnet_random_params(args.backbone, seed=0)
+    cin = {'resnet101': 1024, 'resnet50': 1024, 'resnet18': 256, 'resnet34': 256}[args.backbone]
+    chans = {'layer5': cin * 2, 'layer4': cin, 'layer3': cin // 2, 'layer2': cin // 4}
+    torch.manual_seed(1)
+    refiner = SegNetwork(1, 64, chans, True).eval()
+    iters = ((5, 10, 10, 10), (5,)) if args.fast else ((5, 10, 10, 10, 10), (10,))
+    g = torch.Generator().manual_seed(0)
+    w1 = (torch.rand(96, cin, 1, 1, generator=g) * 2 - 1) / cin ** 0.5
+    w2 = (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / (9 * 96) ** 0.5
+    d = O.DiscriminatorRef(w1, w2, init_iters=iters[0], update_iters=iters[1], CG_forgetting_rate=750, memory_size=80,
+                           pixel_weighting=dict(method='hinge', tf=0.1))
+    t0 = time.time()
+    with torch.no_grad():
+        im0, lb0, _ = seq[0]
+        ft = O.resnet_forward(args.backbone, P, im0.unsqueeze(0).repeat(5, 1, 1, 1), ['layer4'])['layer4']
+        d.init(ft, (lb0 > 0).to(torch.uint8).unsqueeze(0).repeat(5, 1, 1, 1))
+        done = 1
+        for t in range(1, n_frames + 1):
+            if time.time() - t0 > 30.0:       # bounded sample: stop after ~30 s of CPU work
+                break
+            done += 1
+            im = seq[t][0]
+            taps = O.resnet_forward(args.backbone, P, im)
+            s = d.apply(taps['layer4'])
+            y = torch.sigmoid(refiner(s, taps, im.shape[-2:]))
+            masks = torch.zeros(2, *im.shape[-2:])
+            masks[1] = y[0, 0]
+            masks = O.merge_masks(masks)
+            d.update(masks[1][None, None])
+    T = time.time() - t0
+    return {'value': done / T, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/cpu_ref.py: %s %dx%d, 1 object, initialize (no augmentation: 5 copies of frame 0) + %d tracked '
+                      'frames, %d torch threads of %d host cores, %.1f s' % (args.backbone, size[0], size[1], done - 1, threads,
+                                                                             os.cpu_count(), T)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = 'cuda:%d' % (local if world > 1 else 0)
+    size = tuple(int(v) for v in args.size.split('x'))
+
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd import ops
+
+    params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone)
+    tracker = params.get_model()
+    tracker.eval()
+    torch.set_grad_enabled(False)
+
+    timer = StageTimer()
+    ext = tracker.feature_extractor
+    tracker.feature_extractor = _TimedExtractor(ext, timer)
+
+    warm = SyntheticSequence('warm', max(args.warmup, 2), size, args.objects, seed=100 + rank)
+    seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank)
+    warm.preload(dev)
+    seq.preload(dev)
+
+    run_sequence(tracker, warm)                         # untimed: MIOpen find, allocator growth, trunk arena
+    torch.cuda.synchronize()
+    timer.reset()
+    tracker.feature_extractor.flops, tracker.feature_extractor.launches = 0.0, 0
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    n = run_sequence(tracker, seq)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    T = time.time() - t0
+    if dist is not None:
+        tt = torch.tensor([T], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        T = float(tt.item())
+
+    tot = timer.totals()
+    bb_ms, bb_calls = tot.get('trunk', (0.0, 0))
+    flops_total = tracker.feature_extractor.flops
+    n_launch = tracker.feature_extractor.launches
+    achieved = flops_total / (bb_ms * 1e-3) / 1e12 if bb_ms > 0 else 0.0
+    out = {
+        'metric': 'segmented frames/sec/GPU (480p, ResNet101, full CG iters)',
+        'value': world * n / T, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * T / n, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
+                               '%s iterations, memory 80, c=96, random-init weights' %
+                               (args.backbone, size[0], size[1], args.objects, args.steps,
+                                'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)'),
+                   'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm (fp32 MFMA implicit-GEMM conv, whole ResNet trunk)',
+                     'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
+                     'traffic': None,
+                     'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch},
+                     'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
+        'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args, size, args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+class _TimedExtractor:
+    """Brackets every trunk pass with HIP events and counts its algorithmic FLOPs / conv launches."""
+
+    def __init__(self, ext, timer):
+        self.ext, self.timer = ext, timer
+        self.flops, self.launches = 0.0, 0
+        self._call = timer.wrap('trunk', ext.__call__)
+
+    def __call__(self, *a, **k):
+        out = self._call(*a, **k)
+        self.flops += self.ext.last_flops
+        self.launches += self.ext.last_conv_launches
+        return out
+
+    def __getattr__(self, name):
+        return getattr(self.ext, name)
+
+
+if __name__ == '__main__':
+    main()

@@ -15,7 +15,7 @@ P, I, F, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(k, I) for k in ('B', 'Cin', 'Hin', 'Win', 'Cout', 'ksize', 'stride', 'pad',
-                                 'relu', 'out_transposed', 'splitk', 'tile')]
+                                 'relu', 'out_transposed', 'splitk', 'tile', 'w_pitch')]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/frtm_hip.h
@@ -47,6 +47,7 @@ SIGNATURES = {
     'frtm_backbone_set_conv': (I, [P, I, P, P, P, P]),
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_last_flops': (D, [P]),
+    'frtm_backbone_last_conv_launches': (I, [P]),
     'frtm_merge_masks': (I, [P, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),

@@ -6,7 +6,7 @@
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
-void frtm_conv_plan(int M, int Ntot, int nchunks, int* tile, int* splitk);
+void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* splitk);
 
 struct ConvL {
   int Cout, Cin, ks, stride, pad;
@@ -26,6 +26,7 @@ struct frtm_backbone {
   float* ws = nullptr; size_t ws_elems = 0;
   float* pack_tmp = nullptr; size_t pack_tmp_elems = 0;
   double last_flops = 0.0;
+  int last_launches = 0;
 };
 
 __global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __restrict__ img, int HW, const float* __restrict__ sc,
@@ -81,13 +82,13 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
   if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
   frtm_conv_desc d;
   d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = c.pad;
-  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0;
+  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0;
   *Ho = (Hin + 2 * c.pad - c.ks) / c.stride + 1;
   *Wo = (Win + 2 * c.pad - c.ks) / c.stride + 1;
   const size_t need = (size_t)FRTM_CONV_MAX_SPLITK * c.Cout * B * (*Ho) * (*Wo);
   // split-K is only chosen for small outputs; size the workspace for what the planner will pick
   int tile = 0, splitk = 0;
-  frtm_conv_plan(c.Cout, B * (*Ho) * (*Wo), ceil_div(c.Cin * c.ks * c.ks, 32), &tile, &splitk);
+  frtm_conv_plan(c.Cout, B * (*Ho) * (*Wo), ceil_div(c.Cin * c.ks * c.ks, 32), (c.ks == 1 && c.stride == 1 && ((*Ho) * (*Wo)) % 4 == 0) ? 1 : 0, &tile, &splitk);
   if (splitk > 1) {
     const size_t w = (size_t)splitk * c.Cout * B * (*Ho) * (*Wo);
     (void)need;
@@ -95,6 +96,7 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
     if (rc) return rc;
   }
   d.tile = tile; d.splitk = splitk;
+  bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, bb->ws, st);
 }
@@ -175,7 +177,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
   const size_t K = (size_t)c.Cin * c.ks * c.ks;
   hipStream_t st = (hipStream_t)stream;
   if (!c.wT) {
-    FRTM_HIP(hipMalloc((void**)&c.wT, K * c.Cout * sizeof(float)));
+    FRTM_HIP(hipMalloc((void**)&c.wT, (size_t)FRTM_CONV_PACKED_ELEMS(c.Cout, c.Cin, c.ks) * sizeof(float)));
     FRTM_HIP(hipMalloc((void**)&c.scale, c.Cout * sizeof(float)));
     FRTM_HIP(hipMalloc((void**)&c.shift, c.Cout * sizeof(float)));
     if (c.ks > 1) FRTM_HIP(hipMalloc((void**)&c.ktab, K * 3 * sizeof(int)));
@@ -189,6 +191,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 }
 
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
+int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
 
 int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                           const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
@@ -219,6 +222,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
     bb->buf_elems = need;
   }
   bb->last_flops = 0.0;
+  bb->last_launches = 0;
   float* norm = bb->buf[0];
   const size_t npx = (size_t)B * 3 * H * W;
   k_normalize_u8<<<(int)min((npx + 255) / 256, (size_t)4096), 256, 0, st>>>(image_u8, H * W, norm_scale3, norm_bias3, norm, npx);

@@ -22,14 +22,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvParams {
   const float* in; const float* wT; const int* ktab; const float* scale; const float* shift;
   const float* residual; float* out; float* ws;
-  int B, Cin, Hin, Win, M, Ho, Wo, K, stride, pad;
+  int B, Cin, Hin, Win, M, Mp, Ho, Wo, K, stride, pad;
   int Npix, Ntot, relu, out_transposed, splitk, chunks_per_split, nchunks;
+  unsigned in_bytes, w_bytes;
 };
 
 constexpr int BK = 32;
+constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any buffer: raw buffer loads return 0 there
 
-__device__ __forceinline__ void store_out(const ConvParams& p, int m, int n, float v) {
-  const int img = n / p.Npix, rem = n - img * p.Npix;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+__device__ __forceinline__ void store_out(const ConvParams& p, int m, int img, int rem, float v) {
   if (p.scale) v = v * p.scale[m] + p.shift[m];
   const size_t idx = ((size_t)img * p.M + m) * p.Npix + rem;
   if (p.residual) v += p.residual[idx];
@@ -38,71 +48,86 @@ __device__ __forceinline__ void store_out(const ConvParams& p, int m, int n, flo
   else p.out[idx] = v;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool IS1X1>
+// MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
+// MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
+template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int LDA = BM + 16, LDB = BN + 16;          // LD % 32 == 16: the two k rows a 32-lane group reads never share a bank
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
-  constexpr int EA = BK * BM / NT, EB = BK * BN / NT;  // staged elements per thread
-  constexpr int SA = NT / BM, SB = NT / BN;            // k-row stride between a thread's elements
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile");
-  static_assert(NT % BM == 0 && NT % BN == 0 && TM % 16 == 0 && TN % 16 == 0, "tile");
-  __shared__ float As[2][BK][LDA];
-  __shared__ float Bs[2][BK][LDB];
+  constexpr int TA = BM / 4, RA = NT / TA, PA = BK / RA;           // A: dwordx4 along m
+  constexpr int TB4 = BN / 4, RB4 = NT / TB4, PB4 = BK / RB4;      // B (MODE 1): dwordx4 along n
+  constexpr int EB = BK * BN / NT, SB = NT / BN;                   // B (MODE 0): dwords
+  static_assert(BM % 32 == 0 && BN % 64 == 0 && NT % TA == 0 && BK % RA == 0 && BK % RB4 == 0, "tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kc0 = blockIdx.z * p.chunks_per_split;
   const int kc1 = min(p.nchunks, kc0 + p.chunks_per_split);
-
-  // ---- per-thread gather geometry (fixed over the K loop) ----
-  const int am = tid % BM;
-  int ak0 = tid / BM;
-  const int bn = tid % BN;
-  int bk0 = tid / BN;
-  if (BM % 64 == 0) ak0 = __builtin_amdgcn_readfirstlane(ak0);
-  if (BN % 64 == 0) bk0 = __builtin_amdgcn_readfirstlane(bk0);
-  const bool a_ok = (m0 + am) < p.M;
-  const float* a_ptr = p.wT + (m0 + am);
-  const int n = n0 + bn;
-  const bool n_ok = n < p.Ntot;
-  const int img = n_ok ? n / p.Npix : 0;
-  const int rem = n_ok ? n - img * p.Npix : 0;
-  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
-  const float* b_ptr = p.in + (size_t)img * p.Cin * HWin + iy0 * p.Win + ix0;
 
-  float ra[EA], rb[EB];
+  // ---- A: weights [Kp][Mp], zero padded; rows m >= M only feed accumulators that are never stored ----
+  const int acol = (tid % TA) * 4, arow = tid / TA;
+  const unsigned a_off = (unsigned)(m0 + acol) * 4u;
+  // ---- B geometry (fixed over the K loop) ----
+  unsigned b_base = OOB;        // byte offset of (img, ci=0, iy0, ix0)   [MODE 0] / (img, ci=0, pix) [MODE 1]
+  int iy0 = 0, ix0 = 0, bcol, brow;
+  if (MODE == 1) {
+    bcol = (tid % TB4) * 4; brow = tid / TB4;
+    const int n = n0 + bcol;
+    if (n < p.Ntot) { const int img = n / p.Npix; b_base = (unsigned)(img * p.Cin * HWin + (n - img * p.Npix)) * 4u; }
+  } else {
+    bcol = tid % BN; brow = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int n = n0 + bcol;
+    if (n < p.Ntot) {
+      const int img = n / p.Npix, rem = n - img * p.Npix;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      iy0 = oy * p.stride - p.pad; ix0 = ox * p.stride - p.pad;
+      b_base = (unsigned)(img * p.Cin * HWin) * 4u + (unsigned)((iy0 * p.Win + ix0) * 4);
+    } else { iy0 = -(1 << 20); }
+  }
+
+  f32x4 ra[PA];
+  f32x4 rb4[MODE == 1 ? PB4 : 1];
+  float rb[MODE == 1 ? 1 : EB];
   auto gload = [&](int kc) {
     const int kb = kc * BK;
 #pragma unroll
-    for (int i = 0; i < EA; ++i) {
-      const int k = kb + ak0 + i * SA;
-      ra[i] = (a_ok && k < p.K) ? a_ptr[(size_t)k * p.M] : 0.f;
-    }
+    for (int i = 0; i < PA; ++i) ra[i] = buf_ld4(rw, (unsigned)(kb + arow + i * RA) * (unsigned)(p.Mp * 4) + a_off);
+    if (MODE == 1) {
 #pragma unroll
-    for (int i = 0; i < EB; ++i) {
-      const int k = kb + bk0 + i * SB;
-      float v = 0.f;
-      if (IS1X1) {
-        if (n_ok && k < p.K) v = b_ptr[(size_t)k * HWin];
-      } else {
-        if (k < p.K) {
-          const int ci = p.ktab[k * 3], kh = p.ktab[k * 3 + 1], kw = p.ktab[k * 3 + 2];
-          if (n_ok && (unsigned)(iy0 + kh) < (unsigned)p.Hin && (unsigned)(ix0 + kw) < (unsigned)p.Win)
-            v = b_ptr[(size_t)ci * HWin + kh * p.Win + kw];
-        }
+      for (int i = 0; i < PB4; ++i) {
+        const int k = kb + brow + i * RB4;
+        rb4[i] = buf_ld4(rin, (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4));
       }
-      rb[i] = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < EB; ++i) {
+        const int k = kb + brow + i * SB;                  // wave uniform
+        int ci = 0, kh = 0, kw = 0;
+        bool kok = k < p.K;
+        if (p.ktab) { const int kk = kok ? k : 0; ci = p.ktab[kk * 3]; kh = p.ktab[kk * 3 + 1]; kw = p.ktab[kk * 3 + 2]; }
+        else ci = k;
+        const bool ok = kok && (unsigned)(iy0 + kh) < (unsigned)p.Hin && (unsigned)(ix0 + kw) < (unsigned)p.Win;
+        rb[i] = buf_ld1(rin, ok ? b_base + (unsigned)((ci * HWin + kh * p.Win + kw) * 4) : OOB);
+      }
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < EA; ++i) As[buf][ak0 + i * SA][am] = ra[i];
+    for (int i = 0; i < PA; ++i) *(f32x4*)&As[buf][arow + i * RA][acol] = ra[i];
+    if (MODE == 1) {
 #pragma unroll
-    for (int i = 0; i < EB; ++i) Bs[buf][bk0 + i * SB][bn] = rb[i];
+      for (int i = 0; i < PB4; ++i) *(f32x4*)&Bs[buf][brow + i * RB4][bcol] = rb4[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < EB; ++i) Bs[buf][brow + i * SB][bcol] = rb[i];
+    }
   };
 
   f32x4 acc[FM][FN];
@@ -138,20 +163,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   }
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
+  float sc[FM][4], sh[FM][4];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nn = n0 + wn * TN + j * 16 + li;
-      if (nn >= p.Ntot) continue;
+    for (int r = 0; r < 4; ++r) {
+      const int mm = min(m0 + wm * TM + i * 16 + lk * 4 + r, p.M - 1);
+      sc[i][r] = (p.scale && p.splitk == 1) ? p.scale[mm] : 1.f;
+      sh[i][r] = (p.scale && p.splitk == 1) ? p.shift[mm] : 0.f;
+    }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int nn = n0 + wn * TN + j * 16 + li;
+    if (nn >= p.Ntot) continue;
+    const int img = nn / p.Npix, rem = nn - img * p.Npix;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = m0 + wm * TM + i * 16 + lk * 4 + r;
         if (mm >= p.M) continue;
-        if (p.splitk > 1) p.ws[((size_t)blockIdx.z * p.M + mm) * p.Ntot + nn] = acc[i][j][r];
-        else store_out(p, mm, nn, acc[i][j][r]);
+        if (p.splitk > 1) { p.ws[((size_t)blockIdx.z * p.M + mm) * p.Ntot + nn] = acc[i][j][r]; continue; }
+        float v = acc[i][j][r] * sc[i][r] + sh[i][r];
+        const size_t idx = ((size_t)img * p.M + mm) * p.Npix + rem;
+        if (p.residual) v += p.residual[idx];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.out_transposed) p.out[((size_t)img * p.Npix + rem) * p.M + mm] = v;
+        else p.out[idx] = v;
       }
-    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvParams p) {
@@ -160,19 +200,21 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvParams p) {
     const int m = (int)(i / p.Ntot), n = (int)(i - (size_t)m * p.Ntot);
     float s = 0.f;
     for (int z = 0; z < p.splitk; ++z) s += p.ws[(size_t)z * total + i];
-    store_out(p, m, n, s);
+    const int img = n / p.Npix;
+    store_out(p, m, img, n - img * p.Npix, s);
   }
 }
 
-// w (Cout,Cin,ks,ks) -> wT [(ci,kh,kw)][Cout];  ktab[k] = {ci, kh, kw}
+// w (Cout,Cin,ks,ks) -> wT [Kp][Mp] zero padded (Kp = K rounded up to 32, Mp = Cout rounded up to 32);
+// ktab[k] = {ci, kh, kw}
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, int Cout, int Cin, int ks,
                                                        float* __restrict__ wT, int* __restrict__ ktab) {
-  const int K = Cin * ks * ks;
-  const size_t total = (size_t)K * Cout;
+  const int K = Cin * ks * ks, Kp = (K + 31) / 32 * 32, Mp = (Cout + 31) / 32 * 32;
+  const size_t total = (size_t)Kp * Mp;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int k = (int)(i / Cout), m = (int)(i - (size_t)k * Cout);
-    wT[i] = w[(size_t)m * K + k];
-    if (m == 0 && ktab) {
+    const int k = (int)(i / Mp), m = (int)(i - (size_t)k * Mp);
+    wT[i] = (k < K && m < Cout) ? w[(size_t)m * K + k] : 0.f;
+    if (m == 0 && ktab && k < K) {
       const int ci = k / (ks * ks), t = k - ci * ks * ks, kh = t / ks, kw = t - kh * ks;
       ktab[k * 3] = ci;
       ktab[k * 3 + 1] = kh;
@@ -182,28 +224,29 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_tile(const ConvParams& p, bool is1x1, hipStream_t st) {
+static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN), ceil_div(p.M, BM), p.splitk);
-  if (is1x1) k_conv_igemm<BM, BN, WGM, WGN, true><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else k_conv_igemm<BM, BN, WGM, WGN, false><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else k_conv_igemm<BM, BN, WGM, WGN, 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
-// Chooses tile and split-K so that the launch has a few hundred workgroups (256 CUs).
-void frtm_conv_plan(int M, int Ntot, int nchunks, int* tile, int* splitk) {
+// Chooses tile and split-K.  Measured on MI355X (tools/conv_bench.py --sweep, profiles/r01_conv_sweep.txt):
+// these convs are 5-50 us long, so the decisive factor is how many workgroups are co-resident: a workgroup is
+// 4 waves = one wave per SIMD, and a lone wave cannot overlap its own staging with its MFMAs, so ~3 workgroups
+// per CU (~800 over 256 CUs) are needed before the matrix pipe stays busy.
+//  * gather mode (3x3, 7x7, strided): 64x64 tile, split-K up to ~832 workgroups;
+//  * stride-1 1x1 (dwordx4 staging): 32x64 tile (more workgroups), split-K only for the 15x27 stage.
+void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* splitk) {
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(Ntot, bn); };
-  int t;
-  if (M % 128 == 0 && blocks(128, 64) >= 1024) t = FRTM_TILE_128x64;
-  else if (M % 64 == 0 && blocks(64, 64) >= 400) t = FRTM_TILE_64x64;
-  else if (M % 64 != 0 || blocks(64, 64) < 200) t = FRTM_TILE_32x64;
-  else t = FRTM_TILE_64x64;
-  if (*tile == 0) *tile = t;
+  if (*tile == 0) *tile = vec1x1 ? FRTM_TILE_32x64 : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
   const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x64) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
     int s = 1;
-    if (nb < 256) s = ceil_div(512, nb);
+    const int target = vec1x1 ? 512 : 832;
+    if (nb * 2 <= target) s = (target + nb / 2) / nb;
     s = min(s, max(1, nchunks / 4));
     s = min(s, FRTM_CONV_MAX_SPLITK);
-    *splitk = s;
+    *splitk = max(s, 1);
   }
 }
 
@@ -211,7 +254,7 @@ extern "C" {
 
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, float* wT, int* ktab, frtm_stream_t stream) {
   FRTM_CHECK_ARG(w_oihw && wT && Cout > 0 && Cin > 0 && ksize > 0, "frtm_conv_pack_weights: bad argument");
-  const size_t total = (size_t)Cout * Cin * ksize * ksize;
+  const size_t total = (size_t)((Cin * ksize * ksize + 31) / 32 * 32) * ((Cout + 31) / 32 * 32);
   k_pack_weights<<<(int)min((total + 255) / 256, (size_t)2048), 256, 0, (hipStream_t)stream>>>(w_oihw, Cout, Cin, ksize, wT, ktab);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
@@ -233,19 +276,32 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   p.Ntot = d->B * p.Npix;
   p.relu = d->relu; p.out_transposed = d->out_transposed;
   p.nchunks = ceil_div(p.K, BK);
+  p.Mp = (p.M + 31) / 32 * 32;
+  size_t w_bytes = (size_t)p.nchunks * BK * p.Mp * 4;
+  if (d->w_pitch > 0) {
+    FRTM_CHECK_ARG(d->w_pitch >= p.M && d->w_pitch % 4 == 0 && ((size_t)wT) % 16 == 0,
+                   "frtm_conv2d: w_pitch must be >= Cout, a multiple of 4, and wT 16-byte aligned (got %d)", d->w_pitch);
+    p.Mp = d->w_pitch;
+    w_bytes = (size_t)p.K * p.Mp * 4;
+  }
+  const size_t in_bytes = (size_t)d->B * d->Cin * d->Hin * d->Win * 4;
+  FRTM_CHECK_ARG(in_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull, "frtm_conv2d: tensor too large for 32-bit buffer offsets");
+  p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab, "frtm_conv2d: ktab required for ksize > 1");
+  const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);
+  if (is1x1) p.ktab = nullptr;
   int tile = d->tile, splitk = d->splitk;
-  frtm_conv_plan(p.M, p.Ntot, p.nchunks, &tile, &splitk);
+  frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
   splitk = max(1, min(splitk, p.nchunks));
   p.chunks_per_split = ceil_div(p.nchunks, splitk);
   p.splitk = ceil_div(p.nchunks, p.chunks_per_split);
   FRTM_CHECK_ARG(p.splitk == 1 || workspace, "frtm_conv2d: split-K needs a workspace");
   hipStream_t st = (hipStream_t)stream;
   switch (tile) {
-    case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(p, is1x1, st); break;
-    case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(p, is1x1, st); break;
-    case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(p, is1x1, st); break;
+    case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(p, vec1x1, st); break;
+    case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(p, vec1x1, st); break;
+    case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(p, vec1x1, st); break;
     default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
   }
   FRTM_LAUNCH_CHECK();

@@ -95,7 +95,8 @@ class DiscriminatorLoss(MinimizationProblem):
     def _project_grad(self, lam2, pvec, sign, out):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
         H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)
-        ops.conv2d(self.Xt, self.D, self.c, out=self.g1, out_transposed=True, shape=(1, self.N * self.hw, 1, self.Cin))
+        ops.conv2d(self.Xt, self.D, self.c, out=self.g1, out_transposed=True, shape=(1, self.N * self.hw, 1, self.Cin),
+                   w_pitch=self.c)
         H.call('frtm_vec_reduce_slabs', H.ptr(self.g1), 1, 0, self.Cin * self.c, lam2, pvec, sign, out)
 
     def linearize(self, x, b):
@@ -108,7 +109,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return
         n1 = self.Cin * c
         ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
-        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w))
+        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c)
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
         self._stencil(True)
         self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
@@ -124,7 +125,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return
         n1 = self.Cin * c
         p1, p2 = p[:n1], p[n1:]
-        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w))
+        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c)
         ops.filter_scores(self.P, self.w2.data, out=self.s, n=N)
         ops.filter_scores(self.Z, p2, out=self.s, n=N, accumulate=True)
         self._stencil(False)
@@ -199,7 +200,7 @@ class Discriminator(nn.Module):
         self._w1T_key = None
 
     def forward(self, x):
-        cft = ops.conv2d(x.contiguous(), self._project_T(), self.project.out_channels)
+        cft = ops.conv2d(x.contiguous(), self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)
         return ops.filter_scores(cft, self.filter.weight.data)
 
     def _tf(self):
@@ -227,7 +228,7 @@ class Discriminator(nn.Module):
                                   standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
         optimizer.run(self.init_iters)
         self._invalidate()
-        xp = ops.conv2d(x, self._project_T(), self.project.out_channels)        # re-project (:178)
+        xp = ops.conv2d(x, self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)   # re-project (:178)
         # memory + filter-only problem used for the rest of the sequence
         memory = Memory(self.memory_size, xp.shape[-3:], y.shape[-3:], dev, self.learning_rate,
                         pixel_weighting=self.pw_params)
@@ -243,7 +244,7 @@ class Discriminator(nn.Module):
         """Per-frame scoring (reference :201-206)."""
         H.require_gpu(ft, 'Discriminator.apply')
         self.frame_num += 1
-        cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels)
+        cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)
         self.current_sample = cft
         return ops.filter_scores(cft, self.filter.weight.data)
 

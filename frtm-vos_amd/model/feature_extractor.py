@@ -139,6 +139,7 @@ class ResnetFeatureExtractor:
         self._handle = None
         self.device = None
         self.last_flops = 0.0
+        self.last_conv_launches = 0
 
     def __del__(self):
         try:
@@ -205,6 +206,7 @@ class ResnetFeatureExtractor:
         H.call('frtm_backbone_forward', self._handle, H.ptr(x), B, Hh, Ww, H.ptr(self.norm_weight), H.ptr(self.norm_bias),
                *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
+        self.last_conv_launches = H.lib().frtm_backbone_last_conv_launches(self._handle)
         return out
 
     def get_out_channels(self):

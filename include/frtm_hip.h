@@ -120,7 +120,8 @@ int frtm_transpose2d(const float* in, int rows, int cols, float* out, frtm_strea
  * the 1x1 projection, discriminator.py:81,203; the init-problem GEMMs)
  *   out[img, m, oy, ox] = epilogue( sum_{ci,kh,kw} wT[(ci,kh,kw), m] * in[img, ci, oy*s-pad+kh, ox*s-pad+kw] )
  *   epilogue: (* scale[m] + shift[m])?  (+ residual)?  relu?
- * wT: weights pre-transposed to [K = Cin*kh*kw][M = Cout] (see frtm_conv_pack_weights).
+ * wT: weights pre-transposed and zero padded to [Kp][Mp], Kp = K rounded up to 32 (K = Cin*kh*kw), Mp = Cout rounded
+ *     up to 32 (see frtm_conv_pack_weights; FRTM_CONV_PACKED_ELEMS gives the element count).
  * ktab: int32[K*3] = {ci, kh, kw} built by frtm_conv_pack_weights; may be NULL for 1x1 convs.
  * out_transposed: write out[img, pix, m] instead of out[img, m, pix].
  * splitk: 0 = auto, 1 = none, >1: partial sums go through `workspace` (>= splitk*Cout*B*Ho*Wo floats;
@@ -133,8 +134,11 @@ typedef struct {
   int relu, out_transposed;
   int splitk;              /* 0 = auto */
   int tile;                /* 0 = auto, else FRTM_TILE_* */
+  int w_pitch;             /* 0: wT is the padded [Kp][Mp] image of frtm_conv_pack_weights;
+                              >0: wT is a plain [K][w_pitch] matrix (w_pitch >= Cout, multiple of 4, 16-byte aligned) */
 } frtm_conv_desc;
 #define FRTM_CONV_MAX_SPLITK 32
+#define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) ((((Cin) * (k) * (k) + 31) / 32 * 32) * (((Cout) + 31) / 32 * 32))
 #define FRTM_TILE_64x64 1
 #define FRTM_TILE_32x64 2
 #define FRTM_TILE_128x64 3
@@ -163,6 +167,8 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
                           int stop_after_layer, frtm_stream_t stream);
 /* FLOPs (2*MAC over all convs) of the last forward() call. */
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
+/* Number of convolutions (k_conv_igemm launches) of the last forward() call. */
+int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb);
 
 /* ------------------------------------------------------------------------------------------
  * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).

@@ -163,9 +163,9 @@ def test_conv_as_weight_gradient(ops):
     D = torch.randn(N, hw, c, generator=g)
     X = torch.randn(N, hw, Cin, generator=g)
     ref = torch.einsum('npc,npk->ck', D.double(), X.double()).float()
-    out = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin))
+    out = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin), w_pitch=c)
     assert rel(out.view(c, Cin), ref) < 3e-5
-    outT = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin), out_transposed=True)
+    outT = ops.conv2d(X.to(DEV), D.to(DEV).view(N * hw, c), c, shape=(1, N * hw, 1, Cin), out_transposed=True, w_pitch=c)
     assert rel(outT.view(Cin, c), ref.t()) < 3e-5
 
 
