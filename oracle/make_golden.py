@@ -14,6 +14,7 @@ Fixture list:
   g4_init            joint problem: b, A(p1,p2), weights after run((5,10,10,10)) / (5,10,10,10,10)
   g5_disc            Discriminator.init -> (apply, update) x 17
   g6_tracker         Tracker.initialize / track mask flow for 1, 2, 5 objects (+ late object)
+  g7_segnet          SegNetwork.forward (refiner) on name-seeded weights, with and without BatchNorm
 """
 import os
 import sys
@@ -319,9 +320,49 @@ def g6():
     npz('g6_tracker', **res)
 
 
+# ----------------------------------------------------------------------------------- G7
+def keyed_state_dict(module):
+    """Deterministic weights from the key NAME (crc32 seed), so that the other side can rebuild the very same
+    state dict without sharing module-construction order."""
+    sd = {}
+    for k, v in module.state_dict().items():
+        g = torch.Generator().manual_seed(zlib.crc32(k.encode()) & 0x7fffffff)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = v.clone()
+        elif k.endswith('running_var'):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif v.dim() == 4:
+            sd[k] = torch.randn(v.shape, generator=g) / (v.shape[1] * v.shape[2] * v.shape[3]) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1 + (1.0 if k.endswith('.1.weight') else 0.0)
+    return sd
+
+
+def g7():
+    from collections import OrderedDict
+    chans = OrderedDict(layer5=32, layer4=16, layer3=8, layer2=8)
+    res = {}
+    for tag, bn in (('bn', True), ('nobn', False)):
+        net = R.SegNetwork(1, 8, chans, bn).eval()
+        net.load_state_dict(keyed_state_dict(net))
+        g = gen(70)
+        feats = {'layer5': torch.randn(1, 32, 3, 5, generator=g), 'layer4': torch.randn(1, 16, 6, 9, generator=g),
+                 'layer3': torch.randn(1, 8, 12, 18, generator=g), 'layer2': torch.randn(1, 8, 24, 35, generator=g)}
+        scores = torch.randn(3, 1, 6, 9, generator=g)
+        with torch.no_grad():
+            outs = torch.cat([net(scores[k:k + 1], feats, (48, 70)) for k in range(3)])     # one object per call
+        res[tag + '_out'] = outs
+        res[tag + '_nkeys'] = len(net.state_dict())
+        if tag == 'bn':
+            for L, t in feats.items():
+                res['ft_' + L] = t
+            res['scores'] = scores
+    npz('g7_segnet', **res)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
     for name in which:
         globals()[name]()

@@ -1,0 +1,222 @@
+"""CPU-only tests: C-ABI export coverage, host logic of the API mirror, refiner parity with the reference
+recording (G7), sequence sharding with a 2-process gloo group."""
+import os
+import re
+import subprocess
+import sys
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = torch.from_numpy
+
+
+def test_abi_exports_every_declared_symbol():
+    from frtm_vos_amd import _hip
+    hdr = open(os.path.join(ROOT, 'include', 'frtm_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = set(re.findall(r'\b(frtm_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 30
+    L = _hip.lib()                                   # loads without a GPU
+    for n in names:
+        assert hasattr(L, n), 'libfrtm_hip.so does not export %s' % n
+        assert n in _hip.SIGNATURES, '_hip.SIGNATURES lacks %s' % n
+    assert set(_hip.SIGNATURES) <= names
+    assert L.frtm_version() >= 100
+    assert L.frtm_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    from frtm_vos_amd.model.discriminator import Discriminator
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    with pytest.raises(RuntimeError):
+        Memory(4, (2, 3, 3), (1, 8, 8), 'cpu', 0.1)
+    with pytest.raises(RuntimeError):
+        ResnetFeatureExtractor('resnet18').to('cpu')
+    d = Discriminator(in_channels=8, c_channels=4, device='cpu')
+    with pytest.raises(RuntimeError):
+        d.apply(torch.zeros(1, 8, 3, 3))
+    with pytest.raises(ValueError):
+        ResnetFeatureExtractor('resnet7')
+
+
+def test_oracle_is_not_imported_by_the_product():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'frtm-vos_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('# oracle', ''), '%s mentions the oracle' % f
+                assert '/root/reference' not in src
+
+
+def test_tensorlist_algebra():
+    from frtm_vos_amd.lib.tensorlist import TensorList, tensor_operation
+    a = TensorList([torch.ones(2), torch.full((3,), 2.0)])
+    b = a * 2 + a - 1
+    assert torch.equal(b[0], torch.full((2,), 2.0)) and torch.equal(b[1], torch.full((3,), 5.0))
+    assert [float(v) for v in (a @ a)] == [2.0, 12.0]
+    assert torch.equal((3 / a)[1], torch.full((3,), 1.5)) and torch.equal((a - 1)[0], torch.zeros(2))
+    c = a.clone()
+    c += a
+    c /= 2
+    assert torch.equal(c[1], a[1])
+    assert isinstance(a[0:1], TensorList) and isinstance(a[[0, 1]], TensorList)
+    assert [tuple(t.shape) for t in a.view(-1, 1)] == [(2, 1), (3, 1)]
+    with pytest.raises(AttributeError):
+        a.__torch_function__                     # the upstream class answers here and breaks autograd
+    with pytest.raises(AttributeError):
+        a.not_a_tensor_method
+    x = torch.ones(2, requires_grad=True)
+    y = TensorList([(x * 3).sum()])
+    g = torch.autograd.grad(y, [x])              # works because dunder lookups fail cleanly
+    assert torch.equal(g[0], torch.full((2,), 3.0))
+    f = tensor_operation(lambda u, v=1: u * v)
+    assert torch.equal(f(a, v=2)[1], torch.full((3,), 4.0))
+    assert TensorList([TensorList([torch.zeros(1)]), torch.zeros(2)]).unroll().__len__() == 2
+
+
+def test_parameters_match_reference_hyperparameters():
+    from frtm_vos_amd.evaluate import Parameters
+    p = Parameters(None, fast=False, device='cuda:0', feature_extractor='resnet101')
+    d = p.disc_params
+    assert (d.c_channels, d.memory_size, d.train_skipping, d.learning_rate) == (96, 80, 8, 0.1)       # evaluate.py:77-84
+    assert d.init_iters == (5, 10, 10, 10, 10) and d.update_iters == (10,) and d.CG_forgetting_rate == 750
+    assert d.filter_reg == (1e-4, 1e-2) and d.precond == (1e-4, 1e-2) and d.pixel_weighting == dict(method='hinge', tf=0.1)
+    f = Parameters(None, fast=True, feature_extractor='resnet18')
+    assert f.disc_params.init_iters == (5, 10, 10, 10) and f.disc_params.update_iters == (5,) and f.in_channels == 256
+    w = {'refiner.TSE.layer4.reduce.0.weight': torch.zeros(64, 1024, 1, 1)}
+    assert Parameters(w).feature_extractor == 'resnet101'
+    with pytest.raises(ValueError):
+        Parameters({'refiner.TSE.layer4.reduce.0.weight': torch.zeros(64, 7, 1, 1)})
+    assert p.refnet_params.layers == ('layer5', 'layer4', 'layer3', 'layer2') and p.aug_params.num_aug == 5
+
+
+def test_resnet_container_has_torchvision_keys():
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    from oracle import cpu_ref as O
+    for name, n in (('resnet18', 120 + 2), ('resnet101', 624 + 2)):
+        ext = ResnetFeatureExtractor(name)
+        sd = ext.resnet.state_dict()
+        want = O.resnet_param_shapes(name)
+        assert all(k in sd and tuple(sd[k].shape) == tuple(s) for k, s in want.items())
+        assert len([k for k in sd if not k.endswith('num_batches_tracked')]) == len(want)
+        assert list(ext.get_out_channels().keys()) == ['layer5', 'layer4', 'layer3', 'layer2', 'layer1']
+        P = O.resnet_random_params(name, seed=0)          # same seeded synthetic weights as the oracle
+        assert all(torch.equal(sd[k], P[k]) for k in P)
+
+
+def _keyed_state_dict(module):
+    sd = {}
+    for k, v in module.state_dict().items():
+        g = torch.Generator().manual_seed(zlib.crc32(k.encode()) & 0x7fffffff)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = v.clone()
+        elif k.endswith('running_var'):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif v.dim() == 4:
+            sd[k] = torch.randn(v.shape, generator=g) / (v.shape[1] * v.shape[2] * v.shape[3]) ** 0.5
+        else:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1 + (1.0 if k.endswith('.1.weight') else 0.0)
+    return sd
+
+
+def test_segnetwork_g7(golden):
+    """Batched / hoisted refiner == the reference's per-object refiner, same checkpoint keys."""
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    g = golden('g7_segnet')
+    chans = OrderedDict(layer5=32, layer4=16, layer3=8, layer2=8)
+    feats = {L: T(g['ft_' + L]) for L in chans}
+    scores = T(g['scores'])
+    for tag, bn in (('bn', True), ('nobn', False)):
+        net = SegNetwork(1, 8, chans, bn).eval()
+        assert len(net.state_dict()) == int(g[tag + '_nkeys'])
+        net.load_state_dict(_keyed_state_dict(net))          # strict: identical key set
+        with torch.no_grad():
+            out = net(scores, feats, (48, 70))              # all three objects in one pass
+        assert out.shape == (3, 1, 48, 70)
+        assert (out - T(g[tag + '_out'])).abs().max() < 2e-5
+    full = SegNetwork(1, 64, OrderedDict(layer5=2048, layer4=1024, layer3=512, layer2=256), True)
+    assert len(full.state_dict()) == 140 and 'TSE.layer4.reduce.0.weight' in full.state_dict()
+
+
+def test_augmenter_transform_and_draws():
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params)
+    np.random.seed(0)
+    locs = aug._target_locations(5, (480, 854))
+    assert len(locs) == 5 and all(0 < x < 1 and 0 < y < 1 for x, y in locs)
+    specs = aug._draw_specs(dict(aug.params.fg_aug_params), 4)
+    assert len(specs) == 4 and set(specs[0]) == {'rotation', 'fliplr', 'scale', 'skew', 'blur_size', 'blur_angle'}
+    spec = dict(location=(0.5, 0.5), rotation=0.0, fliplr=False, scale=1.0, skew=(0.0, 0.0), blur_size=0.0, blur_angle=0)
+    Tm, G = aug._transform(spec, (100.0, 50.0, 40, 30), (480, 854))
+    assert G is None and np.allclose(Tm @ np.array([100.0, 50.0, 1.0]), [427.0, 240.0, 1.0])    # target centre -> image centre
+    spec.update(fliplr=True, scale=2.0, blur_size=2.0, blur_angle=45)
+    Tm, G = aug._transform(spec, (100.0, 50.0, 40, 30), (480, 854))
+    assert np.allclose(Tm[:2, :2], [[-2, 0], [0, 2]]) and G.shape[0] % 2 == 1 and abs(G.sum() - 1) < 1e-5
+
+
+def test_synthetic_sequence_protocol():
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    s = SyntheticSequence('s', 6, (64, 96), 2, seed=3, late_object_at=2)
+    assert len(s) == 6 and s.obj_ids == [1, 2] and len(s.frame_names) == 6
+    im, lb, new = s[0]
+    assert im.dtype == torch.uint8 and im.shape == (3, 64, 96) and new == [1] and set(lb.unique().tolist()) <= {0, 1}
+    assert s[1][2] == [] and s[2][2] == [2] and set(s[2][1].unique().tolist()) <= {0, 2}
+    s2 = SyntheticSequence('s', 6, (64, 96), 2, seed=3, late_object_at=2)
+    assert all(torch.equal(a, b) for a, b in zip(s.images, s2.images))        # seeded
+
+
+def test_solver_argument_errors():
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG, MinimizationProblem
+    with pytest.raises(TypeError):
+        GaussNewtonCG(MinimizationProblem(), [torch.zeros(1)])
+
+    class P(MinimizationProblem):
+        def initialize(self): pass
+        def vector_layout(self): return 1, 0, 1.0, 1.0
+        def linearize(self, x, b): pass
+        def apply_A(self, p, q): pass
+        def apply_step(self, x, s, d): pass
+        def views(self, f): return [f]
+    opt = GaussNewtonCG(P(), [torch.zeros(1)])
+    with pytest.raises(ValueError):
+        opt.run(3)                       # reference optimizer.py:59-62
+    assert opt.run([]) is None           # zero GN iterations -> None (optimizer.py:65-66)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from frtm_vos_amd.shard import shard_sequences, aggregate_throughput
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'], rank=rank, world_size=world)
+seqs = ['s%%d' %% i for i in range(7)]
+mine = shard_sequences(seqs, rank, world)
+frames = 10 * len(mine)
+fps, f, t = aggregate_throughput(frames, 1.0 + rank)
+got = [None] * world
+dist.all_gather_object(got, mine)
+if rank == 0:
+    flat = sorted(s for part in got for s in part)
+    assert flat == sorted(seqs) and len(set(flat)) == len(flat), got
+    assert f == 70.0 and t == 2.0 and abs(fps - 35.0) < 1e-9, (fps, f, t)
+    print('SHARD_OK')
+dist.destroy_process_group()
+'''
+
+
+def test_sharding_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29613')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'SHARD_OK' in outs[0]
