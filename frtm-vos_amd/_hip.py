@@ -15,7 +15,7 @@ P, I, F, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(k, I) for k in ('B', 'Cin', 'Hin', 'Win', 'Cout', 'ksize', 'stride', 'pad',
-                                 'relu', 'out_transposed', 'splitk', 'tile', 'w_pitch')]
+                                 'relu', 'out_transposed', 'splitk', 'tile', 'w_layout', 'w_pitch')]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/frtm_hip.h
@@ -38,7 +38,7 @@ SIGNATURES = {
     'frtm_cg_update': (I, [P, P, P, P, P, I, I, F, F, I, I, I, P, P, P]),
     'frtm_vec_axpy': (I, [P, F, P, I, P]),
     'frtm_transpose2d': (I, [P, I, I, P, P]),
-    'frtm_conv_pack_weights': (I, [P, I, I, I, P, P, P]),
+    'frtm_conv_pack_weights': (I, [P, I, I, I, I, P, P, P]),
     'frtm_conv2d': (I, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P]),
     'frtm_backbone_create': (I, [I, ctypes.POINTER(P)]),
     'frtm_backbone_destroy': (I, [P]),

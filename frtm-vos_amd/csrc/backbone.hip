@@ -3,6 +3,7 @@
 // enqueues ~105 kernels on the caller's stream: no Python between the convs, weights and activation
 // buffers stay resident in HBM (288 GB: nothing is ever freed or re-packed per frame).
 #include <vector>
+#include <algorithm>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
@@ -12,6 +13,7 @@ struct ConvL {
   int Cout, Cin, ks, stride, pad;
   float* wT = nullptr; float* scale = nullptr; float* shift = nullptr; int* ktab = nullptr;
   bool loaded = false;
+  int layout = 0;
 };
 struct BlockL { int conv[3]; int nconv; int ds; };   // conv indices (ds = -1: identity shortcut)
 
@@ -82,20 +84,17 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
   if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
   frtm_conv_desc d;
   d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = c.pad;
-  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0;
+  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0; d.w_layout = c.layout;
   *Ho = (Hin + 2 * c.pad - c.ks) / c.stride + 1;
   *Wo = (Win + 2 * c.pad - c.ks) / c.stride + 1;
-  const size_t need = (size_t)FRTM_CONV_MAX_SPLITK * c.Cout * B * (*Ho) * (*Wo);
-  // split-K is only chosen for small outputs; size the workspace for what the planner will pick
-  int tile = 0, splitk = 0;
-  frtm_conv_plan(c.Cout, B * (*Ho) * (*Wo), ceil_div(c.Cin * c.ks * c.ks, 32), (c.ks == 1 && c.stride == 1 && ((*Ho) * (*Wo)) % 4 == 0) ? 1 : 0, &tile, &splitk);
-  if (splitk > 1) {
-    const size_t w = (size_t)splitk * c.Cout * B * (*Ho) * (*Wo);
-    (void)need;
-    int rc = ensure(&bb->ws, &bb->ws_elems, w);
+  // conv2d plans tile/split-K itself; the workspace must cover the largest split it can pick.  Split-K is only
+  // chosen when the launch has < ~800 workgroups, i.e. Cout*N <= ~800*64*64 elements, so bound it by that.
+  {
+    const size_t out_elems = (size_t)c.Cout * B * (*Ho) * (*Wo);
+    const size_t w = std::min((size_t)FRTM_CONV_MAX_SPLITK * out_elems, (size_t)16 * 1024 * 1024);
+    int rc = ensure(&bb->ws, &bb->ws_elems, std::max(w, out_elems * 2));
     if (rc) return rc;
   }
-  d.tile = tile; d.splitk = splitk;
   bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, bb->ws, st);
@@ -182,7 +181,8 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
     FRTM_HIP(hipMalloc((void**)&c.shift, c.Cout * sizeof(float)));
     if (c.ks > 1) FRTM_HIP(hipMalloc((void**)&c.ktab, K * 3 * sizeof(int)));
   }
-  int rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, c.ks, c.wT, c.ktab, stream);
+  c.layout = (c.ks == 3 && c.stride == 1 && c.pad == 1) ? FRTM_WLAYOUT_HALO3X3 : FRTM_WLAYOUT_GEMM;
+  int rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, c.ks, c.layout, c.wT, c.ktab, stream);
   if (rc) return rc;
   FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   FRTM_HIP(hipMemcpyAsync(c.shift, bn_shift, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -194,6 +194,164 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a halo tile in LDS ("im2col-free" in LDS as well).
+// The pixel tile is TH x TW = 64 output pixels of one image; per chunk of 8 input channels the raw
+// (TH+2) x (TW+2) input patch is staged ONCE (zero border through buffer-load bounds checks) and the nine
+// tap shifts are applied by the B-fragment LDS reads.  K order inside a chunk is (tap, ci) so that the four
+// k rows of one MFMA are four channels at the same tap: their LDS planes are PL apart, PL == 16 (mod 32),
+// i.e. conflict free.  Weights come packed as [chunk][tap][ci8][Mp] (frtm_conv_pack_weights, layout 1).
+// ------------------------------------------------------------------------------------------
+constexpr int HCI = 8;                  // input channels per chunk
+constexpr int HK = HCI * 9;             // k rows per chunk
+
+template <int BM, int WGM, int WGN, int TW>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParams p) {
+  constexpr int NT = 64 * WGM * WGN, BN = 64, TH = 64 / TW;
+  constexpr int LDA = BM + 16;
+  constexpr int PW = TW + 2, PH = TH + 2;
+  constexpr int PLraw = PW * PH, PL = ((PLraw + 15) / 32) * 32 + 16;      // plane pitch == 16 (mod 32), >= PLraw
+  static_assert(PL >= PLraw && PL % 32 == 16, "plane pitch");
+  constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
+  constexpr int TA = BM / 4, RA = NT / TA, PA = (HK + RA - 1) / RA;
+  constexpr int NB = HCI * PLraw, PB = (NB + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) float As[2][HK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][HCI * PL];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+  int bt = blockIdx.x;
+  const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
+  const int ty = bt / tiles_x, tx = bt - ty * tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int m0 = blockIdx.y * BM;
+  const int kc0 = blockIdx.z * p.chunks_per_split;
+  const int kc1 = min(p.nchunks, kc0 + p.chunks_per_split);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
+  const int HWin = p.Hin * p.Win;
+
+  const int acol = (tid % TA) * 4, arow = tid / TA;
+  const unsigned a_off = (unsigned)(m0 + acol) * 4u;
+  // B staging: element e = tid + i*NT of the [HCI][PH][PW] patch
+  unsigned b_goff[PB]; int b_loff[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int e = tid + i * NT;
+    const int ci = e / PLraw, r = (e - ci * PLraw) / PW, c = e - ci * PLraw - r * PW;
+    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    const bool ok = e < NB && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+    b_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
+    b_loff[i] = e < NB ? ci * PL + r * PW + c : -1;
+  }
+
+  f32x4 ra[PA];
+  float rb[PB];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int row = arow + i * RA;
+      ra[i] = buf_ld4(rw, row < HK ? (unsigned)(kc * HK + row) * (unsigned)(p.Mp * 4) + a_off : OOB);
+    }
+    const unsigned cstep = (unsigned)(kc * HCI) * (unsigned)(HWin * 4);
+    const bool tail = (kc * HCI + HCI) > p.Cin;                     // last chunk of a Cin that is not a multiple of 8
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      unsigned o = b_goff[i] == OOB ? OOB : b_goff[i] + cstep;
+      if (tail && (kc * HCI + (tid + i * NT) / PLraw) >= p.Cin) o = OOB;
+      rb[i] = buf_ld1(rin, o);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) { const int row = arow + i * RA; if (row < HK) *(f32x4*)&As[buf][row][acol] = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) if (b_loff[i] >= 0) Bs[buf][b_loff[i]] = rb[i];
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lk = lane >> 4, li = lane & 15;
+  int pb[FN];                                              // LDS offset of this lane's pixel (tap (0,0)) per fragment
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int pt = wn * TN + j * 16 + li;
+    pb[j] = lk * PL + (pt / TW) * PW + (pt % TW);
+  }
+  if (kc0 < kc1) { gload(kc0); lstore(0); }
+  __syncthreads();
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const int cur = (kc - kc0) & 1;
+    const bool more = (kc + 1) < kc1;
+    if (more) gload(kc + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int cg = 0; cg < HCI / 4; ++cg) {
+        float af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = As[cur][tap * HCI + cg * 4 + lk][wm * TM + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = Bs[cur][pb[j] + cg * 4 * PL + (tap / 3) * PW + (tap % 3)];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  float sc[FM][4], sh[FM][4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mm = min(m0 + wm * TM + i * 16 + lk * 4 + r, p.M - 1);
+      sc[i][r] = (p.scale && p.splitk == 1) ? p.scale[mm] : 1.f;
+      sh[i][r] = (p.scale && p.splitk == 1) ? p.shift[mm] : 0.f;
+    }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int pt = wn * TN + j * 16 + li;
+    const int yy = y0 + pt / TW, xx = x0 + pt % TW;
+    if (yy >= p.Ho || xx >= p.Wo) continue;
+    const int rem = yy * p.Wo + xx, nn = img * p.Npix + rem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = m0 + wm * TM + i * 16 + lk * 4 + r;
+        if (mm >= p.M) continue;
+        if (p.splitk > 1) { p.ws[((size_t)blockIdx.z * p.M + mm) * p.Ntot + nn] = acc[i][j][r]; continue; }
+        float v = acc[i][j][r] * sc[i][r] + sh[i][r];
+        const size_t idx = ((size_t)img * p.M + mm) * p.Npix + rem;
+        if (p.residual) v += p.residual[idx];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.out_transposed) p.out[((size_t)img * p.Npix + rem) * p.M + mm] = v;
+        else p.out[idx] = v;
+      }
+  }
+}
+
+// w (Cout,Cin,3,3) -> halo layout [chunk = ci/8][tap][ci%8][Mp], zero padded (ci >= Cin, m >= Cout)
+__global__ __launch_bounds__(256) void k_pack_weights_halo(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wT) {
+  const int nch = (Cin + HCI - 1) / HCI, Mp = (Cout + 31) / 32 * 32;
+  const size_t total = (size_t)nch * HK * Mp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i % Mp);
+    const int row = (int)(i / Mp);
+    const int ch = row / HK, rr = row - ch * HK, tap = rr / HCI, ci = ch * HCI + rr % HCI;
+    wT[i] = (m < Cout && ci < Cin) ? w[((size_t)m * Cin + ci) * 9 + tap] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvParams p) {
   const size_t total = (size_t)p.M * p.Ntot;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -250,10 +408,39 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
   }
 }
 
+template <int BM, int WGM, int WGN>
+static void launch_halo(const ConvParams& p, int tw, hipStream_t st) {
+  const int th = 64 / tw;
+  dim3 g(p.B * ceil_div(p.Ho, th) * ceil_div(p.Wo, tw), ceil_div(p.M, BM), p.splitk);
+  if (tw == 4) k_conv3x3_halo<BM, WGM, WGN, 4><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else if (tw == 8) k_conv3x3_halo<BM, WGM, WGN, 8><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else k_conv3x3_halo<BM, WGM, WGN, 16><<<g, 64 * WGM * WGN, 0, st>>>(p);
+}
+
+// pixel-tile width (TH*TW = 64) with the least padding waste for an Ho x Wo map
+static int halo_tile_width(int Ho, int Wo) {
+  int best = 8; long bw = -1;
+  for (int tw : {8, 16, 4}) {
+    const int th = 64 / tw;
+    const long w = (long)ceil_div(Ho, th) * ceil_div(Wo, tw);
+    if (bw < 0 || w < bw) { bw = w; best = tw; }
+  }
+  return best;
+}
+
 extern "C" {
 
-int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, float* wT, int* ktab, frtm_stream_t stream) {
+int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout, float* wT, int* ktab,
+                           frtm_stream_t stream) {
   FRTM_CHECK_ARG(w_oihw && wT && Cout > 0 && Cin > 0 && ksize > 0, "frtm_conv_pack_weights: bad argument");
+  if (layout == FRTM_WLAYOUT_HALO3X3) {
+    FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the halo layout is for 3x3 kernels");
+    const size_t total = (size_t)ceil_div(Cin, HCI) * HK * ((Cout + 31) / 32 * 32);
+    k_pack_weights_halo<<<(int)min((total + 255) / 256, (size_t)2048), 256, 0, (hipStream_t)stream>>>(w_oihw, Cout, Cin, wT);
+    FRTM_LAUNCH_CHECK();
+    return FRTM_OK;
+  }
+  FRTM_CHECK_ARG(layout == FRTM_WLAYOUT_GEMM, "frtm_conv_pack_weights: unknown layout %d", layout);
   const size_t total = (size_t)((Cin * ksize * ksize + 31) / 32 * 32) * ((Cout + 31) / 32 * 32);
   k_pack_weights<<<(int)min((total + 255) / 256, (size_t)2048), 256, 0, (hipStream_t)stream>>>(w_oihw, Cout, Cin, ksize, wT, ktab);
   FRTM_LAUNCH_CHECK();
@@ -288,16 +475,38 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   FRTM_CHECK_ARG(in_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull, "frtm_conv2d: tensor too large for 32-bit buffer offsets");
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
-  FRTM_CHECK_ARG(is1x1 || ktab, "frtm_conv2d: ktab required for ksize > 1");
+  FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");
   const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);
   if (is1x1) p.ktab = nullptr;
+  const bool halo = d->w_layout == FRTM_WLAYOUT_HALO3X3;
+  int halo_tw = 8;
+  if (halo) {
+    FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0, "frtm_conv2d: halo layout needs 3x3, stride 1, pad 1");
+    p.nchunks = ceil_div(d->Cin, HCI);
+    p.w_bytes = (unsigned)((size_t)p.nchunks * HK * p.Mp * 4);
+    halo_tw = halo_tile_width(p.Ho, p.Wo);
+  }
   int tile = d->tile, splitk = d->splitk;
-  frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
+  if (halo) {
+    const int ptiles = d->B * ceil_div(p.Ho, 64 / halo_tw) * ceil_div(p.Wo, halo_tw);
+    if (tile == 0) tile = FRTM_TILE_32x64;          // measured best for the halo kernel on every trunk shape
+    frtm_conv_plan(p.M, ptiles * 64, p.nchunks * 2, 0, &tile, &splitk);
+  } else {
+    frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
+  }
   splitk = max(1, min(splitk, p.nchunks));
   p.chunks_per_split = ceil_div(p.nchunks, splitk);
   p.splitk = ceil_div(p.nchunks, p.chunks_per_split);
   FRTM_CHECK_ARG(p.splitk == 1 || workspace, "frtm_conv2d: split-K needs a workspace");
   hipStream_t st = (hipStream_t)stream;
+  if (halo) {
+    switch (tile) {
+      case FRTM_TILE_128x64: launch_halo<128, 2, 2>(p, halo_tw, st); break;
+      case FRTM_TILE_64x64: launch_halo<64, 2, 2>(p, halo_tw, st); break;
+      case FRTM_TILE_32x64: launch_halo<32, 1, 4>(p, halo_tw, st); break;
+      default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
+    }
+  } else
   switch (tile) {
     case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(p, vec1x1, st); break;
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(p, vec1x1, st); break;

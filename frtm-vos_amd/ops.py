@@ -26,18 +26,21 @@ def padded_cols(M):
     return (M + 31) // 32 * 32
 
 
-def pack_weights(w_oihw):
-    """(Cout,Cin,k,k) -> wT [Cin*k*k, Cout] (+ ktab for k > 1).  See frtm_conv_pack_weights."""
+def pack_weights(w_oihw, halo=None):
+    """(Cout,Cin,k,k) -> packed GEMM weights (+ ktab for k > 1).  3x3 kernels default to the halo layout
+    (only valid for stride 1 / pad 1 convs: pass halo=False for strided 3x3).  Returns (wT, ktab, layout)."""
     w = w_oihw.detach().float().contiguous()
     Cout, Cin, k, _ = w.shape
-    wT = torch.empty(padded_rows(Cin * k * k), padded_cols(Cout), device=w.device)
-    ktab = torch.empty(Cin * k * k * 3, device=w.device, dtype=torch.int32) if k > 1 else None
-    H.call('frtm_conv_pack_weights', H.ptr(w), Cout, Cin, k, H.ptr(wT), H.ptr(ktab))
-    return wT, ktab
+    layout = 1 if (halo if halo is not None else k == 3) else 0
+    rows = max(padded_rows(Cin * k * k), (Cin + 7) // 8 * 72)
+    wT = torch.zeros(rows, padded_cols(Cout), device=w.device)
+    ktab = torch.empty(Cin * k * k * 3, device=w.device, dtype=torch.int32) if (k > 1 and layout == 0) else None
+    H.call('frtm_conv_pack_weights', H.ptr(w), Cout, Cin, k, layout, H.ptr(wT), H.ptr(ktab))
+    return wT, ktab, layout
 
 
 def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=None, residual=None, relu=False,
-           out=None, out_transposed=False, splitk=0, tile=0, shape=None, w_pitch=0):
+           out=None, out_transposed=False, splitk=0, tile=0, shape=None, w_pitch=0, w_layout=0):
     """fp32 MFMA implicit-GEMM convolution.  x: (B,Cin,H,W) dense (or any dense buffer when ``shape``
     = (B,Cin,H,W) is given explicitly); wT: packed weights from pack_weights(), or a plain [K, w_pitch]
     matrix when w_pitch > 0.  Returns (B,Cout,Ho,Wo) (or (B,Ho*Wo,Cout)
@@ -47,7 +50,7 @@ def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=N
     Wo = (Win + 2 * pad - ksize) // stride + 1
     if out is None:
         out = torch.empty((B, Ho * Wo, Cout) if out_transposed else (B, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
-    d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile), int(w_pitch))
+    d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile), int(w_layout), int(w_pitch))
     ws = workspace(x.device, 32 * Cout * B * Ho * Wo) if splitk != 1 else None
     H.call('frtm_conv2d', ctypes.byref(d), H.ptr(x), H.ptr(wT), H.ptr(ktab), H.ptr(scale), H.ptr(shift),
            H.ptr(residual), H.ptr(out), H.ptr(ws))

@@ -134,15 +134,22 @@ typedef struct {
   int relu, out_transposed;
   int splitk;              /* 0 = auto */
   int tile;                /* 0 = auto, else FRTM_TILE_* */
+  int w_layout;            /* FRTM_WLAYOUT_GEMM (0) or FRTM_WLAYOUT_HALO3X3 (3x3, stride 1, pad 1 only) */
   int w_pitch;             /* 0: wT is the padded [Kp][Mp] image of frtm_conv_pack_weights;
                               >0: wT is a plain [K][w_pitch] matrix (w_pitch >= Cout, multiple of 4, 16-byte aligned) */
 } frtm_conv_desc;
 #define FRTM_CONV_MAX_SPLITK 32
-#define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) ((((Cin) * (k) * (k) + 31) / 32 * 32) * (((Cout) + 31) / 32 * 32))
+/* Packed weight layouts.  GEMM: rows k = (ci,kh,kw), zero padded to [Kp][Mp].  HALO3X3: rows ordered
+ * [ci/8][tap][ci%8] (72 rows per 8 input channels) for the halo-tile 3x3 kernel, which stages the raw
+ * (TH+2)x(TW+2) input patch once per 8 channels instead of the 9x redundant im2col image. */
+#define FRTM_WLAYOUT_GEMM 0
+#define FRTM_WLAYOUT_HALO3X3 1
+#define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) \
+  (((((Cin) * (k) * (k) + 31) / 32 * 32) > (((Cin) + 7) / 8 * 72) ? (((Cin) * (k) * (k) + 31) / 32 * 32) : (((Cin) + 7) / 8 * 72)) * (((Cout) + 31) / 32 * 32))
 #define FRTM_TILE_64x64 1
 #define FRTM_TILE_32x64 2
 #define FRTM_TILE_128x64 3
-int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize,
+int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,
                 const float* scale, const float* shift, const float* residual, float* out,

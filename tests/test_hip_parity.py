@@ -131,6 +131,9 @@ CONV_CASES = [
     (1, 256, 30, 54, 512, 1, 2, 0),
     (5, 40, 6, 9, 96, 1, 1, 0),
     (1, 100, 9, 11, 33, 3, 1, 1),
+    (1, 65, 30, 54, 65, 3, 1, 1),        # refiner-style odd channel counts, halo layout with a channel tail
+    (2, 16, 15, 27, 40, 3, 1, 1),        # 16x4 pixel tiles
+    (1, 8, 40, 100, 32, 3, 1, 1),
 ]
 
 
@@ -145,14 +148,14 @@ def test_conv2d(ops, case, tile, splitk):
     shift = torch.randn(Cout, generator=g)
     ref = F.conv2d(x, w, stride=s, padding=p)
     res = torch.randn(ref.shape, generator=g)
-    wT, ktab = ops.pack_weights(w.to(DEV))
-    out = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, tile=tile, splitk=splitk)
+    wT, ktab, lay = ops.pack_weights(w.to(DEV), halo=(k == 3 and s == 1 and p == 1))
+    out = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, tile=tile, splitk=splitk, w_layout=lay)
     assert rel(out, ref) < 2e-5
     out2 = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, scale=scale.to(DEV), shift=shift.to(DEV),
-                      residual=res.to(DEV), relu=True, tile=tile, splitk=splitk)
+                      residual=res.to(DEV), relu=True, tile=tile, splitk=splitk, w_layout=lay)
     ref2 = F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
     assert rel(out2, ref2) < 2e-5
-    out3 = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, out_transposed=True, tile=tile, splitk=splitk)
+    out3 = ops.conv2d(x.to(DEV), wT, Cout, k, s, p, ktab=ktab, out_transposed=True, tile=tile, splitk=splitk, w_layout=lay)
     assert rel(out3, ref.flatten(2).transpose(1, 2)) < 2e-5
 
 

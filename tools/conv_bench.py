@@ -52,13 +52,13 @@ def main():
     for (cin, cout, k, s, h, w, cnt) in RN101_480P:
         x = torch.randn(args.batch, cin, h, w, device=dev)
         wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
-        wT, ktab = ops.pack_weights(wt)
+        wT, ktab, lay = ops.pack_weights(wt, halo=(k == 3 and s == 1))
         sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
         pad = k // 2
         ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
         fl = 2.0 * cout * args.batch * ho * wo * cin * k * k
         out = torch.empty(args.batch, cout, ho, wo, device=dev)
-        t = timeit(lambda: ops.conv2d(x, wT, cout, k, s, pad, ktab=ktab, scale=sc, shift=sh, relu=True, out=out))
+        t = timeit(lambda: ops.conv2d(x, wT, cout, k, s, pad, ktab=ktab, scale=sc, shift=sh, relu=True, out=out, w_layout=lay))
         line = '%4d->%4d k%d s%d %3dx%3d x%2d  auto %7.1f us %6.1f TF' % (cin, cout, k, s, h, w, cnt, t, fl / t / 1e6)
         total_us += t * cnt
         total_fl += fl * cnt
@@ -69,7 +69,7 @@ def main():
                     if sk > max(1, (cin * k * k) // 64):
                         continue
                     tt = timeit(lambda: ops.conv2d(x, wT, cout, k, s, pad, ktab=ktab, scale=sc, shift=sh, relu=True, out=out,
-                                                   tile=tile, splitk=sk), iters=10)
+                                                   tile=tile, splitk=sk, w_layout=lay), iters=10)
                     if tt < best[0]:
                         best = (tt, (tile, sk))
             line += '   best %7.1f us %6.1f TF  tile=%d splitk=%d' % (best[0], fl / best[0] / 1e6, best[1][0], best[1][1])
