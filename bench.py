@@ -187,6 +187,13 @@ def main():
     flops_total = tracker.feature_extractor.flops
     n_launch = tracker.feature_extractor.launches
     achieved = flops_total / (bb_ms * 1e-3) / 1e12 if bb_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # written by tools/pmc_summary.py from the rocprofv3 --pmc passes
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf))['conv_family']['bytes_per_launch']
+        except Exception:
+            traffic = None
     out = {
         'metric': 'segmented frames/sec/GPU (480p, ResNet101, full CG iters)',
         'value': world * n / T, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -199,7 +206,7 @@ def main():
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm (fp32 MFMA implicit-GEMM conv, whole ResNet trunk)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
-                     'traffic': None,
+                     'traffic': traffic,
                      'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch},
                      'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},

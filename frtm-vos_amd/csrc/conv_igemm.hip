@@ -27,10 +27,22 @@ struct ConvParams {
   unsigned in_bytes, w_bytes;
 };
 
-constexpr int BK = 32;
+constexpr int BK = 32;                 // K granularity of the packed weights / split-K bookkeeping
 constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any buffer: raw buffer loads return 0 there
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware block order.  Workgroup b runs on XCD b % 8 and each XCD has a private 4 MB L2, so the hardware order
+// scatters neighbouring tiles over all eight L2s and every XCD ends up fetching the whole activation matrix.  The remap
+// gives each XCD one contiguous range of logical tile ids (bijective for any nb), and inside it the M tiles vary fastest:
+// all workgroups that share an activation (N) tile run back to back on ONE XCD and hit its L2; the weights are the
+// small operand and are re-read per XCD.  Placement only affects speed, never results.
+__device__ __forceinline__ void tile_order(int id, int nb, int mt, int& m_tile, int& n_tile) {
+  const int xcd = id & 7, q = nb >> 3, r = nb & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  m_tile = logical % mt;
+  n_tile = logical / mt;
+}
 
 __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
@@ -50,8 +62,9 @@ __device__ __forceinline__ void store_out(const ConvParams& p, int m, int img, i
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
-template <int BM, int BN, int WGM, int WGN, int MODE>
+template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams p) {
+  constexpr int BK = BKT;                                // chunk depth of this instantiation (32 or 64)
   constexpr int NT = 64 * WGM * WGN;
   constexpr int LDA = BM + 16, LDB = BN + 16;          // LD % 32 == 16: the two k rows a 32-lane group reads never share a bank
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
@@ -64,9 +77,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kc0 = blockIdx.z * p.chunks_per_split;
-  const int kc1 = min(p.nchunks, kc0 + p.chunks_per_split);
+  int m_tile, n_tile;
+  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, n_tile);
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  // p.nchunks / p.chunks_per_split count 32-deep chunks; a 64-deep instantiation walks them in pairs
+  const int kc0 = blockIdx.z * p.chunks_per_split / (BK / 32);
+  const int kc1 = min((p.nchunks + BK / 32 - 1) / (BK / 32), (int)((blockIdx.z + 1) * p.chunks_per_split / (BK / 32)));
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
@@ -221,11 +237,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-  int bt = blockIdx.x;
+  int m_tile, bt;
+  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, bt);
   const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
   const int ty = bt / tiles_x, tx = bt - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int m0 = blockIdx.y * BM;
+  const int m0 = m_tile * BM;
   const int kc0 = blockIdx.z * p.chunks_per_split;
   const int kc1 = min(p.nchunks, kc0 + p.chunks_per_split);
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
@@ -381,11 +398,11 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int BKT = 32>
 static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
-  dim3 g(ceil_div(p.Ntot, BN), ceil_div(p.M, BM), p.splitk);
-  if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else k_conv_igemm<BM, BN, WGM, WGN, 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
+  if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else k_conv_igemm<BM, BN, WGM, WGN, 0, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
 // Chooses tile and split-K.  Measured on MI355X (tools/conv_bench.py --sweep, profiles/r01_conv_sweep.txt):
@@ -397,7 +414,8 @@ static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
 void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* splitk) {
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(Ntot, bn); };
   if (*tile == 0) *tile = vec1x1 ? FRTM_TILE_32x64 : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
-  const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x64) ? blocks(64, 64) : blocks(32, 64);
+  const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
+               : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W || *tile == FRTM_TILE_64x64_K64) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
     int s = 1;
     const int target = vec1x1 ? 512 : 832;
@@ -411,7 +429,7 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
 template <int BM, int WGM, int WGN>
 static void launch_halo(const ConvParams& p, int tw, hipStream_t st) {
   const int th = 64 / tw;
-  dim3 g(p.B * ceil_div(p.Ho, th) * ceil_div(p.Wo, tw), ceil_div(p.M, BM), p.splitk);
+  dim3 g(p.B * ceil_div(p.Ho, th) * ceil_div(p.Wo, tw) * ceil_div(p.M, BM), 1, p.splitk);
   if (tw == 4) k_conv3x3_halo<BM, WGM, WGN, 4><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else if (tw == 8) k_conv3x3_halo<BM, WGM, WGN, 8><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv3x3_halo<BM, WGM, WGN, 16><<<g, 64 * WGM * WGN, 0, st>>>(p);
@@ -496,6 +514,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   }
   splitk = max(1, min(splitk, p.nchunks));
   p.chunks_per_split = ceil_div(p.nchunks, splitk);
+  if (!halo && (tile == FRTM_TILE_32x64_K64 || tile == FRTM_TILE_64x64_K64)) p.chunks_per_split = (p.chunks_per_split + 1) / 2 * 2;
   p.splitk = ceil_div(p.nchunks, p.chunks_per_split);
   FRTM_CHECK_ARG(p.splitk == 1 || workspace, "frtm_conv2d: split-K needs a workspace");
   hipStream_t st = (hipStream_t)stream;
@@ -511,6 +530,10 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(p, vec1x1, st); break;
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(p, vec1x1, st); break;
     case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(p, vec1x1, st); break;
+    case FRTM_TILE_64x64_8W: launch_tile<64, 64, 2, 4>(p, vec1x1, st); break;
+    case FRTM_TILE_32x64_K64: launch_tile<32, 64, 1, 4, 64>(p, vec1x1, st); break;
+    case FRTM_TILE_64x64_K64: launch_tile<64, 64, 2, 2, 64>(p, vec1x1, st); break;
+    case FRTM_TILE_64x128_8W: launch_tile<64, 128, 2, 4>(p, vec1x1, st); break;
     default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
   }
   FRTM_LAUNCH_CHECK();

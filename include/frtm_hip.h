@@ -149,6 +149,10 @@ typedef struct {
 #define FRTM_TILE_64x64 1
 #define FRTM_TILE_32x64 2
 #define FRTM_TILE_128x64 3
+#define FRTM_TILE_64x64_8W 4     /* 64x64 tile, 8 waves (two per SIMD) */
+#define FRTM_TILE_32x64_K64 5    /* 64-deep chunks (half the barriers) */
+#define FRTM_TILE_64x64_K64 6
+#define FRTM_TILE_64x128_8W 7
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

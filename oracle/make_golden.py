@@ -14,6 +14,7 @@ Fixture list:
   g4_init            joint problem: b, A(p1,p2), weights after run((5,10,10,10)) / (5,10,10,10,10)
   g5_disc            Discriminator.init -> (apply, update) x 17
   g6_tracker         Tracker.initialize / track mask flow for 1, 2, 5 objects (+ late object)
+  g8_fullsize        480p / c=96 / N=24 update problem: b, A p, filter after run((10,)) (inputs regenerated from a seed)
   g7_segnet          SegNetwork.forward (refiner) on name-seeded weights, with and without BatchNorm
 """
 import os
@@ -360,9 +361,50 @@ def g7():
     npz('g7_segnet', **res)
 
 
+# ----------------------------------------------------------------------------------- G8
+def full_size_inputs(seed, N, c, h, w, H, W):
+    """Seed-regenerable full-size inputs (nothing but the seed is stored)."""
+    g = gen(seed)
+    X = torch.relu(torch.randn(N, c, h, w, generator=g))
+    Y = torch.zeros(N, 1, H, W)
+    for i in range(N):
+        y0 = int(torch.randint(0, H // 2, (1,), generator=g)); x0 = int(torch.randint(0, W // 2, (1,), generator=g))
+        hh = int(torch.randint(20, H // 2, (1,), generator=g)); ww = int(torch.randint(20, W // 2, (1,), generator=g))
+        Y[i, 0, y0:y0 + hh, x0:x0 + ww] = 0.55 + 0.45 * torch.rand(hh, ww, generator=g)
+    sw = torch.rand(N, generator=g) + 0.1
+    sw = sw / sw.sum()
+    w2 = (torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / (9 * c) ** 0.5
+    p = torch.randn(1, c, 3, 3, generator=g)
+    return X, Y, sw, w2, p
+
+
+def g8():
+    """BASELINE-size update problem (480x854 labels, 30x54 grid, c=96, N=24 active samples): b, A p and the filter after
+    run((10,)) from the reference; only checksums / sampled entries are stored, inputs are regenerated from the seed."""
+    N, c, h, w, H, W = 24, 96, 30, 54, 480, 854
+    X, Y, sw, w2, p = full_size_inputs(8, N, c, h, w, H, W)
+    d = new_disc(256, c, (1,), (10,), gen(80), dff_rate=750, memory_size=N)
+    with torch.no_grad():
+        d.filter.weight.copy_(w2)
+    pw = d.compute_pixel_weights((Y > 0.5).float())
+    mem = R.Memory(N, X.shape[-3:], Y.shape[-3:], 'cpu', 0.1)
+    mem.samples[:], mem.labels[:], mem.pixel_weights[:], mem.weights[:] = X, Y, pw, sw
+    mem.current_size = N
+    prob = R.DiscriminatorLoss(x=mem.samples, y=mem.labels, filter_regs=d.filter_reg[1:], precond=d.precond[1:],
+                               sample_weights=mem.weights, net=d.filter, pixel_weighting=mem.pixel_weights)
+    opt = R.GaussNewtonCG(prob, R.TensorList([d.filter.weight]), fletcher_reeves=False, standard_alpha=True,
+                          direction_forget_factor=d.direction_forget_factor)
+    b = gn_setup(opt)[0].clone()
+    Ap = opt.A(R.TensorList([p]))[0].detach().clone()
+    opt.x.detach_()
+    opt.clear_temp()
+    opt.run((10,))
+    npz('g8_fullsize', dims=np.array([N, c, h, w, H, W]), seed=8, b=b, Ap=Ap, filt=d.filter.weight.detach().clone())
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
     for name in which:
         globals()[name]()

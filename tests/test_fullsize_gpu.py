@@ -1,0 +1,204 @@
+"""BASELINE-size checks on the GPU: the reference's own full-size numbers (fixture G8), size-independent properties of
+the solver operator, and an end-to-end tracker run against a CPU assembly of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+PW = dict(method='hinge', tf=0.1)
+DEV = 'cuda:0'
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _fullsize_inputs(seed, N, c, h, w, H, W):
+    """Must mirror oracle/make_golden.py:full_size_inputs (same draw order)."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.relu(torch.randn(N, c, h, w, generator=g))
+    Y = torch.zeros(N, 1, H, W)
+    for i in range(N):
+        y0 = int(torch.randint(0, H // 2, (1,), generator=g)); x0 = int(torch.randint(0, W // 2, (1,), generator=g))
+        hh = int(torch.randint(20, H // 2, (1,), generator=g)); ww = int(torch.randint(20, W // 2, (1,), generator=g))
+        Y[i, 0, y0:y0 + hh, x0:x0 + ww] = 0.55 + 0.45 * torch.rand(hh, ww, generator=g)
+    sw = torch.rand(N, generator=g) + 0.1
+    sw = sw / sw.sum()
+    w2 = (torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / (9 * c) ** 0.5
+    p = torch.randn(1, c, 3, 3, generator=g)
+    return X, Y, sw, w2, p
+
+
+def _problem(N, c, h, w, H, W, X, Y, sw, w2, dff=0.9 ** 750):
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    mem = Memory(N, (c, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+    mem.samples[:] = X.to(DEV)
+    mem._build_normals(Y.to(DEV), None, N, None, 0)           # hinge weights of (Y > 0.5) computed in-kernel
+    mem.weights[:] = sw.to(DEV)
+    mem.current_size = N
+    wv = torch.nn.Parameter(w2.clone().to(DEV), requires_grad=False)
+    prob = DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv)
+    opt = GaussNewtonCG(prob, TensorList([wv]), fletcher_reeves=False, standard_alpha=True, direction_forget_factor=dff)
+    prob.initialize()
+    opt._alloc()
+    return mem, prob, opt, wv
+
+
+def test_g8_fullsize_against_reference(golden):
+    g = golden('g8_fullsize')
+    N, c, h, w, H, W = [int(v) for v in g['dims']]
+    X, Y, sw, w2, p = _fullsize_inputs(int(g['seed']), N, c, h, w, H, W)
+    mem, prob, opt, wv = _problem(N, c, h, w, H, W, X, Y, sw, w2)
+    prob.linearize(opt.x, opt._buf[0])
+    assert rel(opt.b[0], T(g['b'])) < 1e-4
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    assert rel(opt.A(TensorList([p.to(DEV)]))[0], T(g['Ap'])) < 1e-4
+    opt.run((10,))
+    assert rel(wv, T(g['filt'])) < 2e-2          # ten CG steps on the full-size system (noise floor: see DESIGN.md section 2)
+
+
+def test_operator_properties_fullsize():
+    """Size-independent properties at 480p / c=96 / N=80: A symmetric positive definite with A >= lam^2 I,
+    the quadratic decreases monotonically over CG iterations, B is a symmetric stencil with sum_d B = U^T 1 for W=1."""
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    N, c, h, w, H, W = 80, 96, 30, 54, 480, 854
+    X, Y, sw, w2, _ = _fullsize_inputs(21, N, c, h, w, H, W)
+    mem, prob, opt, wv = _problem(N, c, h, w, H, W, X, Y, sw, w2)
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(c * 9, generator=g).to(DEV)
+    q = torch.randn(c * 9, generator=g).to(DEV)
+    Ap, Aq = torch.empty_like(p), torch.empty_like(q)
+    prob.apply_A(p, Ap)
+    prob.apply_A(q, Aq)
+    assert abs(float(Ap @ q) - float(p @ Aq)) / abs(float(Ap @ q)) < 1e-4                # symmetry
+    assert float(p @ Ap) >= 0.999e-4 * float(p @ p)                                      # A - lam^2 I is PSD
+    # stencil symmetry: B[n,(di,dj),(i,j)] == B[n,(-di,-dj),(i+di,j+dj)]
+    B = mem.normal_B.cpu()
+    for a, (di, dj) in enumerate([(i, j) for i in (-1, 0, 1) for j in (-1, 0, 1)]):
+        opp = (1 - di) * 3 + (1 - dj)
+        lhs = B[:, a, max(0, -di):h - max(0, di), max(0, -dj):w - max(0, dj)]
+        rhs = B[:, opp, max(0, di):h - max(0, -di), max(0, dj):w - max(0, -dj)]
+        assert (lhs - rhs).abs().max() < 1e-4
+    # monotone decrease of phi(x) = 1/2 x^T A x - b^T x over the CG iterations of one run
+    prob.linearize(opt.x, opt._buf[0])
+    b = opt._buf[0].clone()
+    phis = []
+    for n_it in (1, 2, 4, 7, 10):
+        opt.reset_state()
+        opt.run_CG(n_it)
+        x = opt._buf[5].clone()
+        Ax = torch.empty_like(x)
+        prob.apply_A(x, Ax)
+        phis.append(0.5 * float(x @ Ax) - float(b @ x))
+    assert all(b_ <= a_ + 1e-6 * abs(a_) for a_, b_ in zip(phis, phis[1:])), phis
+    # W = 1, labels = 1:  sum_d B[., d] == c == U^T 1, and the sample weights stay normalised through updates
+    from frtm_vos_amd.model.memory import Memory
+    m1 = Memory(6, (2, h, w), (1, H, W), DEV, 0.1, pixel_weighting=None)
+    m1.initialize(torch.zeros(5, 2, h, w, device=DEV), torch.ones(5, 1, H, W, device=DEV))
+    assert (m1.normal_B[:5].sum(1) - m1.normal_c[:5]).abs().max() < 2e-3
+    assert abs(float(m1.normal_c[0].sum()) - H * W) / (H * W) < 1e-5
+    for t in range(12):
+        m1.update(torch.zeros(1, 2, h, w, device=DEV), torch.ones(1, 1, H, W, device=DEV))
+        assert abs(float(m1.weights.sum()) - 1) < 1e-5 and float(m1.weights.min()) > 0
+
+
+class _CpuTracker:
+    """CPU assembly of the oracle pieces in the control flow of model/tracker.py (test infrastructure)."""
+
+    def __init__(self, name, P, refiner, w1w2, iters):
+        self.name, self.P, self.refiner, self.w1w2, self.iters = name, P, refiner, w1w2, iters
+        self.targets, self.frame = {}, 0
+
+    def initialize(self, image, labels, ids, K=3):
+        n = len(self.targets) + len(ids) + 1
+        self.masks = torch.zeros(n, *image.shape[-2:])
+        for oid in ids:
+            mask = (labels == oid).to(torch.uint8)
+            w1, w2 = self.w1w2[oid]
+            d = O.DiscriminatorRef(w1, w2, init_iters=self.iters[0], update_iters=self.iters[1], CG_forgetting_rate=750,
+                                   memory_size=8, pixel_weighting=PW)
+            ft = O.resnet_forward(self.name, self.P, image.unsqueeze(0).repeat(K, 1, 1, 1), ['layer4'])['layer4']
+            d.init(ft, mask.unsqueeze(0).repeat(K, 1, 1, 1))
+            self.targets[oid] = dict(d=d, index=len(self.targets) + 1, start=self.frame, mask=mask)
+            self.masks[self.targets[oid]['index']] = mask[0].float()
+
+    def track(self, image):
+        taps = O.resnet_forward(self.name, self.P, image)
+        act = [t for t in self.targets.values() if t['start'] < self.frame]
+        if act:
+            s = torch.cat([t['d'].apply(taps['layer4']) for t in act])
+            y = torch.sigmoid(self.refiner(s, taps, image.shape[-2:]))
+            for k, t in enumerate(act):
+                self.masks[t['index']] = y[k, 0]
+        self.masks = O.merge_masks(self.masks)
+        for t in act:
+            t['d'].update(self.masks[t['index']][None, None])
+
+
+def test_tracker_end_to_end_vs_cpu_oracle():
+    """ResNet-18, 96x128 frames, 2 objects, 7 frames (one CG update): HIP Tracker vs the CPU assembly, same weights and
+    the same (stub) augmentation.  Masks are compared at the algorithm's noise floor."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.manual_seed(0)
+    params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18')
+    params.disc_params.update(memory_size=8, train_skipping=4, init_iters=(3, 5), update_iters=(5,))
+    trk = params.get_model().eval()
+
+    class Aug:
+        def augment_first_frame(self, im, lb):
+            return im.unsqueeze(0).repeat(3, 1, 1, 1), lb.unsqueeze(0).repeat(3, 1, 1, 1)
+    trk.augment = Aug().augment_first_frame
+    seq = SyntheticSequence('e2e', 7, (96, 128), 2, seed=4)
+    P = {k: v.detach().cpu() for k, v in trk.feature_extractor.resnet.state_dict().items()}
+    ref_net = type(trk.refiner)(1, 64, trk.refiner.ft_channels, True).eval()
+    ref_net.load_state_dict({k: v.cpu() for k, v in trk.refiner.state_dict().items()})
+    w1w2 = {}
+    cpu = _CpuTracker('resnet18', P, ref_net, w1w2, ((3, 5), (5,)))
+    cpu.targets = {}
+    torch.set_grad_enabled(False)
+    trk.current_frame, trk.targets = 0, dict()
+    agree, diffs = [], []
+    for oid in (1, 2):                       # shared initial target-model weights, injected into both sides
+        g = torch.Generator().manual_seed(100 + oid)
+        w1w2[oid] = ((torch.rand(96, 256, 1, 1, generator=g) * 2 - 1) / 16, (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / 29.4)
+    import frtm_vos_amd.model.tracker as TR
+    orig = TR.Discriminator
+
+    class Injected(orig):
+        count = 0
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            Injected.count += 1
+            w1, w2 = w1w2[Injected.count]
+            self.project.weight.data.copy_(w1)
+            self.filter.weight.data.copy_(w2)
+    TR.Discriminator = Injected
+    try:
+        trk.current_frame, trk.targets = 0, dict()
+        for i, (image, labels, new) in enumerate(seq):
+            old = set(trk.targets.keys())
+            if new:
+                trk.initialize(image.to(DEV), labels.to(DEV), new)
+                cpu.initialize(image, labels, new)
+            if old:
+                trk.track(image.to(DEV))
+                cpu.track(image)
+                hm, cm = trk.current_masks.cpu(), cpu.masks
+                diffs.append(float((hm - cm).abs().mean()))
+                agree.append(float((hm.argmax(0) == cm.argmax(0)).float().mean()))
+            trk.current_frame += 1
+            cpu.frame += 1
+    finally:
+        TR.Discriminator = orig
+    assert len(diffs) == 6
+    assert max(diffs) < 2e-2, diffs           # mean |mask difference|
+    assert min(agree) > 0.97, agree           # per-pixel label agreement

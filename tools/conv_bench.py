@@ -64,7 +64,7 @@ def main():
         total_fl += fl * cnt
         if args.sweep:
             best = (1e9, None)
-            for tile in (1, 2, 3):
+            for tile in ((1, 2, 3) if lay else (1, 2, 3, 4, 5, 6, 7)):
                 for sk in (1, 2, 4, 8, 16):
                     if sk > max(1, (cin * k * k) // 64):
                         continue
