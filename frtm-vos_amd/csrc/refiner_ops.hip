@@ -1,0 +1,174 @@
+// Fused glue kernels of the refinement network (reference model/seg_network.py:7-189).  The convolutions run on the MFMA
+// conv kernels (conv_igemm.hip) with bias / BatchNorm / ReLU / residual folded into their epilogues; what is left between
+// them -- bilinear / bicubic resampling, the score-channel injection of TSE, the channel-attention combine -- is HBM-bound
+// element-wise work, one kernel each instead of 5-10 framework launches.
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+// ATen bilinear source taps, align_corners=False (same as target_model.hip)
+__device__ __forceinline__ void bl_taps(int d, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+  float src = __fsub_rn(__fmul_rn(scale, (float)d + 0.5f), 0.5f);
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ p, int h, int w, int H, int W, int y, int x) {
+  if (h == H && w == W) return p[y * w + x];
+  int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+  bl_taps(y, (float)h / (float)H, h, y0, y1, ly0, ly1);
+  bl_taps(x, (float)w / (float)W, w, x0, x1, lx0, lx1);
+  return ly0 * (lx0 * p[y0 * w + x0] + lx1 * p[y0 * w + x1]) + ly1 * (lx0 * p[y1 * w + x0] + lx1 * p[y1 * w + x1]);
+}
+
+// out[n,c] = bilinear(in[n,c], (h,w) -> (H,W)); planes = n*c
+__global__ __launch_bounds__(256) void k_bilinear_resize(const float* __restrict__ in, int h, int w, float* __restrict__ out, int H, int W,
+                                                          size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t pl = i / ((size_t)W * H);
+    out[i] = bilinear_at(in + pl * (size_t)h * w, h, w, H, W, y, x);
+  }
+}
+
+// TSE score injection (seg_network.py:16-21: h = cat(reduce(ft), interpolate(score)); transform[0]; relu).  The 3x3 conv over
+// the 64 feature channels does not depend on the object and arrives pre-computed in `base` (C,H,W); this kernel adds the
+// contribution of the one score channel, the bias and the ReLU:
+//   out[n,c,y,x] = relu(base[c,y,x] + bias[c] + sum_{dy,dx} ws[c,dy,dx] * S_n(y+dy-1, x+dx-1)),  S_n = bilinear(scores[n]) (0 outside)
+#define INJ_T 16
+__global__ __launch_bounds__(256) void k_tse_inject(const float* __restrict__ base, const float* __restrict__ bias, const float* __restrict__ ws,
+                                                     const float* __restrict__ scores, int C, int h, int w, int H, int W,
+                                                     float* __restrict__ out) {
+  __shared__ float S[INJ_T + 2][INJ_T + 2];
+  const int n = blockIdx.z;
+  const int ty0 = blockIdx.y * INJ_T, tx0 = blockIdx.x * INJ_T;
+  const float* sc = scores + (size_t)n * h * w;
+  for (int i = threadIdx.x; i < (INJ_T + 2) * (INJ_T + 2); i += 256) {
+    const int r = i / (INJ_T + 2), c = i % (INJ_T + 2);
+    const int y = ty0 - 1 + r, x = tx0 - 1 + c;
+    S[r][c] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? bilinear_at(sc, h, w, H, W, y, x) : 0.f;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / INJ_T, lx = threadIdx.x % INJ_T;
+  const int y = ty0 + ly, x = tx0 + lx;
+  if (y >= H || x >= W) return;
+  float s[9];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) s[dy * 3 + dx] = S[ly + dy][lx + dx];
+  const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
+  for (int c = 0; c < C; ++c) {
+    float v = base[c * HW + pix] + bias[c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v += ws[c * 9 + k] * s[k];
+    out[((size_t)n * C + c) * HW + pix] = fmaxf(v, 0.f);
+  }
+}
+
+// CAB combine (seg_network.py:38-41): out = shallower * sigmoid(gate[n,c]) + bilinear(deeper[n,c], (hd,wd) -> (H,W)).
+// deeper_nstride = 0 broadcasts one deeper tensor over the objects (the pooled vector of the deepest level).
+__global__ __launch_bounds__(256) void k_cab_combine(const float* __restrict__ shallow, const float* __restrict__ gate, const float* __restrict__ deeper,
+                                                      int C, int hd, int wd, size_t deeper_nstride, int H, int W, float* __restrict__ out,
+                                                      size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const size_t pl = i / ((size_t)W * H);                  // n*C + c
+    const int c = (int)(pl % C); const size_t n = pl / C;
+    const float g = 1.f / (1.f + __expf(-gate[pl]));
+    const float d = bilinear_at(deeper + n * deeper_nstride + (size_t)c * hd * wd, hd, wd, H, W, y, x);
+    out[i] = shallow[i] * g + d;
+  }
+}
+
+// 2x polyphase bicubic up-sampling, replicate border (seg_network.py:75-126).  Taps: kernel(d) with a = -0.75 at
+// d = -0.25 (even phase) and d = -0.75 (odd phase); out = crop1(interleave(conv4x4(pad2(in)))).
+__device__ __forceinline__ float cubic(float x) {
+  x = fabsf(x);
+  const float a = -0.75f;
+  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return ((a * x - 5.f * a) * x + 8.f * a) * x - 4.f * a;
+  return 0.f;
+}
+__global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, int h, int w, float* __restrict__ out, size_t total) {
+  const int H = 2 * h, W = 2 * w;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int X = (int)(i % W), Y = (int)((i / W) % H);
+    const size_t pl = i / ((size_t)W * H);
+    const float* p = in + pl * (size_t)h * w;
+    const int ty = Y + 1, tx = X + 1;
+    const int iy = ty >> 1, ix = tx >> 1;
+    const float dy = (ty & 1) ? -0.75f : -0.25f, dx = (tx & 1) ? -0.75f : -0.25f;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = min(max(iy + u - 2, 0), h - 1);
+      const float wy = cubic(dy + (float)(u - 1));
+      float row = 0.f;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int c = min(max(ix + v - 2, 0), w - 1);
+        row += cubic(dx + (float)(v - 1)) * p[(size_t)r * w + c];
+      }
+      acc += wy * row;
+    }
+    out[i] = acc;
+  }
+}
+
+// out[pl] = mean over the plane (adaptive_avg_pool2d to 1x1); one block per plane, fixed summation order
+__global__ __launch_bounds__(256) void k_plane_mean(const float* __restrict__ in, int HW, float* __restrict__ out) {
+  __shared__ float red[16];
+  const float* p = in + (size_t)blockIdx.x * HW;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = acc / (float)HW;
+}
+
+extern "C" {
+
+int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "frtm_bilinear_resize: bad argument");
+  const size_t total = (size_t)planes * H * W;
+  k_bilinear_resize<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, H, W, total);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int C, int h, int w, int H, int W,
+                    float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(base && bias && ws && scores && out && n > 0 && C > 0, "frtm_tse_inject: bad argument");
+  dim3 g(ceil_div(W, INJ_T), ceil_div(H, INJ_T), n);
+  k_tse_inject<<<g, 256, 0, (hipStream_t)stream>>>(base, bias, ws, scores, C, h, w, H, W, out);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd, int deeper_shared, int H,
+                     int W, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(shallow && gate && deeper && out && n > 0 && C > 0, "frtm_cab_combine: bad argument");
+  const size_t total = (size_t)n * C * H * W;
+  k_cab_combine<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(
+      shallow, gate, deeper, C, hd, wd, deeper_shared ? 0 : (size_t)C * hd * wd, H, W, out, total);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0, "frtm_pyrup2x: bad argument");
+  const size_t total = (size_t)planes * 4 * h * w;
+  k_pyrup2x<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, total);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(in && out && planes > 0 && HW > 0, "frtm_plane_mean: bad argument");
+  k_plane_mean<<<planes, 256, 0, (hipStream_t)stream>>>(in, HW, out);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+}  // extern "C"

@@ -1,7 +1,12 @@
 """Refinement network (API + state-dict layout of the reference's model/seg_network.py:149-189).
 
-SURVEY.md 8f row "next-1": this round it runs on stock PyTorch-ROCm ops (MIOpen), not on
-hand-written kernels.  Two structural changes that leave the results unchanged:
+SURVEY.md 8f row "next-1".  Two execution paths with identical results:
+ * ``forward`` on CUDA tensors in inference mode -> ``_forward_hip``: every convolution runs on the fp32 MFMA conv
+   kernels of libfrtm_hip.so (halo-tile 3x3 / vectorised 1x1) with bias, eval-BatchNorm, ReLU and the residual add folded
+   into the conv epilogue; the glue (score injection, channel-attention combine, polyphase bicubic, bilinear) is one fused
+   HIP kernel each (csrc/refiner_ops.hip).  ~80 launches per frame instead of ~370 framework launches.
+ * plain PyTorch ops (the definition of the network; used on CPU, for training, and as the test oracle of the HIP path).
+Structural changes relative to the reference that leave the results unchanged:
  * all objects of a frame go through ONE batched pass (scores (n_obj,1,h,w), shared backbone taps);
    the reference loops over objects in Python (model/tracker.py:200-204);
  * ``TSE.reduce`` (two 1x1 convs on the backbone tap) does not depend on the object and is computed
@@ -12,6 +17,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import _hip as H
+from .. import ops
 from ..lib.utils import conv, relu, interpolate
 
 
@@ -138,6 +145,11 @@ class SegNetwork(nn.Module):
     def forward(self, scores, features, image_size, shared=None):
         """scores: (n,1,h,w) coarse scores of n objects on the same frame; features: backbone taps (batch 1);
         returns (n,1,H,W) logits (reference seg_network.py:176-189 evaluates one object per call)."""
+        if scores.is_cuda and not self.training and not torch.is_grad_enabled() and shared is None:
+            return self._forward_hip(scores, features, image_size)
+        return self.forward_torch(scores, features, image_size, shared)
+
+    def forward_torch(self, scores, features, image_size, shared=None):
         red, pool = shared if shared is not None else self.precompute(features)
         x = None
         for i, L in enumerate(self.ft_channels):
@@ -147,3 +159,112 @@ class SegNetwork(nn.Module):
             h = self.CAB[L](pool if x is None else x, h)
             x = self.RRB2[L](h)
         return self.project(x, image_size)
+
+    # ------------------------------------------------------------------------------------------------------
+    # HIP path
+    # ------------------------------------------------------------------------------------------------------
+    def _packed(self):
+        """Weights in the layouts of the HIP kernels; rebuilt when any parameter changes (version counters)."""
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, '_pack_key', None) == key:
+            return self._pack
+        dev = next(self.parameters()).device
+
+        def cv(m, scale=None, shift=None, relu_=False):
+            wT, ktab, lay = ops.pack_weights(m.weight.data)
+            cout = m.weight.shape[0]
+            if shift is None:
+                shift = m.bias.data.float() if m.bias is not None else None
+            if shift is not None and scale is None:
+                scale = torch.ones(cout, device=dev)
+            return dict(wT=wT, ktab=ktab, lay=lay, cout=cout, k=m.weight.shape[2], scale=None if scale is None else scale.contiguous(),
+                        shift=None if shift is None else shift.contiguous(), relu=relu_)
+
+        def rrb(m):
+            first = m.bblock[0]
+            if isinstance(m.bblock[1], nn.BatchNorm2d):
+                bn = m.bblock[1]
+                sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).data.float()
+                sh = (sc * (first.bias.data - bn.running_mean) + bn.bias.data).float()
+            else:
+                sc, sh = None, None
+            return dict(c1=cv(m.conv1x1), b0=cv(first, sc, sh, True), b1=cv(m.bblock[-1], relu_=True))
+
+        P = {}
+        for L in self.ft_channels:
+            t = self.TSE[L]
+            w0 = t.transform[0].weight.data
+            oc = w0.shape[1] - 1
+            base = nn.Conv2d(oc, w0.shape[0], 3, padding=1, bias=False).to(dev)
+            base.weight.data.copy_(w0[:, :oc])
+            c = self.CAB[L].convreluconv
+            P[L] = dict(r0=cv(t.reduce[0], relu_=True), r2=cv(t.reduce[2]), base=cv(base), ws=w0[:, oc].reshape(w0.shape[0], 9).contiguous(),
+                        b0=t.transform[0].bias.data.float().contiguous(), t2=cv(t.transform[2], relu_=True), t4=cv(t.transform[4], relu_=True),
+                        rrb1=rrb(self.RRB1[L]), rrb2=rrb(self.RRB2[L]),
+                        cab_w1=c[0].weight.data.flatten(1).t().contiguous(), cab_b1=c[0].bias.data, cab_w2=c[2].weight.data.flatten(1).t().contiguous(),
+                        cab_b2=c[2].bias.data)
+        pj = self.project
+        P['project'] = dict(c1=cv(pj.conv1, relu_=True), w2=pj.conv2.weight.data.contiguous(), b2=pj.conv2.bias.data)
+        self._pack, self._pack_key = P, key
+        return P
+
+    @staticmethod
+    def _conv(x, c, residual=None):
+        return ops.conv2d(x, c['wT'], c['cout'], c['k'], 1, c['k'] // 2, ktab=c['ktab'], scale=c['scale'], shift=c['shift'],
+                          residual=residual, relu=c['relu'], w_layout=c['lay'])
+
+    def _rrb_hip(self, x, r):
+        a = self._conv(x, r['c1'])
+        return self._conv(self._conv(a, r['b0']), r['b1'], residual=a)
+
+    @staticmethod
+    def _mean(x):
+        n, c, hh, ww = x.shape
+        out = torch.empty(n, c, device=x.device)
+        H.call('frtm_plane_mean', H.ptr(x), n * c, hh * ww, H.ptr(out))
+        return out
+
+    def _forward_hip(self, scores, features, image_size):
+        P = self._packed()
+        scores = scores.float().contiguous()
+        n, _, sh, sw = scores.shape
+        dev = scores.device
+        x, pool0 = None, None
+        for L in self.ft_channels:
+            p = P[L]
+            ft = features[L].contiguous()
+            Hh, Ww = ft.shape[-2:]
+            h = self._conv(self._conv(ft, p['r0']), p['r2'])                       # TSE.reduce, shared by all objects
+            if x is None:
+                pool0 = self._mean(h)                                            # (1,oc): deeper input of the deepest CAB
+            base = self._conv(h, p['base'])                                      # object-independent part of transform[0]
+            C0 = p['base']['cout']
+            t0 = torch.empty(n, C0, Hh, Ww, device=dev)
+            H.call('frtm_tse_inject', H.ptr(base), H.ptr(p['b0']), H.ptr(p['ws']), H.ptr(scores), n, C0, sh, sw, Hh, Ww, H.ptr(t0))
+            t = self._conv(self._conv(t0, p['t2']), p['t4'])
+            r = self._rrb_hip(t, p['rrb1'])
+            sp = self._mean(r)
+            dp = pool0.expand(n, -1) if x is None else self._mean(x)
+            gate = torch.addmm(p['cab_b2'], torch.relu(torch.addmm(p['cab_b1'], torch.cat((sp, dp), 1), p['cab_w1'])), p['cab_w2']).contiguous()
+            out = torch.empty_like(r)
+            if x is None:
+                H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(pool0), n, r.shape[1], 1, 1, 1, Hh, Ww, H.ptr(out))
+            else:
+                H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(x), n, r.shape[1], x.shape[2], x.shape[3], 0, Hh, Ww, H.ptr(out))
+            x = self._rrb_hip(out, p['rrb2'])
+        pj = P['project']
+        c, hh, ww = x.shape[1:]
+        u1 = torch.empty(n, c, 2 * hh, 2 * ww, device=dev)
+        H.call('frtm_pyrup2x', H.ptr(x), n * c, hh, ww, H.ptr(u1))
+        y = self._conv(u1, pj['c1'])
+        c2 = y.shape[1]
+        u2 = torch.empty(n, c2, 4 * hh, 4 * ww, device=dev)
+        H.call('frtm_pyrup2x', H.ptr(y), n * c2, 2 * hh, 2 * ww, H.ptr(u2))
+        Ho, Wo = int(image_size[-2]), int(image_size[-1])
+        if (Ho, Wo) != (4 * hh, 4 * ww):
+            z = torch.empty(n, c2, Ho, Wo, device=dev)
+            H.call('frtm_bilinear_resize', H.ptr(u2), n * c2, 4 * hh, 4 * ww, H.ptr(z), Ho, Wo)
+        else:
+            z = u2
+        out = pj['b2'].view(1, 1, 1, 1).expand(n, 1, Ho, Wo).contiguous()
+        return ops.filter_scores(z, pj['w2'], out=out, accumulate=True)

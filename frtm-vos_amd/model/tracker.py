@@ -131,6 +131,7 @@ class Tracker(nn.Module):
         return outputs, N / T
 
     # ------------------------------------------------------------------------------------
+    @torch.no_grad()
     def initialize(self, image, labels, new_objects):
         """Reference tracker.py:165-191."""
         self.current_masks = torch.zeros((len(self.targets) + len(new_objects) + 1, *image.shape[-2:]), device=self.device)
@@ -147,6 +148,7 @@ class Tracker(nn.Module):
             self.current_masks[target.index] = mask
         return self.current_masks
 
+    @torch.no_grad()
     def track(self, image):
         """Reference tracker.py:193-227."""
         im_size = image.shape[-2:]

@@ -189,6 +189,24 @@ int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream);
 int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, frtm_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Refinement network glue (model/seg_network.py:7-189); its convolutions go through frtm_conv2d / frtm_filter_scores.
+ * ------------------------------------------------------------------------------------------ */
+/* F.interpolate(..., 'bilinear', align_corners=False) of `planes` maps (lib/utils.py:33-35) */
+int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream);
+/* TSE: out[n,c] = relu(base[c] + bias[c] + conv3x3(bilinear(scores[n]) , ws[c]))  (seg_network.py:16-21 with the
+ * object-independent 64-channel part of transform[0] pre-computed in base (C,H,W)); scores (n,1,h,w), out (n,C,H,W). */
+int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int C,
+                    int h, int w, int H, int W, float* out, frtm_stream_t stream);
+/* CAB: out = shallow * sigmoid(gate[n,c]) + bilinear(deeper[n,c] (hd,wd) -> (H,W))  (seg_network.py:38-41);
+ * deeper_shared != 0: one deeper tensor (1,C,hd,wd) for all n. */
+int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd,
+                     int deeper_shared, int H, int W, float* out, frtm_stream_t stream);
+/* PyrUpBicubic2d: 2x polyphase bicubic with replicate border (seg_network.py:75-126); out (planes,2h,2w) */
+int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream);
+/* adaptive_avg_pool2d(x, 1): out[plane] = mean(in[plane]) */
+int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Affine warp of C planes (replaces lib/_npp/nppig.cpp:48-104 = NVIDIA NPP nppiWarpAffine_*, called from
  * lib/image.py:53).  fwd6_host: HOST float[6], the forward 2x3 transform (source -> destination), as
  * cv2.warpAffine / NPP take it.  mode: 0 nearest, 1 bilinear, 2 bicubic.  Outside pixels become 0.

@@ -392,3 +392,46 @@ def test_warp_affine():
     assert (out[:, 2:, 3:] - src[:, :-2, :-3]).abs().max() < 1e-5 and float(out[:, :2].abs().max()) == 0
     flip = np.array([[-1, 0, 49], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
     assert (warp_affine(src, flip, (40, 50), 'nearest') - src.flip(-1)).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ refiner
+@pytest.mark.parametrize('bn,n,size', [(True, 2, (96, 140)), (False, 3, (61, 83)), (True, 1, (480, 854))])
+def test_segnetwork_hip_vs_torch(bn, n, size):
+    """HIP refiner path (MFMA convs + fused glue kernels) vs the plain PyTorch definition (pinned to the reference by G7)."""
+    from collections import OrderedDict
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    full = size == (480, 854)
+    chans = OrderedDict(layer5=2048, layer4=1024, layer3=512, layer2=256) if full else OrderedDict(layer5=40, layer4=24, layer3=16, layer2=8)
+    torch.manual_seed(3)
+    net = SegNetwork(1, 64 if full else 8, chans, bn).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    g = gen(17)
+    H0, W0 = size
+    dims = [((H0 + 2 ** k - 1) // 2 ** k, (W0 + 2 ** k - 1) // 2 ** k) for k in (5, 4, 3, 2)]
+    feats = {L: torch.relu(torch.randn(1, c, *d, generator=g)) for (L, c), d in zip(chans.items(), dims)}
+    scores = torch.randn(n, 1, *dims[1], generator=g)
+    net = net.to(DEV)
+    fd = {k: v.to(DEV) for k, v in feats.items()}
+    with torch.no_grad():
+        hip = net(scores.to(DEV), fd, size)
+        ref = net.forward_torch(scores.to(DEV), fd, size)
+    assert hip.shape == (n, 1) + size
+    assert rel(hip, ref) < 2e-4, rel(hip, ref)
+
+
+def test_refiner_glue_kernels():
+    from frtm_vos_amd import _hip as H
+    from frtm_vos_amd.model.seg_network import PyrUpBicubic2d
+    g = gen(23)
+    x = torch.randn(6, 13, 17, generator=g).to(DEV)
+    out = torch.empty(6, 40, 50, device=DEV)
+    H.call('frtm_bilinear_resize', H.ptr(x), 6, 13, 17, H.ptr(out), 40, 50)
+    assert rel(out, F.interpolate(x[None], (40, 50), mode='bilinear', align_corners=False)[0]) < 1e-5
+    up = torch.empty(6, 26, 34, device=DEV)
+    H.call('frtm_pyrup2x', H.ptr(x), 6, 13, 17, H.ptr(up))
+    assert rel(up, PyrUpBicubic2d(6).to(DEV)(x[None])[0]) < 1e-5
+    m = torch.empty(6, device=DEV)
+    H.call('frtm_plane_mean', H.ptr(x), 6, 13 * 17, H.ptr(m))
+    assert rel(m, x.mean((1, 2))) < 1e-5
