@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--backbone', default='resnet101')
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--size', default='480x854')
+    ap.add_argument('--trunk-batch', type=int, default=4, help='frames per trunk pass (1 = frame by frame like the reference)')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=8)
@@ -74,12 +75,12 @@ def run_sequence(tracker, seq):
     tracker.current_frame = 0
     tracker.targets = dict()
     n = 0
-    for image, labels, new_objects in seq:
+    for image, labels, new_objects, feats in tracker.frames_with_features(seq):
         old = set(tracker.targets.keys())
         if len(new_objects) > 0:
             tracker.initialize(image, labels, new_objects)
         if len(old) > 0:
-            tracker.track(image)
+            tracker.track(image, feats)
         tracker.current_frame += 1
         n += 1
     return n
@@ -149,7 +150,7 @@ def main():
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     from frtm_vos_amd import ops
 
-    params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone)
+    params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone, feature_batch=args.trunk_batch)
     tracker = params.get_model()
     tracker.eval()
     torch.set_grad_enabled(False)
@@ -200,9 +201,9 @@ def main():
         'ms_per_step': 1e3 * T / n, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
-                               '%s iterations, memory 80, c=96, random-init weights' %
+                               '%s iterations, memory 80, c=96, random-init weights, trunk fed %d frames per pass' %
                                (args.backbone, size[0], size[1], args.objects, args.steps,
-                                'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)'),
+                                'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.trunk_batch),
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm (fp32 MFMA implicit-GEMM conv, whole ResNet trunk)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,

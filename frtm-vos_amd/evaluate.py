@@ -20,8 +20,9 @@ class AttrDict(dict):
 
 class Parameters:
 
-    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None):
+    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=4):
         self.device = device
+        self.feature_batch = feature_batch
         self.weights = weights
         self.num_aug = 5
         self.train_skipping = 8
@@ -70,7 +71,7 @@ class Parameters:
         if self.weights is None:
             torch.manual_seed(1)                                   # seeded default init
             refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
-        mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device)
+        mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device, feature_batch=self.feature_batch)
         if self.weights is not None:
             mdl.load_state_dict(self.weights)
         mdl.to(self.device)

@@ -7,6 +7,10 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
  * all objects go through the refiner in one batched pass; the object-independent half of it is
    computed once per frame;
  * merge (clamp / background / soft-max / arg-max, tracker.py:214-221) is one HIP kernel, in place;
+ * the trunk does not depend on tracking state, so ``run_sequence`` feeds it ``feature_batch`` pre-loaded frames at a time
+   (default 4): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs (47 TFLOP/s, many split-K convs), at batch 4 they
+   do (~70 TFLOP/s, no split-K).  Per-frame results are unchanged up to fp32 summation order; ``track(image)`` without
+   pre-computed features still works frame by frame;
  * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for
    all objects by one kernel and ONE small device->host copy per frame instead of a sync per object.
 """
@@ -43,8 +47,9 @@ class TargetObject:
 
 class Tracker(nn.Module):
 
-    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device):
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=4):
         super().__init__()
+        self.feature_batch = feature_batch
         self.augmenter = augmenter
         self.augment = augmenter.augment_first_frame
         self.disc_params = disc_params
@@ -108,14 +113,14 @@ class Tracker(nn.Module):
             self.targets = dict()
         outputs = []
         t0 = time()
-        for i, (image, labels, new_objects) in enumerate(sequence):
+        for i, (image, labels, new_objects, feats) in enumerate(self.frames_with_features(sequence)):
             old_objects = set(self.targets.keys())
             image = image.to(self.device)
             if len(new_objects) > 0:
                 labels = labels.to(self.device)
                 self.initialize(image, labels, new_objects)
             if len(old_objects) > 0:
-                self.track(image)
+                self.track(image, feats)
                 masks = self.current_masks
                 if len(sequence.obj_ids) == 1:
                     labels = object_ids[(masks[1:2] > 0.5).long()]
@@ -129,6 +134,23 @@ class Tracker(nn.Module):
         torch.cuda.synchronize()
         T = time() - t0
         return outputs, N / T
+
+    def frames_with_features(self, sequence):
+        """Yields (image, labels, new_objects, taps) and runs the trunk on up to ``feature_batch`` consecutive frames at once.
+        Frame 0 of a sequence is never tracked (only initialised), so its taps are not computed."""
+        frames = list(sequence)
+        fb = max(1, int(self.feature_batch))
+        cache = {}
+        for i, (image, labels, new_objects) in enumerate(frames):
+            feats = None
+            if i > 0:
+                if i not in cache:
+                    idx = list(range(i, min(i + fb, len(frames))))
+                    batch = torch.stack([frames[j][0].to(self.device) for j in idx])
+                    taps = self.feature_extractor(batch)
+                    cache = {j: {L: t[k:k + 1] for L, t in taps.items()} for k, j in enumerate(idx)}
+                feats = cache.pop(i)
+            yield image, labels, new_objects, feats
 
     # ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -149,10 +171,11 @@ class Tracker(nn.Module):
         return self.current_masks
 
     @torch.no_grad()
-    def track(self, image):
-        """Reference tracker.py:193-227."""
+    def track(self, image, features=None):
+        """Reference tracker.py:193-227.  ``features``: optional pre-computed taps of this frame (frames_with_features)."""
         im_size = image.shape[-2:]
-        features = self.feature_extractor(image)
+        if features is None:
+            features = self.feature_extractor(image)
         active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
         if active:
             scores = torch.cat([t.classify(features[t.disc_layer]) for t in active])       # (n,1,h,w)
