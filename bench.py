@@ -237,6 +237,12 @@ class _TimedExtractor:
     def __getattr__(self, name):
         return getattr(self.ext, name)
 
+    def __setattr__(self, name, value):
+        if name in ('ext', 'timer', 'flops', 'launches', '_call'):
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.ext, name, value)
+
 
 if __name__ == '__main__':
     main()

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int cell = blockIdx.x * 4 + wid;
   if (cell >= h * w) return;
+  if (slot_dev && slot_dev[0] < 0) return;   // guarded insert
   const int ci = cell / w, cj = cell % w;
   float wf = 1.f, wb = 1.f;
   if (!pw) hinge_weights(sum_parts(partial, n), (float)(H * W), tf, wf, wb);
@@ -143,8 +144,11 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
 // Memory.update_sample_weights on the device (model/memory.py:65-92).  One wave.
 // state[0] = previous replace index (-1 = None), state[1] = index chosen by this call.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state) {
+__global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state,
+                                                          const int* __restrict__ count, int min_count) {
   const int lane = threadIdx.x;
+  // device-side form of the early-out of Discriminator.update (discriminator.py:214): no weight update, no slot
+  if (count && count[0] < min_count) { if (lane == 0) state[1] = -1; return; }
   int r_ind;
   if (num_zero || lr == 1.f) {
     for (int i = lane; i < cap; i += 64) sw[i] = (i == 0) ? 1.f : 0.f;
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw,
 template <typename T>
 __global__ __launch_bounds__(256) void k_memory_insert(const T* __restrict__ src, T* __restrict__ dst_base, int len,
                                                         const int* __restrict__ slot) {
+  if (slot[0] < 0) return;                 // guarded insert (see k_memory_next_slot)
   T* dst = dst_base + (size_t)slot[0] * len;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
 }
@@ -563,9 +568,10 @@ int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int
   return FRTM_OK;
 }
 
-int frtm_memory_next_slot(float* sw, int cap, float lr, int num_samp_is_zero, int* state, frtm_stream_t stream) {
+int frtm_memory_next_slot(float* sw, int cap, float lr, int num_samp_is_zero, int* state, const int* count_dev, int min_count,
+                          frtm_stream_t stream) {
   FRTM_CHECK_ARG(sw && state && cap > 0, "frtm_memory_next_slot: bad argument");
-  k_memory_next_slot<<<1, 64, 0, (hipStream_t)stream>>>(sw, cap, lr, num_samp_is_zero, state);
+  k_memory_next_slot<<<1, 64, 0, (hipStream_t)stream>>>(sw, cap, lr, num_samp_is_zero, state, count_dev, min_count);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

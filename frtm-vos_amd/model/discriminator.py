@@ -248,17 +248,24 @@ class Discriminator(nn.Module):
         self.current_sample = cft
         return ops.filter_scores(cft, self.filter.weight.data)
 
-    def update(self, train_y, num_positive=None):
+    def update(self, train_y, num_positive=None, count_dev=None):
         """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
-        ``num_positive``: optional pre-computed count of pixels > 0.5 (the tracker batches that
-        test for all objects into one device->host copy); otherwise it is evaluated here."""
+        The reference's early-out "fewer than 10 pixels above 0.5" (:214) needs the pixel count:
+          * ``num_positive`` (host int) -> decided here, like the reference;
+          * ``count_dev`` (device int32, from ops.count_above) on a frame WITHOUT a filter re-solve -> the insert is guarded
+            on the device and the host never waits (the tracker uses this on 7 of 8 frames);
+          * neither -> the count is computed and read back here (one sync)."""
         if not self.update_filters or self.current_sample is None:
             return
+        solve = self.frame_num % self.train_skipping == 0
+        if num_positive is None and count_dev is not None and not solve:
+            self.memory.update(self.current_sample, train_y, count_dev=count_dev)
+            return
         if num_positive is None:
-            num_positive = int(ops.count_above(train_y.reshape(1, -1)).item())
+            num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
         if num_positive < 10:
             return
         self.memory.update(self.current_sample, train_y)     # soft mask as label, weights from (y > 0.5)  (:217-219)
-        if self.frame_num % self.train_skipping != 0:
+        if not solve:
             return
         self.update_optimizer.run(self.update_iters)

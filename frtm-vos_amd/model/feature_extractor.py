@@ -140,6 +140,8 @@ class ResnetFeatureExtractor:
         self.device = None
         self.last_flops = 0.0
         self.last_conv_launches = 0
+        self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
+        self._out_cache = {}
 
     def __del__(self):
         try:
@@ -201,7 +203,13 @@ class ResnetFeatureExtractor:
             if i > 0:
                 ch, cw = (ch + 1) // 2, (cw + 1) // 2
             dims[L] = (self._out_channels[L], ch, cw)
-        out = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
+        if self.reuse_outputs:
+            key = (B, Hh, Ww, tuple(want))
+            out = self._out_cache.get(key)
+            if out is None:
+                out = self._out_cache[key] = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
+        else:
+            out = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
         ptrs = [H.ptr(out.get(L)) for L in ('layer1', 'layer2', 'layer3', 'layer4', 'layer5')]
         H.call('frtm_backbone_forward', self._handle, H.ptr(x), B, Hh, Ww, H.ptr(self.norm_weight), H.ptr(self.norm_bias),
                *ptrs, stop)

@@ -107,10 +107,12 @@ class Memory:
         H.call('frtm_pixel_weights', H.ptr(ys), 0, n, lab.shape[-2], lab.shape[-1], self._tf(), H.ptr(out), H.ptr(self._scratch))
         return out
 
-    def update_sample_weights(self, previous_replace_ind=None):
-        """Reference memory.py:65-92, on the device.  Returns nothing: the chosen slot stays in ``self._slot``."""
+    def update_sample_weights(self, previous_replace_ind=None, count_dev=None, min_count=10):
+        """Reference memory.py:65-92, on the device.  Returns nothing: the chosen slot stays in ``self._slot``.
+        ``count_dev``: optional device int32 (pixels > 0.5); below ``min_count`` the whole update becomes a no-op on the
+        device (slot -1), which is how Discriminator.update's early-out runs without a host sync."""
         H.call('frtm_memory_next_slot', H.ptr(self.weights), self._capacity, float(self.learning_rates),
-               int(self.current_size == 0), H.ptr(self._slot))
+               int(self.current_size == 0), H.ptr(self._slot), None if count_dev is None else count_dev.data_ptr(), int(min_count))
         self._have_prev = True
 
     def insert_at(self, slot_dev_ptr, ft, labels, pixel_weights):
@@ -124,8 +126,9 @@ class Memory:
             pwt = pw if pw is not None else self._hires_pw(lab)
             H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self.pixel_weights), pwt.numel(), slot_dev_ptr)
 
-    def update(self, features, labels, pixel_weights=None):
-        """Reference memory.py:59-63."""
-        self.update_sample_weights()
+    def update(self, features, labels, pixel_weights=None, count_dev=None):
+        """Reference memory.py:59-63.  With ``count_dev`` the insert is guarded on the device; ``current_size`` is then an
+        upper bound (a skipped insert leaves a zero-weight slot, which contributes nothing to the solver)."""
+        self.update_sample_weights(count_dev=count_dev)
         self.insert_at(self._slot[1:].data_ptr(), features, labels, pixel_weights)
         self.current_size = min(self.current_size + 1, self._capacity)

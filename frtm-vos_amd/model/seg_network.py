@@ -135,6 +135,8 @@ class SegNetwork(nn.Module):
             self.CAB[L] = CAB(out_channels, L == 'layer5')
             self.RRB2[L] = RRB(out_channels, use_bn=use_bn)
         self.project = BackwardCompatibleUpsampler(out_channels)
+        self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
+        self._graphs = {}
 
     def precompute(self, features):
         """Object-independent part: reduce(ft) for every tap (+ its global pool for the deepest one)."""
@@ -146,6 +148,8 @@ class SegNetwork(nn.Module):
         """scores: (n,1,h,w) coarse scores of n objects on the same frame; features: backbone taps (batch 1);
         returns (n,1,H,W) logits (reference seg_network.py:176-189 evaluates one object per call)."""
         if scores.is_cuda and not self.training and not torch.is_grad_enabled() and shared is None:
+            if self.use_graphs:
+                return self._forward_graphed(scores, features, image_size)
             return self._forward_hip(scores, features, image_size)
         return self.forward_torch(scores, features, image_size, shared)
 
@@ -163,6 +167,30 @@ class SegNetwork(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     # HIP path
     # ------------------------------------------------------------------------------------------------------
+    def _forward_graphed(self, scores, features, image_size):
+        """The ~80 launches of _forward_hip are a static sequence for a given object count and set of tap tensors:
+        capture them once in a hipGraph and replay it per frame (one host call instead of ~80).  The graph is keyed by the
+        tap ADDRESSES (the trunk writes into persistent buffers, model/feature_extractor.py reuse_outputs), the score
+        shape and the weight versions; scores go through a static input buffer."""
+        P = self._packed()
+        key = (tuple(features[L].data_ptr() for L in self.ft_channels), tuple(scores.shape), tuple(image_size[-2:]), self._pack_key)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if len(self._graphs) > 64:
+                self._graphs.clear()
+            static_scores = scores.clone()
+            self._forward_hip(static_scores, features, image_size)          # warm-up outside capture (allocator, workspaces)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward_hip(static_scores, features, image_size)
+            entry = self._graphs[key] = (g, static_scores, out, [features[L] for L in self.ft_channels])
+        g, static_scores, out, _keepalive = entry
+        static_scores.copy_(scores)
+        g.replay()
+        return out
+
+
     def _packed(self):
         """Weights in the layouts of the HIP kernels; rebuilt when any parameter changes (version counters)."""
         key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))

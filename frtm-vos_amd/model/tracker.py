@@ -11,8 +11,9 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
    (default 4): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs (47 TFLOP/s, many split-K convs), at batch 4 they
    do (~70 TFLOP/s, no split-K).  Per-frame results are unchanged up to fp32 summation order; ``track(image)`` without
    pre-computed features still works frame by frame;
- * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for
-   all objects by one kernel and ONE small device->host copy per frame instead of a sync per object.
+ * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for all objects by
+   one kernel; on frames without a filter re-solve it guards the memory insert on the device (no host sync at all), on
+   re-solve frames (every 8th) ONE small device->host copy serves all objects.
 """
 from time import time
 
@@ -50,6 +51,7 @@ class Tracker(nn.Module):
     def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=4):
         super().__init__()
         self.feature_batch = feature_batch
+        self.graph_refiner = True
         self.augmenter = augmenter
         self.augment = augmenter.augment_first_frame
         self.disc_params = disc_params
@@ -141,6 +143,11 @@ class Tracker(nn.Module):
         frames = list(sequence)
         fb = max(1, int(self.feature_batch))
         cache = {}
+        # persistent tap buffers -> stable addresses -> the refiner can replay a captured hipGraph per frame
+        if hasattr(self.feature_extractor, 'reuse_outputs'):
+            self.feature_extractor.reuse_outputs = True
+            if hasattr(self.refiner, 'use_graphs'):
+                self.refiner.use_graphs = self.graph_refiner
         for i, (image, labels, new_objects) in enumerate(frames):
             feats = None
             if i > 0:
@@ -189,7 +196,13 @@ class Tracker(nn.Module):
         ops.merge_masks_(self.current_masks)                                                 # :214-221
         if active and self.disc_params.update_filters:
             idx = torch.tensor([t.index for t in active], device=self.device)
-            counts = ops.count_above(self.current_masks[idx]).tolist()                       # one D2H per frame
-            for t, n_pos in zip(active, counts):
-                t.discriminator.update(self.current_masks[t.index].unsqueeze(0).unsqueeze(0), num_positive=n_pos)
+            counts = ops.count_above(self.current_masks[idx])                                # device int32 (n)
+            solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
+            host = counts.tolist() if solve else None                                        # one D2H only on re-solve frames
+            for k, t in enumerate(active):
+                y = self.current_masks[t.index].unsqueeze(0).unsqueeze(0)
+                if host is not None:
+                    t.discriminator.update(y, num_positive=host[k])
+                else:
+                    t.discriminator.update(y, count_dev=counts[k:k + 1])
         return self.current_masks

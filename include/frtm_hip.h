@@ -57,9 +57,12 @@ int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int
 
 /* Memory.update_sample_weights (model/memory.py:65-92) on the device, no host sync.
  * sw: (cap) sample weights, updated in place.  state: device int32[2] = {previous_replace_ind or -1,
- * replace index written by this call}.  num_samp_is_zero / lr as in the reference. */
+ * replace index written by this call}.  num_samp_is_zero / lr as in the reference.
+ * count_dev != NULL: device int32 holding the number of mask pixels > 0.5; if it is < min_count the call leaves the
+ * weights untouched and writes slot -1, which makes frtm_memory_insert / frtm_normal_build no-ops: the early-out of
+ * Discriminator.update (discriminator.py:214) without a host sync. */
 int frtm_memory_next_slot(float* sw, int cap, float lr, int num_samp_is_zero, int* state,
-                          frtm_stream_t stream);
+                          const int* count_dev, int min_count, frtm_stream_t stream);
 
 /* Copy one sample (len floats) into slot state[1] of a (cap,len) buffer (Memory.insert_at, memory.py:50-57). */
 int frtm_memory_insert(const float* src, float* dst_base, int len, const int* slot_dev, frtm_stream_t stream);

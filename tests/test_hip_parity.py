@@ -435,3 +435,21 @@ def test_refiner_glue_kernels():
     m = torch.empty(6, device=DEV)
     H.call('frtm_plane_mean', H.ptr(x), 6, 13 * 17, H.ptr(m))
     assert rel(m, x.mean((1, 2))) < 1e-5
+
+
+def test_device_guarded_memory_update():
+    """count < 10 on the device == the reference's early-out: weights, slots and samples untouched; count >= 10 == update."""
+    from frtm_vos_amd.model.memory import Memory
+    m = Memory(8, (2, 3, 4), (1, 16, 16), DEV, 0.1, pixel_weighting=PW)
+    m.initialize(torch.ones(5, 2, 3, 4, device=DEV), torch.zeros(5, 1, 16, 16, device=DEV))
+    w0, s0, B0 = m.weights.clone(), m.samples.clone(), m.normal_B.clone()
+    few = torch.tensor([3], dtype=torch.int32, device=DEV)
+    lab = torch.zeros(1, 1, 16, 16, device=DEV)
+    lab[..., 2:9, 3:12] = 0.9          # (an all-ones mask gives wb = 0/0 = NaN, exactly like discriminator.py:137)
+    m.update(torch.full((1, 2, 3, 4), 7.0, device=DEV), lab, count_dev=few)
+    assert torch.equal(m.weights, w0) and torch.equal(m.samples, s0) and torch.equal(m.normal_B, B0)
+    assert int(m._slot[1]) == -1 and int(m._slot[0]) == -1
+    many = torch.tensor([200], dtype=torch.int32, device=DEV)
+    m.update(torch.full((1, 2, 3, 4), 7.0, device=DEV), lab, count_dev=many)
+    assert int(m._slot[1]) == 5 and float(m.samples[5, 0, 0, 0]) == 7.0 and abs(float(m.weights.sum()) - 1) < 1e-6
+    assert float(m.normal_B[5].abs().sum()) > 0
