@@ -174,6 +174,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     n = run_sequence(tracker, seq)
+    t_host = time.time() - t0                 # host-side enqueue time (the GPU may still be working)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -211,6 +212,7 @@ def main():
                      'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch},
                      'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
+        'host_enqueue_ms_per_step': 1e3 * t_host / n,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, size, args.cpu_frames)

@@ -85,7 +85,13 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (also the capture stream during graph capture)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

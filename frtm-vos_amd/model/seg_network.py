@@ -137,6 +137,20 @@ class SegNetwork(nn.Module):
         self.project = BackwardCompatibleUpsampler(out_channels)
         self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
         self._graphs = {}
+        self._pack_key = None
+
+    def invalidate(self):
+        """Drop the packed HIP weights and captured graphs (call after editing parameters in place)."""
+        self._pack_key = None
+        self._graphs = {}
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate()
+        return super().load_state_dict(*a, **k)
 
     def precompute(self, features):
         """Object-independent part: reduce(ft) for every tap (+ its global pool for the deepest one)."""
@@ -193,9 +207,9 @@ class SegNetwork(nn.Module):
 
     def _packed(self):
         """Weights in the layouts of the HIP kernels; rebuilt when any parameter changes (version counters)."""
+        if getattr(self, '_pack_key', None) is not None:
+            return self._pack                 # invalidated by _apply (.to/.cuda), load_state_dict and invalidate()
         key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
-        if getattr(self, '_pack_key', None) == key:
-            return self._pack
         dev = next(self.parameters()).device
 
         def cv(m, scale=None, shift=None, relu_=False):

@@ -195,14 +195,13 @@ class Tracker(nn.Module):
                     self.current_masks[t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
         ops.merge_masks_(self.current_masks)                                                 # :214-221
         if active and self.disc_params.update_filters:
-            idx = torch.tensor([t.index for t in active], device=self.device)
-            counts = ops.count_above(self.current_masks[idx])                                # device int32 (n)
+            counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync
             solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
             host = counts.tolist() if solve else None                                        # one D2H only on re-solve frames
             for k, t in enumerate(active):
                 y = self.current_masks[t.index].unsqueeze(0).unsqueeze(0)
                 if host is not None:
-                    t.discriminator.update(y, num_positive=host[k])
+                    t.discriminator.update(y, num_positive=host[t.index])
                 else:
-                    t.discriminator.update(y, count_dev=counts[k:k + 1])
+                    t.discriminator.update(y, count_dev=counts[t.index:t.index + 1])
         return self.current_masks
