@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=8)
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) for real multi-GPU runs; gloo to exercise the path on one GPU')
+    ap.add_argument('--share-gpu', action='store_true', help='testing only: all ranks use cuda:0')
     return ap.parse_args()
 
 
@@ -136,14 +138,20 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if args.share_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         dist = None
         torch.cuda.set_device(0)
     dev = 'cuda:%d' % (local if world > 1 else 0)
+    red_dev = dev if args.dist_backend == 'nccl' else 'cpu'
     size = tuple(int(v) for v in args.size.split('x'))
 
     from frtm_vos_amd.evaluate import Parameters
@@ -180,7 +188,7 @@ def main():
         dist.barrier()
     T = time.time() - t0
     if dist is not None:
-        tt = torch.tensor([T], device=dev, dtype=torch.float64)
+        tt = torch.tensor([T], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         T = float(tt.item())
 

@@ -413,7 +413,11 @@ static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
 //  * stride-1 1x1 (dwordx4 staging): 32x64 tile (more workgroups), split-K only for the 15x27 stage.
 void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* splitk) {
   auto blocks = [&](int bm, int bn) { return ceil_div(M, bm) * ceil_div(Ntot, bn); };
-  if (*tile == 0) *tile = vec1x1 ? FRTM_TILE_32x64 : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
+  // stride-1 1x1: 32x64 tiles while the problem is small (more workgroups); once even 64x64 tiles give >= 2 per CU
+  // (batched trunk, refiner at 120x214) the 8-wave 64x64 tile wins (fewer LDS reads and barriers per MFMA).
+  if (*tile == 0)
+    *tile = vec1x1 ? ((M % 64 == 0 && blocks(64, 64) >= 512) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64)
+                   : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
   const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
                : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W || *tile == FRTM_TILE_64x64_K64) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
