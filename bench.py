@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--trunk-batch', type=int, default=4, help='frames per trunk pass (1 = frame by frame like the reference)')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=8)
+    ap.add_argument('--cpu-frames', type=int, default=24)
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) for real multi-GPU runs; gloo to exercise the path on one GPU')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: all ranks use cuda:0')
     return ap.parse_args()

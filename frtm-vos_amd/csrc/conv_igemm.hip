@@ -162,17 +162,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     const int cur = (kc - kc0) & 1;
     const bool more = (kc + 1) < kc1;
     if (more) gload(kc + 1);
+    // fragment reads are software pipelined: the LDS reads of k-step kk+1 are issued before the MFMAs of k-step kk,
+    // so the matrix pipe never waits a full LDS round trip (the compiler emits counted lgkmcnt waits for this form)
+    float af[2][FM], bf[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = As[cur][lk][wm * TM + i * 16 + li];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[0][j] = Bs[cur][lk][wn * TN + j * 16 + li];
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      float af[FM], bf[FN];
+      if (kk + 1 < BK / 4) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = As[cur][kk * 4 + lk][wm * TM + i * 16 + li];
+        for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = As[cur][(kk + 1) * 4 + lk][wm * TM + i * 16 + li];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = Bs[cur][kk * 4 + lk][wn * TN + j * 16 + li];
+        for (int j = 0; j < FN; ++j) bf[(kk + 1) & 1][j] = Bs[cur][(kk + 1) * 4 + lk][wn * TN + j * 16 + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) lstore(cur ^ 1);
     __syncthreads();
@@ -306,20 +316,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
     const int cur = (kc - kc0) & 1;
     const bool more = (kc + 1) < kc1;
     if (more) gload(kc + 1);
+    // 18 k-steps per chunk: step = tap * 2 + cg (4 channels each); fragment reads pipelined one step ahead
+    constexpr int NS = 9 * (HCI / 4);
+    float af[2][FM], bf[2][FN];
+    auto frag = [&](int st, float* a, float* b) {
+      const int tap = st / (HCI / 4), cg = st % (HCI / 4);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+      for (int i = 0; i < FM; ++i) a[i] = As[cur][tap * HCI + cg * 4 + lk][wm * TM + i * 16 + li];
 #pragma unroll
-      for (int cg = 0; cg < HCI / 4; ++cg) {
-        float af[FM], bf[FN];
+      for (int j = 0; j < FN; ++j) b[j] = Bs[cur][pb[j] + cg * 4 * PL + (tap / 3) * PW + (tap % 3)];
+    };
+    frag(0, af[0], bf[0]);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = As[cur][tap * HCI + cg * 4 + lk][wm * TM + i * 16 + li];
+    for (int st = 0; st < NS; ++st) {
+      if (st + 1 < NS) frag(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = Bs[cur][pb[j] + cg * 4 * PL + (tap / 3) * PW + (tap % 3)];
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st & 1][i], bf[st & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) lstore(cur ^ 1);
     __syncthreads();

@@ -82,38 +82,38 @@ __global__ __launch_bounds__(256) void k_cab_combine(const float* __restrict__ s
   }
 }
 
-// 2x polyphase bicubic up-sampling, replicate border (seg_network.py:75-126).  Taps: kernel(d) with a = -0.75 at
-// d = -0.25 (even phase) and d = -0.75 (odd phase); out = crop1(interleave(conv4x4(pad2(in)))).
-__device__ __forceinline__ float cubic(float x) {
-  x = fabsf(x);
-  const float a = -0.75f;
-  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
-  if (x < 2.f) return ((a * x - 5.f * a) * x + 8.f * a) * x - 4.f * a;
-  return 0.f;
-}
-__global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, int h, int w, float* __restrict__ out, size_t total) {
+// 2x polyphase bicubic up-sampling, replicate border (seg_network.py:75-126): out = crop1(interleave(conv4x4(pad2(in)))).
+// The taps are the a = -0.75 cubic kernel at d = -0.25 (even phase) / d = -0.75 (odd phase):
+//   even: cubic(1.25), cubic(.25), cubic(.75), cubic(1.75) = -27/256, 225/256, 67/256, -9/256 ; odd: the reverse.
+// One thread produces a 2x2 output quad from the 5x5 input patch both phases share (25 loads for 4 outputs).
+__global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, int h, int w, float* __restrict__ out, size_t quads) {
+  const float E[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};
   const int H = 2 * h, W = 2 * w;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int X = (int)(i % W), Y = (int)((i / W) % H);
-    const size_t pl = i / ((size_t)W * H);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) {
+    const int qx = (int)(i % w), qy = (int)((i / w) % h);
+    const size_t pl = i / ((size_t)w * h);
     const float* p = in + pl * (size_t)h * w;
-    const int ty = Y + 1, tx = X + 1;
-    const int iy = ty >> 1, ix = tx >> 1;
-    const float dy = (ty & 1) ? -0.75f : -0.25f, dx = (tx & 1) ? -0.75f : -0.25f;
-    float acc = 0.f;
+    // output rows 2qy (odd phase at input row qy) and 2qy+1 (even phase at input row qy+1): input rows qy-2 .. qy+2
+    float v[5][5];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = min(max(iy + u - 2, 0), h - 1);
-      const float wy = cubic(dy + (float)(u - 1));
-      float row = 0.f;
+    for (int r = 0; r < 5; ++r) {
+      const int rr = min(max(qy + r - 2, 0), h - 1);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int c = min(max(ix + v - 2, 0), w - 1);
-        row += cubic(dx + (float)(v - 1)) * p[(size_t)r * w + c];
-      }
-      acc += wy * row;
+      for (int c = 0; c < 5; ++c) v[r][c] = p[(size_t)rr * w + min(max(qx + c - 2, 0), w - 1)];
     }
-    out[i] = acc;
+    // horizontal pass: column phase odd (taps reversed) uses cols 0..3, even phase uses cols 1..4
+    float hx[5][2];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      hx[r][0] = E[3] * v[r][0] + E[2] * v[r][1] + E[1] * v[r][2] + E[0] * v[r][3];
+      hx[r][1] = E[0] * v[r][1] + E[1] * v[r][2] + E[2] * v[r][3] + E[3] * v[r][4];
+    }
+    float* o = out + pl * (size_t)H * W + (size_t)(2 * qy) * W + 2 * qx;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      o[c] = E[3] * hx[0][c] + E[2] * hx[1][c] + E[1] * hx[2][c] + E[0] * hx[3][c];
+      o[W + c] = E[0] * hx[1][c] + E[1] * hx[2][c] + E[2] * hx[3][c] + E[3] * hx[4][c];
+    }
   }
 }
 
@@ -158,8 +158,8 @@ int frtm_cab_combine(const float* shallow, const float* gate, const float* deepe
 
 int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream) {
   FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0, "frtm_pyrup2x: bad argument");
-  const size_t total = (size_t)planes * 4 * h * w;
-  k_pyrup2x<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, total);
+  const size_t quads = (size_t)planes * h * w;
+  k_pyrup2x<<<(int)min((quads + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, quads);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
