@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=24)
+    ap.add_argument('--memory', type=int, default=80, help='target-model memory slots (80 = evaluate.py:80)')
+    ap.add_argument('--late-object', type=int, default=None, help='frame at which the last object first appears')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) for real multi-GPU runs; gloo to exercise the path on one GPU')
     ap.add_argument('--share-gpu', action='store_true', help='testing only: all ranks use cuda:0')
     return ap.parse_args()
@@ -159,6 +161,7 @@ def main():
     from frtm_vos_amd import ops
 
     params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone, feature_batch=args.trunk_batch)
+    params.disc_params['memory_size'] = args.memory
     tracker = params.get_model()
     tracker.eval()
     torch.set_grad_enabled(False)
@@ -166,9 +169,14 @@ def main():
     timer = StageTimer()
     ext = tracker.feature_extractor
     tracker.feature_extractor = _TimedExtractor(ext, timer)
+    tracker.augment = timer.wrap('init_augment', tracker.augment)
+    tracker.initialize = timer.wrap('initialize_total', tracker.initialize)
+    tracker.refiner.forward = timer.wrap('refiner', tracker.refiner.forward)
+    import frtm_vos_amd.model.tracker as _TR
+    _TR.TargetObject.initialize = timer.wrap('init_fit', _TR.TargetObject.initialize)
 
     warm = SyntheticSequence('warm', max(args.warmup, 2), size, args.objects, seed=100 + rank)
-    seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank)
+    seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank, late_object_at=args.late_object)
     warm.preload(dev)
     seq.preload(dev)
 

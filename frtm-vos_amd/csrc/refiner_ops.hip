@@ -22,13 +22,23 @@ __device__ __forceinline__ float bilinear_at(const float* __restrict__ p, int h,
   return ly0 * (lx0 * p[y0 * w + x0] + lx1 * p[y0 * w + x1]) + ly1 * (lx0 * p[y1 * w + x0] + lx1 * p[y1 * w + x1]);
 }
 
-// out[n,c] = bilinear(in[n,c], (h,w) -> (H,W)); planes = n*c
+// out[pl] = bilinear(in[pl], (h,w) -> (H,W)) for `planes` maps.  One thread per output pixel computes the four taps once and
+// walks all planes (coalesced along x in both tensors), instead of redoing the tap arithmetic per plane.
 __global__ __launch_bounds__(256) void k_bilinear_resize(const float* __restrict__ in, int h, int w, float* __restrict__ out, int H, int W,
-                                                          size_t total) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const size_t pl = i / ((size_t)W * H);
-    out[i] = bilinear_at(in + pl * (size_t)h * w, h, w, H, W, y, x);
+                                                          int planes, int planes_per_z) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H * W) return;
+  const int y = pix / W, x = pix - y * W;
+  int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+  bl_taps(y, (float)h / (float)H, h, y0, y1, ly0, ly1);
+  bl_taps(x, (float)w / (float)W, w, x0, x1, lx0, lx1);
+  const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+  const int o00 = y0 * w + x0, o01 = y0 * w + x1, o10 = y1 * w + x0, o11 = y1 * w + x1;
+  const int p0 = blockIdx.y * planes_per_z, p1 = min(planes, p0 + planes_per_z);
+  const size_t hw = (size_t)h * w, HW = (size_t)H * W;
+  for (int pl = p0; pl < p1; ++pl) {
+    const float* p = in + pl * hw;
+    out[pl * HW + pix] = w00 * p[o00] + w01 * p[o01] + w10 * p[o10] + w11 * p[o11];
   }
 }
 
@@ -37,11 +47,13 @@ __global__ __launch_bounds__(256) void k_bilinear_resize(const float* __restrict
 // contribution of the one score channel, the bias and the ReLU:
 //   out[n,c,y,x] = relu(base[c,y,x] + bias[c] + sum_{dy,dx} ws[c,dy,dx] * S_n(y+dy-1, x+dx-1)),  S_n = bilinear(scores[n]) (0 outside)
 #define INJ_T 16
+#define INJ_CG 4      // channel groups per object (more workgroups on the small maps)
 __global__ __launch_bounds__(256) void k_tse_inject(const float* __restrict__ base, const float* __restrict__ bias, const float* __restrict__ ws,
                                                      const float* __restrict__ scores, int C, int h, int w, int H, int W,
                                                      float* __restrict__ out) {
   __shared__ float S[INJ_T + 2][INJ_T + 2];
-  const int n = blockIdx.z;
+  const int n = blockIdx.z / INJ_CG, cg = blockIdx.z % INJ_CG;
+  const int cper = (C + INJ_CG - 1) / INJ_CG, c_lo = cg * cper, c_hi = min(C, c_lo + cper);
   const int ty0 = blockIdx.y * INJ_T, tx0 = blockIdx.x * INJ_T;
   const float* sc = scores + (size_t)n * h * w;
   for (int i = threadIdx.x; i < (INJ_T + 2) * (INJ_T + 2); i += 256) {
@@ -59,7 +71,7 @@ __global__ __launch_bounds__(256) void k_tse_inject(const float* __restrict__ ba
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) s[dy * 3 + dx] = S[ly + dy][lx + dx];
   const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
-  for (int c = 0; c < C; ++c) {
+  for (int c = c_lo; c < c_hi; ++c) {
     float v = base[c * HW + pix] + bias[c];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v += ws[c * 9 + k] * s[k];
@@ -117,12 +129,19 @@ __global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, i
   }
 }
 
-// out[pl] = mean over the plane (adaptive_avg_pool2d to 1x1); one block per plane, fixed summation order
+// out[pl] = mean over the plane (adaptive_avg_pool2d to 1x1); one block per plane, dwordx4 loads, fixed summation order
 __global__ __launch_bounds__(256) void k_plane_mean(const float* __restrict__ in, int HW, float* __restrict__ out) {
   __shared__ float red[16];
   const float* p = in + (size_t)blockIdx.x * HW;
   float acc = 0.f;
-  for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+  if ((HW & 3) == 0 && ((size_t)p & 15) == 0) {
+    const float4* p4 = (const float4*)p;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = threadIdx.x; i < HW / 4; i += 256) { const float4 v = p4[i]; a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w; }
+    acc = (a0 + a1) + (a2 + a3);
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+  }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) out[blockIdx.x] = acc / (float)HW;
 }
@@ -131,8 +150,9 @@ extern "C" {
 
 int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream) {
   FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "frtm_bilinear_resize: bad argument");
-  const size_t total = (size_t)planes * H * W;
-  k_bilinear_resize<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, H, W, total);
+  const int ppz = 8;
+  dim3 g(ceil_div(H * W, 256), ceil_div(planes, ppz));
+  k_bilinear_resize<<<g, 256, 0, (hipStream_t)stream>>>(in, h, w, out, H, W, planes, ppz);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
@@ -140,7 +160,7 @@ int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, 
 int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int C, int h, int w, int H, int W,
                     float* out, frtm_stream_t stream) {
   FRTM_CHECK_ARG(base && bias && ws && scores && out && n > 0 && C > 0, "frtm_tse_inject: bad argument");
-  dim3 g(ceil_div(W, INJ_T), ceil_div(H, INJ_T), n);
+  dim3 g(ceil_div(W, INJ_T), ceil_div(H, INJ_T), n * INJ_CG);
   k_tse_inject<<<g, 256, 0, (hipStream_t)stream>>>(base, bias, ws, scores, C, h, w, H, W, out);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;

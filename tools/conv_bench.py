@@ -23,6 +23,13 @@ RN101_480P = [
 ]
 
 
+# refinement network, 2 objects, 480p: (Cin, Cout, k, stride, Hin, Win, count per frame), batch = objects (1 for the shared part)
+REFINER_480P_N2 = [
+    (64, 64, 3, 1, 120, 214, 4), (65, 65, 3, 1, 120, 214, 1), (65, 64, 3, 1, 120, 214, 1), (64, 64, 1, 1, 120, 214, 2),
+    (64, 32, 3, 1, 240, 428, 1), (64, 64, 3, 1, 60, 107, 4), (65, 65, 3, 1, 60, 107, 1), (64, 64, 3, 1, 30, 54, 4),
+]
+
+
 def timeit(fn, iters=20):
     """Kernel time only: capture `iters` back-to-back launches in a hipGraph (frtm_* enqueue on torch's
     current stream, which is the capture stream here) and time replays with HIP events."""
@@ -46,10 +53,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--sweep', action='store_true')
     ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--set', default='trunk', choices=['trunk', 'refiner'])
     args = ap.parse_args()
     dev = 'cuda:0'
     total_us, total_fl = 0.0, 0.0
-    for (cin, cout, k, s, h, w, cnt) in RN101_480P:
+    for (cin, cout, k, s, h, w, cnt) in (RN101_480P if args.set == 'trunk' else REFINER_480P_N2):
         x = torch.randn(args.batch, cin, h, w, device=dev)
         wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
         wT, ktab, lay = ops.pack_weights(wt, halo=(k == 3 and s == 1))
