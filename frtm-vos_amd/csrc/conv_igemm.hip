@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   constexpr int TA = BM / 4, RA = NT / TA, PA = BK / RA;           // A: dwordx4 along m
   constexpr int TB4 = BN / 4, RB4 = NT / TB4, PB4 = BK / RB4;      // B (MODE 1): dwordx4 along n
   constexpr int EB = BK * BN / NT, SB = NT / BN;                   // B (MODE 0): dwords
-  static_assert(BM % 32 == 0 && BN % 64 == 0 && NT % TA == 0 && BK % RA == 0 && BK % RB4 == 0, "tile");
+  static_assert(BM % 32 == 0 && BN % 64 == 0 && NT % TA == 0 && BK % RA == 0 && BK % RB4 == 0 && (BK * BN) % NT == 0, "tile");
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
@@ -435,6 +435,7 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
     *tile = vec1x1 ? ((M % 64 == 0 && blocks(64, 64) >= 512) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64)
                    : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
   const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
+               : (*tile == FRTM_TILE_128x128_8W || *tile == FRTM_TILE_128x128_16W) ? blocks(128, 128)
                : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W || *tile == FRTM_TILE_64x64_K64) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
     int s = 1;
@@ -554,6 +555,8 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     case FRTM_TILE_32x64_K64: launch_tile<32, 64, 1, 4, 64>(p, vec1x1, st); break;
     case FRTM_TILE_64x64_K64: launch_tile<64, 64, 2, 2, 64>(p, vec1x1, st); break;
     case FRTM_TILE_64x128_8W: launch_tile<64, 128, 2, 4>(p, vec1x1, st); break;
+    case FRTM_TILE_128x128_8W: launch_tile<128, 128, 2, 4>(p, vec1x1, st); break;
+    case FRTM_TILE_128x128_16W: launch_tile<128, 128, 4, 4>(p, vec1x1, st); break;
     default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
   }
   FRTM_LAUNCH_CHECK();

@@ -156,6 +156,8 @@ typedef struct {
 #define FRTM_TILE_32x64_K64 5    /* 64-deep chunks (half the barriers) */
 #define FRTM_TILE_64x64_K64 6
 #define FRTM_TILE_64x128_8W 7
+#define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
+#define FRTM_TILE_128x128_16W 9
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

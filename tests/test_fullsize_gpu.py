@@ -202,3 +202,23 @@ def test_tracker_end_to_end_vs_cpu_oracle():
     assert len(diffs) == 6
     assert max(diffs) < 2e-2, diffs           # mean |mask difference|
     assert min(agree) > 0.97, agree           # per-pixel label agreement
+
+
+def test_feature_batching_and_graphs_do_not_change_results():
+    """run_sequence with the trunk fed 4 frames per pass + hipGraph refiner == frame-by-frame eager execution."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    outs = []
+    for fb, graphs in ((1, False), (4, True)):
+        torch.manual_seed(0)
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=fb)
+        params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+        trk = params.get_model().eval()
+        trk.graph_refiner = graphs
+        seq = SyntheticSequence('fb', 11, (128, 160), 2, seed=9)
+        seq.preload(DEV)
+        labels, fps = trk.run_sequence(seq)
+        assert len(labels) == 11 and fps > 0
+        outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
+    agree = float((outs[0] == outs[1]).float().mean())
+    assert agree > 0.995, agree            # identical up to fp32 summation order inside the convs (split-K vs none)
