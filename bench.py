@@ -135,6 +135,58 @@ def cpu_baseline(args, size, n_frames):
                                                                              os.cpu_count(), T)}
 
 
+def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20):
+    """HBM-bound leg: GaussNewtonCG.run((10,)) of the filter-only problem on a full memory (N = 80, 30x54 grid, c = 96).
+    Algorithmic bytes: reference formulation 2*4*N*c*hw + 4*N*HW per operator application (+4*N*HW labels for
+    the right-hand side); this formulation's own traffic 2*4*N*c*hw + 4*N*10*hw.  11 applications per run."""
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    Hh, Ww = size
+    h, w = (Hh + 15) // 16, (Ww + 15) // 16
+    g = torch.Generator().manual_seed(7)
+    mem = Memory(n_samples, (c, h, w), (1, Hh, Ww), dev, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
+    mem.samples.copy_(torch.relu(torch.randn(n_samples, c, h, w, generator=g)))
+    lab = torch.zeros(8, 1, Hh, Ww)
+    lab[:, :, Hh // 4: Hh // 2, Ww // 4: Ww // 2] = 0.9
+    for k in range(0, n_samples, 8):
+        mem._build_normals(lab.to(dev), None, 8, None, k)
+    mem.weights.fill_(1.0 / n_samples)
+    mem.current_size = n_samples
+    wv = torch.nn.Parameter(((torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / 29.4).to(dev), requires_grad=False)
+    opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=False,
+                        direction_forget_factor=0.9 ** 750)
+    for _ in range(3):
+        opt.run((iters,))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        opt.run((iters,))
+    e1.record()
+    torch.cuda.synchronize()
+    ms_eager = e0.elapsed_time(e1) / reps
+    g_ = torch.cuda.CUDAGraph()                      # the same run as one hipGraph: device time without host launch cost
+    with torch.cuda.graph(g_):
+        opt.run((iters,))
+    g_.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        g_.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    hw, HW, apps = h * w, Hh * Ww, iters + 1
+    ref_bytes = apps * (2 * 4 * n_samples * c * hw + 4 * n_samples * HW) + 4 * n_samples * HW
+    own_bytes = apps * (2 * 4 * n_samples * c * hw + 4 * n_samples * 10 * hw)
+    return {'bound': 'hbm', 'kernel': 'k_filter_scores + k_filter_wgrad<stencil> + k_cg_step_small: GaussNewtonCG.run((10,)), N=80',
+            'achieved': own_bytes / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': own_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            'ms_per_run': ms, 'ms_per_run_eager_launch': ms_eager, 'bytes_moved_this_formulation': own_bytes, 'bytes_reference_formulation': ref_bytes,
+            'equivalent_rate_on_reference_bytes': ref_bytes / (ms * 1e-3) / 1e9}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -230,6 +282,8 @@ def main():
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'host_enqueue_ms_per_step': 1e3 * t_host / n,
     }
+    if rank == 0 and world == 1:
+        out['roofline_cg'] = cg_roofline(dev, size)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, size, args.cpu_frames)
     if rank == 0:

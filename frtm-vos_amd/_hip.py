@@ -30,12 +30,14 @@ SIGNATURES = {
     'frtm_filter_scores': (I, [P, P, I, I, I, I, P, I, P]),
     'frtm_stencil': (I, [P, P, P, P, I, I, I, P, P]),
     'frtm_filter_wgrad': (I, [P, P, I, I, I, I, P, P]),
+    'frtm_filter_wgrad_stencil': (I, [P, P, P, P, P, I, I, I, I, P, P]),
     'frtm_filter_igrad': (I, [P, P, I, I, I, I, P, I, P]),
     'frtm_vec_reduce_slabs': (I, [P, I, I, I, F, P, F, P, P]),
     'frtm_cg_begin': (I, [P, P, P, I, I, F, F, I, P, P]),
     'frtm_cg_direction': (I, [P, P, I, I, F, F, I, I, I, F, P, P, P]),
     'frtm_cg_pq': (I, [P, P, P, I, P, P]),
     'frtm_cg_update': (I, [P, P, P, P, P, I, I, F, F, I, I, I, P, P, P]),
+    'frtm_cg_step_small': (I, [P, I, I, F, P, P, P, P, P, I, F, I, I, I, I, P, P]),
     'frtm_vec_axpy': (I, [P, F, P, I, P]),
     'frtm_transpose2d': (I, [P, I, I, P, P]),
     'frtm_conv_pack_weights': (I, [P, I, I, I, I, P, P, P]),

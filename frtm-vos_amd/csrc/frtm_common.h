@@ -58,3 +58,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < nw; ++i) t += red[i];   // fixed order -> deterministic
   return t;
 }
+
+// Two block-wide sums at once (one pair of barriers instead of two); `red` must hold >= 32 floats.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  if (lane == 0) { red[wid] = a; red[16 + wid] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+  for (int i = 0; i < nw; ++i) { ta += red[i]; tb += red[16 + i]; }
+  a = ta; b = tb;
+}

@@ -262,14 +262,41 @@ __global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ B, co
 // Block = (sample n, 16 channels): 4 waves x 4 channels, 36 accumulators per lane, then wave sums.
 // ------------------------------------------------------------------------------------------
 #define WG_CH 4
+// STENCIL: t is not read from memory but formed here from the scores s: t = sw[n] * (B s - c)  (saves the k_stencil launch
+// and the round trip of t; every block of a sample recomputes it from the 9+1 maps, which stay in L2)
+template <bool STENCIL>
 __global__ __launch_bounds__(256) void k_filter_wgrad(const float* __restrict__ X, const float* __restrict__ t, int C, int h, int w,
-                                                       float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float tl[];      // (h+2) x (w+2), zero border
+                                                       float* __restrict__ partial, const float* __restrict__ Bm, const float* __restrict__ cm,
+                                                       const float* __restrict__ sw) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];      // (h+2) x (w+2), zero border  [+ the same for s]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hw = h * w, wp = w + 2;
-  for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
-    const int yy = i / wp - 1, xx = i % wp - 1;
-    tl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? t[(size_t)n * hw + yy * w + xx] : 0.f;
+  if (STENCIL) {
+    float* sl = tl + (h + 2) * wp;
+    for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
+      const int yy = i / wp - 1, xx = i % wp - 1;
+      sl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? t[(size_t)n * hw + yy * w + xx] : 0.f;   // t holds s here
+    }
+    __syncthreads();
+    const float* Bn = Bm + (size_t)n * 9 * hw;
+    const float swn = sw[n];
+    for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
+      const int yy = i / wp - 1, xx = i % wp - 1;
+      float v = 0.f;
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+        const int pq_ = yy * w + xx;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) v += Bn[(size_t)d * hw + pq_] * sl[i + (d / 3 - 1) * wp + (d % 3 - 1)];
+        if (cm) v -= cm[(size_t)n * hw + pq_];
+        v *= swn;
+      }
+      tl[i] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < (h + 2) * wp; i += 256) {
+      const int yy = i / wp - 1, xx = i % wp - 1;
+      tl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? t[(size_t)n * hw + yy * w + xx] : 0.f;
+    }
   }
   __syncthreads();
   const int cbase = blockIdx.x * (4 * WG_CH) + wid * WG_CH;
@@ -450,6 +477,56 @@ __global__ __launch_bounds__(256) void k_cg_update(float* __restrict__ x, float*
   }
 }
 
+// One whole CG iteration's vector work for n <= 1024 (the 864-element filter problem) in ONE workgroup:
+//   q = sum_k slabs[k] + lam2 p ; pq = <p,q> ; alpha ; r_prev = r ; x (+)= alpha p ; r -= alpha q (not on the last iteration) ;
+//   z = M^-1 r ; rho' = <r,z> ; rho2 = <r_prev,z> ; and, unless this is the last iteration of the run, the next direction
+//   beta = clamp((rho' - rho2)/rho, 0) ; p = z + beta p ; rho = rho'.          (optimizer.py:113-151, same order of operations)
+__global__ __launch_bounds__(1024) void k_cg_step_small(const float* __restrict__ slabs, int nslab, int stride, float lam2, float* __restrict__ x,
+                                                         float* __restrict__ r, float* __restrict__ r_prev, float* __restrict__ p,
+                                                         float* __restrict__ q, int n, float invM, int first, int last, int std_alpha, int fr,
+                                                         float* __restrict__ state) {
+  __shared__ float red[32];
+  const int i = threadIdx.x;
+  const bool on = i < n;
+  float qv = 0.f, pv = 0.f, rv = 0.f;
+  if (on) {
+    // eight independent accumulators keep eight loads in flight; the final order of additions is fixed (deterministic)
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += slabs[(size_t)(k + j) * stride + i];
+    }
+    for (; k < nslab; ++k) a[0] += slabs[(size_t)k * stride + i];
+    qv = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    pv = p[i]; rv = r[i];
+    qv += lam2 * pv;
+    q[i] = qv;
+  }
+  float pq = on ? pv * qv : 0.f, pr = on ? pv * rv : 0.f;
+  block_sum2(pq, pr, red);
+  const float rho = state[4];                          // rho of this iteration (left by k_cg_direction / the previous step)
+  const float alpha = std_alpha ? rho / pq : pr / pq;
+  float rn = rv;
+  if (on) {
+    r_prev[i] = rv;
+    x[i] = first ? pv * alpha : x[i] + pv * alpha;
+    if (!last) { rn = rv - qv * alpha; r[i] = rn; }
+  }
+  const float z = rn * invM;
+  float rho_new = on ? rn * z : 0.f, rho2 = on ? rv * z : 0.f;
+  block_sum2(rho_new, rho2, red);
+  if (!last) {
+    const float v = fr ? rho_new / rho : (rho_new - rho2) / rho;
+    const float beta = (v < 0.f) ? 0.f : v;
+    if (on) p[i] = z + pv * beta;
+    __syncthreads();
+    if (i == 0) { state[0] = rho; state[4] = rho_new; state[1] = alpha; state[2] = beta; }
+  } else if (i == 0) {
+    state[0] = rho; state[1] = alpha;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_vec_axpy(float* __restrict__ y, float a, const float* __restrict__ x, int n) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] += a * x[i];
 }
@@ -606,7 +683,18 @@ int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w
   const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
   FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_wgrad: feature grid %dx%d too large for the LDS tile", h, w);
   dim3 g(ceil_div(C, 4 * WG_CH), N);
-  k_filter_wgrad<<<g, 256, lds, (hipStream_t)stream>>>(X, t, C, h, w, partial);
+  k_filter_wgrad<false><<<g, 256, lds, (hipStream_t)stream>>>(X, t, C, h, w, partial, nullptr, nullptr, nullptr);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_filter_wgrad_stencil(const float* X, const float* s, const float* B, const float* c, const float* sw, int N, int C, int h, int w,
+                              float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && s && B && sw && partial && N > 0 && C > 0, "frtm_filter_wgrad_stencil: bad argument");
+  const size_t lds = 2 * (size_t)(h + 2) * (w + 2) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_wgrad_stencil: feature grid %dx%d too large for the LDS tile", h, w);
+  dim3 g(ceil_div(C, 4 * WG_CH), N);
+  k_filter_wgrad<true><<<g, 256, lds, (hipStream_t)stream>>>(X, s, C, h, w, partial, B, c, sw);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
@@ -657,6 +745,15 @@ int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const floa
                    int first, int last, int standard_alpha, float* state, float* partial, frtm_stream_t stream) {
   FRTM_CHECK_ARG(x && r && r_prev && p && q && state && partial, "frtm_cg_update: bad argument");
   k_cg_update<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(x, r, r_prev, p, q, n1, n2, invM1, invM2, first, last, standard_alpha, state, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cg_step_small(const float* slabs, int nslab, int stride, float lam2, float* x, float* r, float* r_prev, float* p, float* q, int n,
+                       float invM, int first, int last, int standard_alpha, int fletcher_reeves, float* state, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(slabs && x && r && r_prev && p && q && state && nslab > 0 && n > 0 && n <= 1024, "frtm_cg_step_small: needs 0 < n <= 1024 (got %d)", n);
+  k_cg_step_small<<<1, 1024, 0, (hipStream_t)stream>>>(slabs, nslab, stride, lam2, x, r, r_prev, p, q, n, invM, first, last, standard_alpha,
+                                                       fletcher_reeves, state);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

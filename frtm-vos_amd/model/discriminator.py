@@ -92,6 +92,16 @@ class DiscriminatorLoss(MinimizationProblem):
         H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, H.ptr(self.partial))
         H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N, self.c * 9, self.c * 9, lam2, pvec, sign, out)
 
+    def apply_A_partials(self, p):
+        """Filter-only problem: leaves J^T J p as per-sample partial slabs (the solver's fused step kernel reduces them and
+        adds lam^2 p).  Three launches: scores, stencil, weight gradient.  Returns (slabs, nslab, stride, lam2) or None."""
+        if self.joint:
+            return None
+        ops.filter_scores(self.mem.samples, p, out=self.s, n=self.N)
+        self._stencil(False)          # separate 4.6 us kernel: fusing it into the weight-gradient kernel measured slower (+8 us)
+        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, H.ptr(self.partial))
+        return self.partial, self.N, self.c * 9, self.filter_regs[0] ** 2
+
     def _project_grad(self, lam2, pvec, sign, out):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
         H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)

@@ -138,6 +138,16 @@ class GaussNewtonCG:
         apply_dff = int(self._has_p and dff != 0)
         fr = int(self.fletcher_reeves)
         H.call('frtm_cg_begin', b, r, r_prev, n1, n2, im1, im2, int(self._has_p and not fr), part)
+        fused = n2 == 0 and n1 <= 1024 and hasattr(pr, 'apply_A_partials')
+        if fused:
+            # small single-tensor problem: one fused vector kernel per iteration (3 launches per CG iteration in total)
+            H.call('frtm_cg_direction', r, p, n1, n2, im1, im2, int(self._has_p), apply_dff, fr, dff if dff != 0 else 1.0, st, part)
+            self._has_p = True
+            for ii in range(num_iter):
+                slabs, nslab, stride, lam2 = pr.apply_A_partials(self._buf[3])
+                H.call('frtm_cg_step_small', H.ptr(slabs), nslab, stride, float(lam2), dx, r, r_prev, p, q, n1, im1, int(ii == 0),
+                       int(ii == num_iter - 1), int(self.standard_alpha), fr, st)
+            return pr.views(self._buf[5]), []
         for ii in range(num_iter):
             H.call('frtm_cg_direction', r, p, n1, n2, im1, im2, int(self._has_p), apply_dff if ii == 0 else 0, fr,
                    dff if dff != 0 else 1.0, st, part)

@@ -82,6 +82,10 @@ int frtm_stencil(const float* B, const float* c, const float* sw, const float* s
 int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w,
                       float* partial, frtm_stream_t stream);
 
+/* The same with the stencil fused in: t = sw * (B s - c) is formed inside the kernel from the scores s (c may be NULL). */
+int frtm_filter_wgrad_stencil(const float* X, const float* s, const float* B, const float* c, const float* sw,
+                              int N, int C, int h, int w, float* partial, frtm_stream_t stream);
+
 /* Input gradient of the 3x3 filter: D[n,c,y,x] = sum_{dy,dx} f[c,dy,dx] * t[n,y-dy+1,x-dx+1].
  * pix_major != 0 writes D as (n, h*w, C) instead of (n, C, h*w). */
 int frtm_filter_igrad(const float* t, const float* f, int N, int C, int h, int w,
@@ -113,6 +117,13 @@ int frtm_cg_pq(const float* p, const float* q, const float* r, int n, float* par
 int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const float* q, int n1, int n2,
                    float invM1, float invM2, int first, int last, int standard_alpha, float* state,
                    float* partial, frtm_stream_t stream);
+/* One CG iteration's vector work for n <= 1024 in a single workgroup (the 864-element filter problem): slab reduce
+ * (q = sum_k slabs[k*stride+i] + lam2 p), <p,q>, alpha, r_prev/x/r updates, and -- unless `last` -- the next direction
+ * (beta, p, rho).  Same order of operations as optimizer.py:113-151; replaces frtm_vec_reduce_slabs + frtm_cg_pq +
+ * frtm_cg_update + frtm_cg_direction on that problem. */
+int frtm_cg_step_small(const float* slabs, int nslab, int stride, float lam2, float* x, float* r, float* r_prev,
+                       float* p, float* q, int n, float invM, int first, int last, int standard_alpha,
+                       int fletcher_reeves, float* state, frtm_stream_t stream);
 /* y += a * x */
 int frtm_vec_axpy(float* y, float a, const float* x, int n, frtm_stream_t stream);
 /* out[c*rows + r] = in[r*cols + c]  (small 2-D transpose, rows x cols -> cols x rows) */

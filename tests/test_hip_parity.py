@@ -111,6 +111,9 @@ def test_filter_kernels(ops, N, C, h, w):
     H.call('frtm_stencil', H.ptr(Bd), H.ptr(cd), H.ptr(swd), H.ptr(sd), N, h, w, H.ptr(out))
     ref = (O.stencil_apply(Bm, sflat) - cc) * sw[:, None, None]
     assert rel(out.view(N, h, w), ref) < 1e-5
+    part2 = torch.empty(N, C * 9, device=DEV)         # stencil fused into the weight gradient == the two separate kernels
+    H.call('frtm_filter_wgrad_stencil', H.ptr(Xd), H.ptr(sd), H.ptr(Bd), H.ptr(cd), H.ptr(swd), N, C, h, w, H.ptr(part2))
+    assert rel(part2.sum(0).view(1, C, 3, 3), O.conv3x3_wgrad(X, ref[:, None])) < 3e-5
 
 
 def test_transpose_and_axpy(ops):
