@@ -1,0 +1,81 @@
+"""DAVIS region (J) and boundary (F) measures (names of the reference's lib/davis.py:19-189, itself a port of the public
+DAVIS toolkit; that file cannot run here: it needs skimage and uses np.bool, removed in numpy >= 1.24).
+
+Restated from the published definitions (Perazzi et al., CVPR 2016):
+  J  = |M & G| / |M | G|  (1 when both are empty)
+  F  = 2PR/(P+R) between the boundary maps of M and G, a boundary pixel counting as matched when the other boundary has
+       a pixel within bound_th * image diagonal (>= 1 px), implemented as a disk dilation.
+Pixel-exact agreement with skimage's disk()/binary_dilation is UNPINNED (skimage is not installed); the disk here is
+{(dy,dx): dy^2 + dx^2 <= r^2}.  CPU only; not on the hot path.
+"""
+import numpy as np
+from scipy import ndimage
+
+
+def db_eval_iou(annotation, segmentation):
+    a = np.asarray(annotation).astype(bool)
+    s = np.asarray(segmentation).astype(bool)
+    union = np.logical_or(a, s).sum()
+    if union == 0:
+        return 1.0
+    return float(np.logical_and(a, s).sum()) / float(union)
+
+
+def seg2bmap(seg):
+    """Boundary map: a pixel is a boundary pixel if it differs from its east, south or south-east neighbour."""
+    seg = np.asarray(seg).astype(bool)
+    e = np.zeros_like(seg)
+    s = np.zeros_like(seg)
+    se = np.zeros_like(seg)
+    e[:, :-1] = seg[:, 1:]
+    e[:, -1] = seg[:, -1]
+    s[:-1, :] = seg[1:, :]
+    s[-1, :] = seg[-1, :]
+    se[:-1, :-1] = seg[1:, 1:]
+    se[:-1, -1] = seg[1:, -1]
+    se[-1, :-1] = seg[-1, 1:]
+    se[-1, -1] = seg[-1, -1]
+    b = (seg ^ e) | (seg ^ s) | (seg ^ se)
+    b[-1, :] = seg[-1, :] ^ e[-1, :]
+    b[:, -1] = seg[:, -1] ^ s[:, -1]
+    b[-1, -1] = False
+    return b
+
+
+def _disk(r):
+    y, x = np.ogrid[-r:r + 1, -r:r + 1]
+    return (x * x + y * y) <= r * r
+
+
+def db_eval_boundary(foreground_mask, gt_mask, bound_th=0.008):
+    fg = np.asarray(foreground_mask).astype(bool)
+    gt = np.asarray(gt_mask).astype(bool)
+    bound_pix = bound_th if bound_th >= 1 else int(np.ceil(bound_th * np.linalg.norm(fg.shape)))
+    fg_b, gt_b = seg2bmap(fg), seg2bmap(gt)
+    k = _disk(max(int(bound_pix), 1))
+    fg_d = ndimage.binary_dilation(fg_b, structure=k)
+    gt_d = ndimage.binary_dilation(gt_b, structure=k)
+    gt_match, fg_match = gt_b & fg_d, fg_b & gt_d
+    n_fg, n_gt = fg_b.sum(), gt_b.sum()
+    if n_fg == 0 and n_gt > 0:
+        precision, recall = 1.0, 0.0
+    elif n_fg > 0 and n_gt == 0:
+        precision, recall = 0.0, 1.0
+    elif n_fg == 0 and n_gt == 0:
+        precision, recall = 1.0, 1.0
+    else:
+        precision, recall = fg_match.sum() / float(n_fg), gt_match.sum() / float(n_gt)
+    if precision + recall == 0:
+        return 0.0
+    return float(2 * precision * recall / (precision + recall))
+
+
+def db_statistics(per_frame_values):
+    """Mean, recall (fraction > 0.5) and decay (first-quarter mean minus last-quarter mean) over the frames."""
+    v = np.asarray(per_frame_values, dtype=np.float64)
+    v = v[~np.isnan(v)]
+    if v.size == 0:
+        return float('nan'), float('nan'), float('nan')
+    ids = np.round(np.linspace(1, len(v), 5) + 1e-10).astype(np.int64) - 1
+    bins = [v[ids[i]:ids[i + 1] + 1] for i in range(4)]
+    return float(v.mean()), float((v > 0.5).mean()), float(np.mean(bins[0]) - np.mean(bins[3]))

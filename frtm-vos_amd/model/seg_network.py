@@ -5,7 +5,7 @@ SURVEY.md 8f row "next-1".  Two execution paths with identical results:
    kernels of libfrtm_hip.so (halo-tile 3x3 / vectorised 1x1) with bias, eval-BatchNorm, ReLU and the residual add folded
    into the conv epilogue; the glue (score injection, channel-attention combine, polyphase bicubic, bilinear) is one fused
    HIP kernel each (csrc/refiner_ops.hip).  ~80 launches per frame instead of ~370 framework launches.
- * plain PyTorch ops (the definition of the network; used on CPU, for training, and as the test oracle of the HIP path).
+ * plain PyTorch ops (the definition of the network; used on CPU, for training, and as the definition the HIP path is tested against).
 Structural changes relative to the reference that leave the results unchanged:
  * all objects of a frame go through ONE batched pass (scores (n_obj,1,h,w), shared backbone taps);
    the reference loops over objects in Python (model/tracker.py:200-204);

@@ -220,3 +220,21 @@ def test_sharding_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'SHARD_OK' in outs[0]
+
+
+def test_davis_measures():
+    from frtm_vos_amd.lib.davis import db_eval_boundary, db_eval_iou, db_statistics, seg2bmap
+    from frtm_vos_amd.lib.evaluation import evaluate_dataset, j_and_f
+    a = np.zeros((60, 80), bool); a[10:40, 20:60] = True
+    b = np.zeros((60, 80), bool); b[12:42, 22:62] = True
+    assert db_eval_iou(a, a) == 1.0 and db_eval_iou(np.zeros_like(a), np.zeros_like(a)) == 1.0
+    assert abs(db_eval_iou(a, b) - (28 * 38) / (2 * 30 * 40 - 28 * 38)) < 1e-12
+    assert db_eval_boundary(a, a) == 1.0 and db_eval_boundary(a, np.zeros_like(a)) == 0.0
+    assert 0.0 < db_eval_boundary(a, b) < 0.2 and db_eval_boundary(a, b, bound_th=3) == 1.0      # 2 px shift, 3 px tolerance
+    assert seg2bmap(a).sum() == 2 * 30 + 2 * 40
+    m, r, d = db_statistics([0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2])
+    assert abs(m - 0.55) < 1e-12 and r == 0.5 and d > 0
+    lab = [a.astype(np.uint8) * 2] * 6
+    assert j_and_f(lab, lab, [2])[0] == 100.0
+    res = evaluate_dataset([('s', lab, lab, [2])], 'J')
+    assert res['mean'] == 1.0 and 's' in res['per_sequence']

@@ -165,7 +165,7 @@ def test_tracker_end_to_end_vs_cpu_oracle():
     cpu.targets = {}
     torch.set_grad_enabled(False)
     trk.current_frame, trk.targets = 0, dict()
-    agree, diffs = [], []
+    agree, diffs, hip_labels, cpu_labels = [], [], [], []
     for oid in (1, 2):                       # shared initial target-model weights, injected into both sides
         g = torch.Generator().manual_seed(100 + oid)
         w1w2[oid] = ((torch.rand(96, 256, 1, 1, generator=g) * 2 - 1) / 16, (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / 29.4)
@@ -193,6 +193,7 @@ def test_tracker_end_to_end_vs_cpu_oracle():
                 trk.track(image.to(DEV))
                 cpu.track(image)
                 hm, cm = trk.current_masks.cpu(), cpu.masks
+                hip_labels.append(hm.argmax(0)); cpu_labels.append(cm.argmax(0))
                 diffs.append(float((hm - cm).abs().mean()))
                 agree.append(float((hm.argmax(0) == cm.argmax(0)).float().mean()))
             trk.current_frame += 1
@@ -202,6 +203,14 @@ def test_tracker_end_to_end_vs_cpu_oracle():
     assert len(diffs) == 6
     assert max(diffs) < 2e-2, diffs           # mean |mask difference|
     assert min(agree) > 0.97, agree           # per-pixel label agreement
+    # J&F of both paths against the synthetic ground truth (weights are random, so the absolute value is meaningless;
+    # the gate is the difference between the HIP path and the CPU oracle path)
+    from frtm_vos_amd.lib.evaluation import j_and_f
+    gt = [lb.reshape(96, 128).numpy() for lb in seq.gt]
+    jf_h = j_and_f([m.numpy() for m in hip_labels], gt[1:], [1, 2])[0]
+    jf_c = j_and_f([m.numpy() for m in cpu_labels], gt[1:], [1, 2])[0]
+    print('J&F hip %.3f  cpu-oracle %.3f' % (jf_h, jf_c))
+    assert abs(jf_h - jf_c) < 1.0
 
 
 def test_feature_batching_and_graphs_do_not_change_results():

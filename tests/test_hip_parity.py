@@ -456,3 +456,59 @@ def test_device_guarded_memory_update():
     m.update(torch.full((1, 2, 3, 4), 7.0, device=DEV), lab, count_dev=many)
     assert int(m._slot[1]) == 5 and float(m.samples[5, 0, 0, 0]) == 7.0 and abs(float(m.weights.sum()) - 1) < 1e-6
     assert float(m.normal_B[5].abs().sum()) > 0
+
+
+def test_discriminator_early_outs_and_flags():
+    """Silent early-outs of Discriminator.update (reference discriminator.py:210-215,221) and the frame counter semantics."""
+    from frtm_vos_amd.model.discriminator import Discriminator
+    g = gen(31)
+    cin, c, h, w, H, W = 16, 8, 6, 9, 48, 70
+    x = torch.relu(torch.randn(3, cin, h, w, generator=g)).to(DEV)
+    y = torch.zeros(3, 1, H, W, dtype=torch.uint8)
+    y[:, :, 10:30, 20:50] = 1
+    d = Discriminator(in_channels=cin, c_channels=c, init_iters=(2, 2), update_iters=(2,), memory_size=6, train_skipping=2,
+                      pixel_weighting=PW, device=DEV, layer='layer4')
+    d.update(torch.ones(1, 1, H, W, device=DEV))                   # before init/apply: nothing to insert -> silent return
+    assert d.memory is None and d.frame_num == 0
+    d.init(x, y.to(DEV))
+    assert d.memory.current_size == 3 and d.update_optimizer is not None
+    w_before = d.filter.weight.detach().clone()
+    s = d.apply(x[:1])
+    assert d.frame_num == 1 and d.current_sample.shape == (1, c, h, w)
+    d.update(torch.zeros(1, 1, H, W, device=DEV))                  # < 10 px above 0.5 -> no insert, no solve (:214)
+    assert d.memory.current_size == 3 and torch.equal(d.filter.weight, w_before)
+    d.apply(x[1:2])                                                # frame 2: train_skipping = 2 -> insert AND re-solve
+    soft = y[:1].float().to(DEV) * 0.8
+    d.update(soft)
+    assert d.memory.current_size == 4 and not torch.equal(d.filter.weight, w_before)
+    w_mid = d.filter.weight.detach().clone()
+    d.apply(x[2:3])                                                # frame 3: insert only
+    d.update(soft)
+    assert d.memory.current_size == 5 and torch.equal(d.filter.weight, w_mid)
+    d.update_filters = False
+    d.apply(x[:1])
+    d.update(soft)
+    assert d.memory.current_size == 5 and d.frame_num == 4         # frame counter advances in apply(), not in update()
+    for _ in range(4):                                             # fill past capacity: replacement keeps the size at cap
+        d.update_filters = True
+        d.apply(x[:1])
+        d.update(soft)
+    assert d.memory.current_size == 6 and abs(float(d.memory.weights.sum()) - 1) < 1e-5
+
+
+def test_run_sequence_label_decoding():
+    """Single-object sequences are thresholded at 0.5, multi-object ones arg-max merged (reference tracker.py:143-150)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    for n_obj in (1, 3):
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18')
+        params.disc_params.update(memory_size=6, init_iters=(2, 2), update_iters=(2,))
+        trk = params.get_model().eval()
+        seq = SyntheticSequence('lab', 5, (96, 128), n_obj, seed=12)
+        seq.preload(DEV)
+        labels, fps = trk.run_sequence(seq)
+        assert len(labels) == 5 and fps > 0
+        for lb in labels:
+            assert lb.dtype == torch.uint8 and lb.shape[-2:] == (96, 128)
+            assert set(lb.unique().tolist()) <= set(range(n_obj + 1))
+        assert torch.equal(labels[0].reshape(96, 128), seq.gt[0].reshape(96, 128))       # frame 0 = the given labels
