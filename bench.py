@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=24)
+    ap.add_argument('--overlap', action='store_true', help='run the next trunk batch on a side stream, overlapped with tracking')
     ap.add_argument('--memory', type=int, default=80, help='target-model memory slots (80 = evaluate.py:80)')
     ap.add_argument('--late-object', type=int, default=None, help='frame at which the last object first appears')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) for real multi-GPU runs; gloo to exercise the path on one GPU')
@@ -215,6 +216,7 @@ def main():
     params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone, feature_batch=args.trunk_batch)
     params.disc_params['memory_size'] = args.memory
     tracker = params.get_model()
+    tracker.prefetch_stream = args.overlap
     tracker.eval()
     torch.set_grad_enabled(False)
 

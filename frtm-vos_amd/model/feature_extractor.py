@@ -142,6 +142,7 @@ class ResnetFeatureExtractor:
         self.last_conv_launches = 0
         self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
         self._out_cache = {}
+        self.output_set = 0            # which persistent tap set to write (double buffering for the prefetch stream)
 
     def __del__(self):
         try:
@@ -204,7 +205,7 @@ class ResnetFeatureExtractor:
                 ch, cw = (ch + 1) // 2, (cw + 1) // 2
             dims[L] = (self._out_channels[L], ch, cw)
         if self.reuse_outputs:
-            key = (B, Hh, Ww, tuple(want))
+            key = (B, Hh, Ww, tuple(want), self.output_set)
             out = self._out_cache.get(key)
             if out is None:
                 out = self._out_cache[key] = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
