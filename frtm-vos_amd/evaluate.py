@@ -76,3 +76,62 @@ class Parameters:
             mdl.load_state_dict(self.weights)
         mdl.to(self.device)
         return mdl
+
+
+def main(argv=None):
+    """``python -m frtm_vos_amd.evaluate --model rn101_all.pth --dset dv2017val --davis /data/DAVIS --output /tmp/out``
+    (reference evaluate.py:108-165).  One process per GPU: launched under torch.distributed.run, every rank takes
+    ``dataset[rank::world_size]`` (no collective on the data path) and rank 0 prints the aggregate frame rate."""
+    import argparse
+    import os
+    from pathlib import Path
+
+    from .lib.datasets import DAVISDataset, YouTubeVOSDataset
+    from .lib.evaluation import evaluate_sequence
+    from .lib.davis import db_statistics
+    from .shard import aggregate_throughput, shard_sequences
+
+    ap = argparse.ArgumentParser(description='Evaluate FRTM on a validation dataset (MI355X-native hot path)')
+    ap.add_argument('--model', required=True, help='FRTM checkpoint (.pth with the refiner weights)')
+    ap.add_argument('--dset', required=True, choices=['dv2016val', 'dv2017val', 'yt2018val', 'yt2018jjval'])
+    ap.add_argument('--dev', default='cuda:0')
+    ap.add_argument('--fast', action='store_true', help='fewer optimizer steps (README "fast" schedule)')
+    ap.add_argument('--davis', default=os.environ.get('DAVIS_ROOT', '/path/to/DAVIS'))
+    ap.add_argument('--yt2018', default=os.environ.get('YTVOS_ROOT', '/path/to/ytvos2018'))
+    ap.add_argument('--jjval-list', default=None, help="id list of the reference's jjval split (lib/ytvos_jjvalid.txt upstream)")
+    ap.add_argument('--output', default='results')
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', 0))
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        args.dev = 'cuda:%d' % local
+    weights = torch.load(args.model, map_location='cpu')['model']
+    if args.dset.startswith('dv'):
+        dset = DAVISDataset(args.davis, args.dset[2:6], 'val')
+    elif args.dset == 'yt2018jjval':
+        dset = YouTubeVOSDataset(args.yt2018, '2018', 'jjval_all_frames', sequences_file=args.jjval_list)
+    else:
+        dset = YouTubeVOSDataset(args.yt2018, '2018', 'valid_all_frames')
+    out_path = Path(args.output).expanduser().resolve() / (dset.name + '-' + Path(args.model).stem + ('_fast' if args.fast else ''))
+    tracker = Parameters(weights, fast=args.fast, device=args.dev).get_model()
+
+    class _Shard:
+        name = dset.name
+
+        def __iter__(self):
+            return iter(shard_sequences(list(dset), rank, world))
+    import time
+    t0, frames = time.time(), 0
+    tracker.run_dataset(_Shard(), out_path, speedrun=args.dset == 'dv2016val')
+    frames = sum(len(s) for s in shard_sequences(list(dset), rank, world))
+    fps, total, wall = aggregate_throughput(frames, time.time() - t0, device=args.dev if world > 1 else 'cpu')
+    if rank == 0:
+        print('%d frames on %d GPU(s): %.1f frames/s incl. decoding and PNG writing' % (total, world, fps))
+
+
+if __name__ == '__main__':
+    main()

@@ -238,3 +238,55 @@ def test_davis_measures():
     assert j_and_f(lab, lab, [2])[0] == 100.0
     res = evaluate_dataset([('s', lab, lab, [2])], 'J')
     assert res['mean'] == 1.0 and 's' in res['per_sequence']
+
+
+def test_file_datasets(tmp_path):
+    """DAVIS / YouTube-VOS directory layouts -> FileSequence protocol (reference lib/datasets.py:16-158)."""
+    from PIL import Image
+    from frtm_vos_amd.lib.datasets import DAVISDataset, YouTubeVOSDataset
+    from frtm_vos_amd.lib.image import imwrite_indexed, imread
+    root = tmp_path / 'DAVIS'
+    for seq, ids in (('bear', (1,)), ('cows', (1, 2))):
+        (root / 'JPEGImages' / '480p' / seq).mkdir(parents=True)
+        (root / 'Annotations' / '480p' / seq).mkdir(parents=True)
+        for t in range(3):
+            Image.fromarray(np.full((20, 30, 3), 40 * t, np.uint8)).save(root / 'JPEGImages' / '480p' / seq / ('%05d.jpg' % t))
+            lb = torch.zeros(20, 30, dtype=torch.uint8)
+            for i in ids:
+                lb[2 + 5 * i:6 + 5 * i, 3:12] = i
+            imwrite_indexed(root / 'Annotations' / '480p' / seq / ('%05d.png' % t), lb)
+    (root / 'ImageSets' / '2017').mkdir(parents=True)
+    (root / 'ImageSets' / '2016').mkdir(parents=True)
+    (root / 'ImageSets' / '2017' / 'val.txt').write_text('cows\nbear\n')
+    (root / 'ImageSets' / '2016' / 'val.txt').write_text('cows\n')
+    d17 = DAVISDataset(root, '2017', 'val')
+    assert d17.name == 'dv2017val' and d17.sequences == ['bear', 'cows'] and len(d17) == 2
+    cows = d17[1]
+    assert cows.obj_ids == [1, 2] and len(cows) == 3 and cows.frame_names == ['00000', '00001', '00002']
+    im, lb, new = cows[0]
+    assert im.shape == (3, 20, 30) and im.dtype == torch.uint8 and lb.shape == (1, 20, 30) and new == [1, 2]
+    assert set(lb.unique().tolist()) == {0, 1, 2} and cows[1][1] == [] and cows[1][2] == []
+    d16 = DAVISDataset(root, '2016', 'val')
+    im, lb, new = d16[0][0]
+    assert d16[0].obj_ids == [1] and new == [1] and set(lb.unique().tolist()) == {0, 1}      # merged foreground
+    with pytest.raises(ValueError):
+        DAVISDataset(root, '2017', 'val', sequences=['nope'])
+    assert DAVISDataset(root, '2017', 'val', restart='cows').sequences == ['cows']
+    # YouTube-VOS: object 2 starts at the second frame; its label is suppressed in the first annotation
+    yt = tmp_path / 'yt'
+    (yt / 'valid_all_frames' / 'JPEGImages' / 'v1').mkdir(parents=True)
+    (yt / 'valid' / 'Annotations' / 'v1').mkdir(parents=True)
+    for t in range(3):
+        Image.fromarray(np.zeros((20, 30, 3), np.uint8)).save(yt / 'valid_all_frames' / 'JPEGImages' / 'v1' / ('%05d.jpg' % t))
+        lb = torch.zeros(20, 30, dtype=torch.uint8)
+        lb[2:6, 2:8] = 1
+        lb[10:14, 2:8] = 2
+        imwrite_indexed(yt / 'valid' / 'Annotations' / 'v1' / ('%05d.png' % t), lb)
+    (yt / 'valid' / 'meta.json').write_text('{"videos": {"v1": {"objects": {"1": {"frames": ["00000"]}, "2": {"frames": ["00001"]}}}}}')
+    v1 = YouTubeVOSDataset(yt, '2018', 'valid_all_frames')[0]
+    im, lb, new = v1[0]
+    assert new == [1] and set(lb.unique().tolist()) == {0, 1}
+    im, lb, new = v1[1]
+    assert new == [2] and set(lb.unique().tolist()) == {0, 2} and v1[2][2] == []
+    with pytest.raises(ValueError):
+        YouTubeVOSDataset(yt, '2018', 'jjval_all_frames')
