@@ -181,7 +181,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
     FRTM_HIP(hipMalloc((void**)&c.shift, c.Cout * sizeof(float)));
     if (c.ks > 1) FRTM_HIP(hipMalloc((void**)&c.ktab, K * 3 * sizeof(int)));
   }
-  c.layout = (c.ks == 3 && c.stride == 1 && c.pad == 1) ? FRTM_WLAYOUT_HALO3X3 : FRTM_WLAYOUT_GEMM;
+  c.layout = (c.ks == 3 && c.stride <= 2 && c.pad == 1) ? FRTM_WLAYOUT_HALO3X3 : FRTM_WLAYOUT_GEMM;
   int rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, c.ks, c.layout, c.wT, c.ktab, stream);
   if (rc) return rc;
   FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -72,8 +72,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   constexpr int TB4 = BN / 4, RB4 = NT / TB4, PB4 = BK / RB4;      // B (MODE 1): dwordx4 along n
   constexpr int EB = BK * BN / NT, SB = NT / BN;                   // B (MODE 0): dwords
   static_assert(BM % 32 == 0 && BN % 64 == 0 && NT % TA == 0 && BK % RA == 0 && BK % RB4 == 0 && (BK * BN) % NT == 0, "tile");
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+  constexpr int LDC = BN + 4;                                       // epilogue tile pitch: 16-byte aligned rows, conflict-free writes
+  constexpr int STAGE = 2 * BK * (LDA + LDB), CT = BM * LDC;
+  __shared__ __attribute__((aligned(16))) float smem[STAGE > CT ? STAGE : CT];
+  float (*As)[BK][LDA] = reinterpret_cast<float (*)[BK][LDA]>(smem);
+  float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(smem + 2 * BK * LDA);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
@@ -188,35 +191,49 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
-  float sc[FM][4], sh[FM][4];
+  // ---- epilogue.  The accumulators (C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg) go through an LDS
+  // tile so that global memory sees whole rows: one dwordx4 per lane, 256 contiguous bytes per 16 lanes, instead of four 64-byte
+  // fragments per store instruction.  BN scale/shift, residual (dwordx4 read) and ReLU are applied on the way out.
+  float* Cs = smem;                                    // the K loop ended with a barrier: the staging buffers are free
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mm = min(m0 + wm * TM + i * 16 + lk * 4 + r, p.M - 1);
-      sc[i][r] = (p.scale && p.splitk == 1) ? p.scale[mm] : 1.f;
-      sh[i][r] = (p.scale && p.splitk == 1) ? p.shift[mm] : 0.f;
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(wm * TM + i * 16 + lk * 4 + r) * LDC + wn * TN + j * 16 + li] = acc[i][j][r];
+  __syncthreads();
+  const bool raw = p.splitk > 1;
+  float* dst = raw ? p.ws + (size_t)blockIdx.z * p.M * p.Ntot : p.out;
+  const bool vec = (p.Npix % 4 == 0) && !p.out_transposed && (((size_t)dst) % 16 == 0) && (raw || !p.residual || ((size_t)p.residual) % 16 == 0);
+  if (vec) {
+    for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      const int mm = m0 + row, nn = n0 + c4;
+      if (mm >= p.M || nn >= p.Ntot) continue;
+      f32x4 v = *(const f32x4*)&Cs[row * LDC + c4];
+      if (raw) { *(f32x4*)&dst[(size_t)mm * p.Ntot + nn] = v; continue; }
+      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
+      if (p.scale) { const float a = p.scale[mm], b = p.shift[mm]; v = v * a + b; }
+      if (p.residual) v += *(const f32x4*)&p.residual[o];
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *(f32x4*)&dst[o] = v;
     }
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int nn = n0 + wn * TN + j * 16 + li;
-    if (nn >= p.Ntot) continue;
-    const int img = nn / p.Npix, rem = nn - img * p.Npix;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mm = m0 + wm * TM + i * 16 + lk * 4 + r;
-        if (mm >= p.M) continue;
-        if (p.splitk > 1) { p.ws[((size_t)blockIdx.z * p.M + mm) * p.Ntot + nn] = acc[i][j][r]; continue; }
-        float v = acc[i][j][r] * sc[i][r] + sh[i][r];
-        const size_t idx = ((size_t)img * p.M + mm) * p.Npix + rem;
-        if (p.residual) v += p.residual[idx];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.out_transposed) p.out[((size_t)img * p.Npix + rem) * p.M + mm] = v;
-        else p.out[idx] = v;
-      }
+  } else {
+    for (int idx = tid; idx < BM * BN; idx += NT) {
+      const int row = idx / BN, col = idx - row * BN;
+      const int mm = m0 + row, nn = n0 + col;
+      if (mm >= p.M || nn >= p.Ntot) continue;
+      float v = Cs[row * LDC + col];
+      if (raw) { dst[(size_t)mm * p.Ntot + nn] = v; continue; }
+      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
+      if (p.scale) v = v * p.scale[mm] + p.shift[mm];
+      if (p.residual) v += p.residual[o];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.out_transposed) p.out[((size_t)img * p.Npix + rem) * p.M + mm] = v;
+      else p.out[o] = v;
+    }
   }
 }
 
@@ -231,11 +248,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 constexpr int HCI = 8;                  // input channels per chunk
 constexpr int HK = HCI * 9;             // k rows per chunk
 
-template <int BM, int WGM, int WGN, int TW>
+template <int BM, int WGM, int WGN, int TW, int S = 1>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParams p) {
   constexpr int NT = 64 * WGM * WGN, BN = 64, TH = 64 / TW;
   constexpr int LDA = BM + 16;
-  constexpr int PW = TW + 2, PH = TH + 2;
+  constexpr int PW = (TW - 1) * S + 3, PH = (TH - 1) * S + 3;       // input patch of a TH x TW output tile (stride S, 3x3, pad 1)
   constexpr int PLraw = PW * PH, PL = ((PLraw + 15) / 32) * 32 + 16;      // plane pitch == 16 (mod 32), >= PLraw
   static_assert(PL >= PLraw && PL % 32 == 16, "plane pitch");
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   for (int i = 0; i < PB; ++i) {
     const int e = tid + i * NT;
     const int ci = e / PLraw, r = (e - ci * PLraw) / PW, c = e - ci * PLraw - r * PW;
-    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+    const int yy = y0 * S - 1 + r, xx = x0 * S - 1 + c;
     const bool ok = e < NB && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
     b_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
     b_loff[i] = e < NB ? ci * PL + r * PW + c : -1;
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int pt = wn * TN + j * 16 + li;
-    pb[j] = lk * PL + (pt / TW) * PW + (pt % TW);
+    pb[j] = lk * PL + (pt / TW) * S * PW + (pt % TW) * S;
   }
   if (kc0 < kc1) { gload(kc0); lstore(0); }
   __syncthreads();
@@ -451,6 +468,12 @@ template <int BM, int WGM, int WGN>
 static void launch_halo(const ConvParams& p, int tw, hipStream_t st) {
   const int th = 64 / tw;
   dim3 g(p.B * ceil_div(p.Ho, th) * ceil_div(p.Wo, tw) * ceil_div(p.M, BM), 1, p.splitk);
+  if (p.stride == 2) {
+    if (tw == 4) k_conv3x3_halo<BM, WGM, WGN, 4, 2><<<g, 64 * WGM * WGN, 0, st>>>(p);
+    else if (tw == 8) k_conv3x3_halo<BM, WGM, WGN, 8, 2><<<g, 64 * WGM * WGN, 0, st>>>(p);
+    else k_conv3x3_halo<BM, WGM, WGN, 16, 2><<<g, 64 * WGM * WGN, 0, st>>>(p);
+    return;
+  }
   if (tw == 4) k_conv3x3_halo<BM, WGM, WGN, 4><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else if (tw == 8) k_conv3x3_halo<BM, WGM, WGN, 8><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv3x3_halo<BM, WGM, WGN, 16><<<g, 64 * WGM * WGN, 0, st>>>(p);
@@ -520,7 +543,8 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   const bool halo = d->w_layout == FRTM_WLAYOUT_HALO3X3;
   int halo_tw = 8;
   if (halo) {
-    FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0, "frtm_conv2d: halo layout needs 3x3, stride 1, pad 1");
+    FRTM_CHECK_ARG(d->ksize == 3 && (d->stride == 1 || d->stride == 2) && d->pad == 1 && d->w_pitch == 0,
+                   "frtm_conv2d: halo layout needs 3x3, stride 1 or 2, pad 1");
     p.nchunks = ceil_div(d->Cin, HCI);
     p.w_bytes = (unsigned)((size_t)p.nchunks * HK * p.Mp * 4);
     halo_tw = halo_tile_width(p.Ho, p.Wo);

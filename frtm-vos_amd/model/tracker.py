@@ -173,7 +173,7 @@ class Tracker(nn.Module):
                 batch.record_stream(side)
             else:
                 if persistent:
-                    ext.output_set = bi & 1
+                    ext.output_set = 0              # single tap set: the refiner's graphs stay keyed to 4 slice addresses
                 taps, ev = ext(batch), None
             pending[i0] = (taps, ev, idx)
 

@@ -28,7 +28,7 @@ def padded_cols(M):
 
 def pack_weights(w_oihw, halo=None):
     """(Cout,Cin,k,k) -> packed GEMM weights (+ ktab for k > 1).  3x3 kernels default to the halo layout
-    (only valid for stride 1 / pad 1 convs: pass halo=False for strided 3x3).  Returns (wT, ktab, layout)."""
+    (valid for pad-1 convs of stride 1 or 2).  Returns (wT, ktab, layout)."""
     w = w_oihw.detach().float().contiguous()
     Cout, Cin, k, _ = w.shape
     layout = 1 if (halo if halo is not None else k == 3) else 0

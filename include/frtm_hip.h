@@ -148,7 +148,7 @@ typedef struct {
   int relu, out_transposed;
   int splitk;              /* 0 = auto */
   int tile;                /* 0 = auto, else FRTM_TILE_* */
-  int w_layout;            /* FRTM_WLAYOUT_GEMM (0) or FRTM_WLAYOUT_HALO3X3 (3x3, stride 1, pad 1 only) */
+  int w_layout;            /* FRTM_WLAYOUT_GEMM (0) or FRTM_WLAYOUT_HALO3X3 (3x3, stride 1 or 2, pad 1 only) */
   int w_pitch;             /* 0: wT is the padded [Kp][Mp] image of frtm_conv_pack_weights;
                               >0: wT is a plain [K][w_pitch] matrix (w_pitch >= Cout, multiple of 4, 16-byte aligned) */
 } frtm_conv_desc;
