@@ -15,7 +15,7 @@ P, I, F, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(k, I) for k in ('B', 'Cin', 'Hin', 'Win', 'Cout', 'ksize', 'stride', 'pad',
-                                 'relu', 'out_transposed', 'splitk', 'tile', 'w_layout', 'w_pitch')]
+                                 'relu', 'out_transposed', 'splitk', 'tile', 'w_layout', 'ws_elems', 'w_pitch')]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/frtm_hip.h

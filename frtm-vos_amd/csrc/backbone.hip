@@ -84,7 +84,7 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
   if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
   frtm_conv_desc d;
   d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = c.pad;
-  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0; d.w_layout = c.layout;
+  d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0; d.w_layout = c.layout; d.ws_elems = 0;
   *Ho = (Hin + 2 * c.pad - c.ks) / c.stride + 1;
   *Wo = (Win + 2 * c.pad - c.ks) / c.stride + 1;
   // conv2d plans tile/split-K itself; the workspace must cover the largest split it can pick.  Split-K is only
@@ -95,6 +95,7 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
     int rc = ensure(&bb->ws, &bb->ws_elems, std::max(w, out_elems * 2));
     if (rc) return rc;
   }
+  d.ws_elems = (int)std::min<size_t>(bb->ws_elems, 0x7fffffff);
   bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, bb->ws, st);

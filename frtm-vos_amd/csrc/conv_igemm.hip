@@ -14,6 +14,7 @@
 //    chunk c and written to the other LDS buffer afterwards; one barrier per chunk.
 //  * the trunk runs at batch 1 on 30x54 .. 120x214 maps, i.e. 400..25k pixels per conv: small
 //    tiles (32x64 / 64x64 / 128x64) plus split-K keep >= 256 workgroups in flight.
+#include <algorithm>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
@@ -556,6 +557,11 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     frtm_conv_plan(p.M, ptiles * 64, p.nchunks * 2, 0, &tile, &splitk);
   } else {
     frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
+  }
+  {  // never let the partial slabs outgrow the caller's workspace
+    const size_t out_elems = (size_t)p.M * p.Ntot;
+    const int fit = (workspace && d->ws_elems > 0) ? (int)std::min<size_t>((size_t)d->ws_elems / out_elems, 1u << 20) : 1;
+    splitk = min(splitk, max(fit, 1));
   }
   splitk = max(1, min(splitk, p.nchunks));
   p.chunks_per_split = ceil_div(p.nchunks, splitk);

@@ -50,8 +50,11 @@ def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=N
     Wo = (Win + 2 * pad - ksize) // stride + 1
     if out is None:
         out = torch.empty((B, Ho * Wo, Cout) if out_transposed else (B, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
-    d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile), int(w_layout), int(w_pitch))
-    ws = workspace(x.device, 32 * Cout * B * Ho * Wo) if splitk != 1 else None
+    out_elems = Cout * B * Ho * Wo
+    # split-K only happens for small outputs (< ~800 workgroups); the library clamps the factor to the capacity given here
+    ws = workspace(x.device, min(32 * out_elems, max(2 * out_elems, 1 << 24))) if splitk != 1 else None
+    d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile), int(w_layout),
+                   0 if ws is None else min(ws.numel(), 0x7fffffff), int(w_pitch))
     H.call('frtm_conv2d', ctypes.byref(d), H.ptr(x), H.ptr(wT), H.ptr(ktab), H.ptr(scale), H.ptr(shift),
            H.ptr(residual), H.ptr(out), H.ptr(ws))
     return out

@@ -138,8 +138,8 @@ int frtm_transpose2d(const float* in, int rows, int cols, float* out, frtm_strea
  *     up to 32 (see frtm_conv_pack_weights; FRTM_CONV_PACKED_ELEMS gives the element count).
  * ktab: int32[K*3] = {ci, kh, kw} built by frtm_conv_pack_weights; may be NULL for 1x1 convs.
  * out_transposed: write out[img, pix, m] instead of out[img, m, pix].
- * splitk: 0 = auto, 1 = none, >1: partial sums go through `workspace` (>= splitk*Cout*B*Ho*Wo floats;
- *         FRTM_CONV_MAX_SPLITK bounds the auto choice) and a second kernel applies the epilogue.
+ * splitk: 0 = auto, 1 = none, >1: partial sums go through `workspace` (splitk*Cout*B*Ho*Wo floats; the factor is clamped
+ *         to desc.ws_elems and to FRTM_CONV_MAX_SPLITK) and a second kernel applies the epilogue.
  * The init-problem weight gradient g1[c,ci] = sum_{img,pix} D[img,pix,c] * X[img,pix,ci] is the same
  * call with B=1, Cin = n_img*h*w, "pixels" = ci, wT = D (pixel-major) and in = X in NHWC.
  * ------------------------------------------------------------------------------------------ */
@@ -149,6 +149,7 @@ typedef struct {
   int splitk;              /* 0 = auto */
   int tile;                /* 0 = auto, else FRTM_TILE_* */
   int w_layout;            /* FRTM_WLAYOUT_GEMM (0) or FRTM_WLAYOUT_HALO3X3 (3x3, stride 1 or 2, pad 1 only) */
+  int ws_elems;            /* capacity of `workspace` in floats (0 = no workspace: split-K is disabled); split-K is clamped to it */
   int w_pitch;             /* 0: wT is the padded [Kp][Mp] image of frtm_conv_pack_weights;
                               >0: wT is a plain [K][w_pitch] matrix (w_pitch >= Cout, multiple of 4, 16-byte aligned) */
 } frtm_conv_desc;
