@@ -1,0 +1,28 @@
+"""The trunk alone, exactly as bench.py drives it (RN101, 480x854, 4 frames per pass): HIP-event timing per pass and, under
+`rocprofv3 --kernel-trace --stats`, a kernel trace that contains nothing but trunk kernels -- the one-to-one cross-check of
+bench.py's roofline.per_launch numbers (sum of conv-family kernel durations / conv launches)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+ext = ResnetFeatureExtractor('resnet101').to('cuda:0')
+ext.reuse_outputs = True
+img = torch.randint(0, 256, (B, 3, 480, 854), dtype=torch.uint8, device='cuda:0')
+for _ in range(3):
+    ext(img)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+N = 20
+e0.record()
+for _ in range(N):
+    ext(img)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / N
+print('trunk pass B=%d: %.3f ms, %.1f GFLOP, %.1f TFLOP/s, %d conv launches, %.1f us per conv launch' %
+      (B, ms, ext.last_flops / 1e9, ext.last_flops / ms / 1e9, ext.last_conv_launches, 1e3 * ms / ext.last_conv_launches))
