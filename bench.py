@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--trunk-batch', type=int, default=4, help='frames per trunk pass (1 = frame by frame like the reference)')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--cpu-frames', type=int, default=24)
     ap.add_argument('--overlap', action='store_true', help='run the next trunk batch on a side stream, overlapped with tracking')
     ap.add_argument('--memory', type=int, default=80, help='target-model memory slots (80 = evaluate.py:80)')
@@ -284,7 +285,7 @@ def main():
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'host_enqueue_ms_per_step': 1e3 * t_host / n,
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_cg_roofline:
         out['roofline_cg'] = cg_roofline(dev, size)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, size, args.cpu_frames)

@@ -512,3 +512,21 @@ def test_run_sequence_label_decoding():
             assert lb.dtype == torch.uint8 and lb.shape[-2:] == (96, 128)
             assert set(lb.unique().tolist()) <= set(range(n_obj + 1))
         assert torch.equal(labels[0].reshape(96, 128), seq.gt[0].reshape(96, 128))       # frame 0 = the given labels
+
+
+def test_run_dataset_writes_label_pngs(tmp_path):
+    """Tracker.run_dataset (reference tracker.py:68-101): per-sequence output directories with one palette PNG per frame."""
+    from PIL import Image
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticDataset, SyntheticSequence
+    params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18')
+    params.disc_params.update(memory_size=6, init_iters=(2, 2), update_iters=(2,))
+    trk = params.get_model().eval()
+    dset = SyntheticDataset('synth', [SyntheticSequence('a', 4, (64, 96), 1, seed=1), SyntheticSequence('b', 5, (64, 96), 2, seed=2)])
+    fps = trk.run_dataset(dset, tmp_path / 'out')
+    assert fps > 0
+    for name, n in (('a', 4), ('b', 5)):
+        files = sorted((tmp_path / 'out' / name).glob('*.png'))
+        assert len(files) == n
+        im = Image.open(files[-1])
+        assert im.mode == 'P' and im.size == (96, 64)
