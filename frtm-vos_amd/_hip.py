@@ -50,6 +50,8 @@ SIGNATURES = {
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_last_flops': (D, [P]),
     'frtm_backbone_last_conv_launches': (I, [P]),
+    'frtm_backbone_set_lanes': (I, [P, I]),
+    'frtm_backbone_generation': (I, [P]),
     'frtm_merge_masks': (I, [P, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),
     'frtm_bilinear_resize': (I, [P, I, I, I, P, I, I, P]),

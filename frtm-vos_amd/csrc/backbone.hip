@@ -17,18 +17,28 @@ struct ConvL {
 };
 struct BlockL { int conv[3]; int nconv; int ds; };   // conv indices (ds = -1: identity shortcut)
 
+// A lane is one independent sub-batch of a forward call: its own activation arena, split-K workspace and (for lanes > 0
+// of a multi-lane pass) its own stream.  Frames do not depend on each other, so the lanes' kernels run concurrently and the
+// tail of one lane's kernel (the last, partly filled round of workgroups) is covered by the other lanes' kernels.
+struct Lane {
+  float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t buf_elems = 0;
+  float* ws = nullptr; size_t ws_elems = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
+
 struct frtm_backbone {
   int arch = 0;
   bool bottleneck = false;
   std::vector<ConvL> convs;
   std::vector<std::vector<BlockL>> stages;   // 4 stages
-  // activation arena
-  float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t buf_elems = 0;
-  float* ws = nullptr; size_t ws_elems = 0;
-  float* pack_tmp = nullptr; size_t pack_tmp_elems = 0;
+  std::vector<Lane> lanes = std::vector<Lane>(1);
+  int nlanes = 1;
+  hipEvent_t fork = nullptr;
   double last_flops = 0.0;
   int last_launches = 0;
+  int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
 __global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __restrict__ img, int HW, const float* __restrict__ sc,
@@ -69,8 +79,9 @@ static int add_conv(frtm_backbone* bb, int Cout, int Cin, int ks, int stride) {
   return (int)bb->convs.size() - 1;
 }
 
-static int ensure(float** p, size_t* have, size_t need) {
+static int ensure(frtm_backbone* bb, float** p, size_t* have, size_t need) {
   if (*have >= need) return FRTM_OK;
+  bb->generation += 1;
   if (*p) FRTM_HIP(hipFree(*p));
   *p = nullptr; *have = 0;
   FRTM_HIP(hipMalloc((void**)p, need * sizeof(float)));
@@ -78,8 +89,8 @@ static int ensure(float** p, size_t* have, size_t need) {
   return FRTM_OK;
 }
 
-static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const float* in, const float* residual, int relu, float* out,
-                    int* Ho, int* Wo, hipStream_t st) {
+static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Win, const float* in, const float* residual, int relu,
+                    float* out, int* Ho, int* Wo, hipStream_t st) {
   ConvL& c = bb->convs[idx];
   if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
   frtm_conv_desc d;
@@ -92,13 +103,91 @@ static int run_conv(frtm_backbone* bb, int idx, int B, int Hin, int Win, const f
   {
     const size_t out_elems = (size_t)c.Cout * B * (*Ho) * (*Wo);
     const size_t w = std::min((size_t)FRTM_CONV_MAX_SPLITK * out_elems, (size_t)16 * 1024 * 1024);
-    int rc = ensure(&bb->ws, &bb->ws_elems, std::max(w, out_elems * 2));
+    int rc = ensure(bb, &ln.ws, &ln.ws_elems, std::max(w, out_elems * 2));
     if (rc) return rc;
   }
-  d.ws_elems = (int)std::min<size_t>(bb->ws_elems, 0x7fffffff);
+  d.ws_elems = (int)std::min<size_t>(ln.ws_elems, 0x7fffffff);
   bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
-  return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, bb->ws, st);
+  return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
+}
+
+// One sub-batch through the trunk on one stream (reference feature_extractor.py:40-68).
+static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
+                        const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
+                        int stop_after_layer, hipStream_t st) {
+  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
+  // arena element count = the largest activation of the pass (stem output, or a stage output when the
+  // frame size is odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2))
+  size_t need = (size_t)B * 64 * Hs * Ws;
+  {
+    int ah = (Hs + 1) / 2, aw = (Ws + 1) / 2;
+    const int exp = bb->bottleneck ? 4 : 1;
+    for (int s = 0; s < 4; ++s) {
+      if (s > 0) { ah = (ah + 1) / 2; aw = (aw + 1) / 2; }
+      need = max(need, (size_t)B * (64 << s) * exp * ah * aw);
+      need = max(need, (size_t)B * (64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
+    }
+    need = max(need, (size_t)B * 3 * H * W);
+  }
+  if (ln.buf_elems < need) {
+    bb->generation += 1;
+    for (auto& b : ln.buf) {
+      if (b) FRTM_HIP(hipFree(b));
+      b = nullptr;
+      FRTM_HIP(hipMalloc((void**)&b, need * sizeof(float)));
+    }
+    ln.buf_elems = need;
+  }
+  float* norm = ln.buf[0];
+  const size_t npx = (size_t)B * 3 * H * W;
+  k_normalize_u8<<<(int)min((npx + 255) / 256, (size_t)4096), 256, 0, st>>>(image_u8, H * W, norm_scale3, norm_bias3, norm, npx);
+  FRTM_LAUNCH_CHECK();
+  int h1, w1;
+  int rc = run_conv(bb, ln, 0, B, H, W, norm, nullptr, 1, ln.buf[1], &h1, &w1, st);   // conv1 + bn1 + relu
+  if (rc) return rc;
+  const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
+  float* x = layer1 ? layer1 : ln.buf[2];
+  const size_t np = (size_t)B * 64 * Hp * Wp;
+  k_maxpool3s2<<<(int)min((np + 255) / 256, (size_t)4096), 256, 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x, np);
+  FRTM_LAUNCH_CHECK();
+  int ch = Hp, cw = Wp;
+  float* taps[4] = {layer2, layer3, layer4, layer5};
+  // scratch rotation: x lives in buf[2] or buf[3] (or a tap); t1,t2,t3 in buf[0],buf[1],buf[4]; buf[5] spare
+  for (int s = 0; s < 4 && (s + 2) <= stop_after_layer; ++s) {
+    const auto& blocks = bb->stages[s];
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const BlockL& bl = blocks[b];
+      const bool last = (b + 1 == blocks.size());
+      float* outp = (last && taps[s]) ? taps[s] : ((x == ln.buf[2]) ? ln.buf[3] : ln.buf[2]);
+      float* t1 = ln.buf[0];
+      float* t2 = ln.buf[1];
+      float* t3 = ln.buf[4];
+      int ho, wo, h2, w2, hd, wd;
+      const float* idn = x;
+      if (bl.ds >= 0) {
+        rc = run_conv(bb, ln, bl.ds, B, ch, cw, x, nullptr, 0, t3, &hd, &wd, st);
+        if (rc) return rc;
+        idn = t3;
+      }
+      if (bl.nconv == 3) {
+        rc = run_conv(bb, ln, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &ho, &wo, st);
+        if (rc) return rc;
+        rc = run_conv(bb, ln, bl.conv[1], B, ho, wo, t1, nullptr, 1, t2, &h2, &w2, st);
+        if (rc) return rc;
+        rc = run_conv(bb, ln, bl.conv[2], B, h2, w2, t2, idn, 1, outp, &ho, &wo, st);
+        if (rc) return rc;
+      } else {
+        rc = run_conv(bb, ln, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &h2, &w2, st);
+        if (rc) return rc;
+        rc = run_conv(bb, ln, bl.conv[1], B, h2, w2, t1, idn, 1, outp, &ho, &wo, st);
+        if (rc) return rc;
+      }
+      ch = ho; cw = wo;
+      x = outp;
+    }
+  }
+  return FRTM_OK;
 }
 
 extern "C" {
@@ -153,9 +242,13 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
     if (c.shift) (void)hipFree(c.shift);
     if (c.ktab) (void)hipFree(c.ktab);
   }
-  for (auto& b : bb->buf) if (b) (void)hipFree(b);
-  if (bb->ws) (void)hipFree(bb->ws);
-  if (bb->pack_tmp) (void)hipFree(bb->pack_tmp);
+  for (auto& ln : bb->lanes) {
+    for (auto& b : ln.buf) if (b) (void)hipFree(b);
+    if (ln.ws) (void)hipFree(ln.ws);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+  }
+  if (bb->fork) (void)hipEventDestroy(bb->fork);
   delete bb;
   return FRTM_OK;
 }
@@ -193,6 +286,20 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
+int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->generation : 0; }
+
+int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
+  FRTM_CHECK_ARG(bb && lanes >= 1 && lanes <= 8, "frtm_backbone_set_lanes: lanes must be 1..8");
+  if ((int)bb->lanes.size() < lanes) bb->lanes.resize(lanes);
+  for (int l = 1; l < lanes; ++l) {
+    Lane& ln = bb->lanes[l];
+    if (!ln.stream) FRTM_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    if (!ln.done) FRTM_HIP(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+  }
+  if (!bb->fork) FRTM_HIP(hipEventCreateWithFlags(&bb->fork, hipEventDisableTiming));
+  bb->nlanes = lanes;
+  return FRTM_OK;
+}
 
 int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                           const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
@@ -200,78 +307,38 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   FRTM_CHECK_ARG(bb && image_u8 && norm_scale3 && norm_bias3 && B > 0 && H >= 32 && W >= 32, "frtm_backbone_forward: bad argument");
   FRTM_CHECK_ARG(stop_after_layer >= 1 && stop_after_layer <= 5, "frtm_backbone_forward: stop_after_layer must be 1..5");
   hipStream_t st = (hipStream_t)stream;
-  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
-  // arena element count = the largest activation of the pass (stem output, or a stage output when the
-  // frame size is odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2))
-  size_t need = (size_t)B * 64 * Hs * Ws;
-  {
-    int ah = (Hs + 1) / 2, aw = (Ws + 1) / 2;
-    const int exp = bb->bottleneck ? 4 : 1;
-    for (int s = 0; s < 4; ++s) {
-      if (s > 0) { ah = (ah + 1) / 2; aw = (aw + 1) / 2; }
-      need = max(need, (size_t)B * (64 << s) * exp * ah * aw);
-      need = max(need, (size_t)B * (64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
-    }
-    need = max(need, (size_t)B * 3 * H * W);
-  }
-  if (bb->buf_elems < need) {
-    for (auto& b : bb->buf) {
-      if (b) FRTM_HIP(hipFree(b));
-      b = nullptr;
-      FRTM_HIP(hipMalloc((void**)&b, need * sizeof(float)));
-    }
-    bb->buf_elems = need;
-  }
   bb->last_flops = 0.0;
   bb->last_launches = 0;
-  float* norm = bb->buf[0];
-  const size_t npx = (size_t)B * 3 * H * W;
-  k_normalize_u8<<<(int)min((npx + 255) / 256, (size_t)4096), 256, 0, st>>>(image_u8, H * W, norm_scale3, norm_bias3, norm, npx);
-  FRTM_LAUNCH_CHECK();
-  int h1, w1;
-  int rc = run_conv(bb, 0, B, H, W, norm, nullptr, 1, bb->buf[1], &h1, &w1, st);   // conv1 + bn1 + relu
-  if (rc) return rc;
-  const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
-  float* x = layer1 ? layer1 : bb->buf[2];
-  const size_t np = (size_t)B * 64 * Hp * Wp;
-  k_maxpool3s2<<<(int)min((np + 255) / 256, (size_t)4096), 256, 0, st>>>(bb->buf[1], h1, w1, Hp, Wp, x, np);
-  FRTM_LAUNCH_CHECK();
-  int ch = Hp, cw = Wp;
-  float* taps[4] = {layer2, layer3, layer4, layer5};
-  // scratch rotation: x lives in buf[2] or buf[3] (or a tap); t1,t2,t3 in buf[0],buf[1],buf[4]; buf[5] spare
-  for (int s = 0; s < 4 && (s + 2) <= stop_after_layer; ++s) {
-    const auto& blocks = bb->stages[s];
-    for (size_t b = 0; b < blocks.size(); ++b) {
-      const BlockL& bl = blocks[b];
-      const bool last = (b + 1 == blocks.size());
-      float* outp = (last && taps[s]) ? taps[s] : ((x == bb->buf[2]) ? bb->buf[3] : bb->buf[2]);
-      float* t1 = bb->buf[0];
-      float* t2 = bb->buf[1];
-      float* t3 = bb->buf[4];
-      int ho, wo, h2, w2, hd, wd;
-      const float* idn = x;
-      if (bl.ds >= 0) {
-        rc = run_conv(bb, bl.ds, B, ch, cw, x, nullptr, 0, t3, &hd, &wd, st);
-        if (rc) return rc;
-        idn = t3;
-      }
-      if (bl.nconv == 3) {
-        rc = run_conv(bb, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &ho, &wo, st);
-        if (rc) return rc;
-        rc = run_conv(bb, bl.conv[1], B, ho, wo, t1, nullptr, 1, t2, &h2, &w2, st);
-        if (rc) return rc;
-        rc = run_conv(bb, bl.conv[2], B, h2, w2, t2, idn, 1, outp, &ho, &wo, st);
-        if (rc) return rc;
-      } else {
-        rc = run_conv(bb, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &h2, &w2, st);
-        if (rc) return rc;
-        rc = run_conv(bb, bl.conv[1], B, h2, w2, t1, idn, 1, outp, &ho, &wo, st);
-        if (rc) return rc;
-      }
-      ch = ho; cw = wo;
-      x = outp;
-    }
+  const int L = std::min(bb->nlanes, B);
+  if (L == 1) return forward_lane(bb, bb->lanes[0], image_u8, B, H, W, norm_scale3, norm_bias3, layer1, layer2, layer3, layer4, layer5,
+                                  stop_after_layer, st);
+  // tap geometry (per image element counts) for the per-lane slices of the batched outputs
+  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
+  int th = (Hs + 1) / 2, tw = (Ws + 1) / 2;
+  const int exp = bb->bottleneck ? 4 : 1;
+  size_t per_img[5];
+  per_img[0] = (size_t)64 * th * tw;
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) { th = (th + 1) / 2; tw = (tw + 1) / 2; }
+    per_img[s + 1] = (size_t)(64 << s) * exp * th * tw;
   }
+  float* taps[5] = {layer1, layer2, layer3, layer4, layer5};
+  FRTM_HIP(hipEventRecord(bb->fork, st));
+  int b0 = 0;
+  for (int l = 0; l < L; ++l) {
+    Lane& ln = bb->lanes[l];
+    const int Bl = B / L + (l < B % L ? 1 : 0);
+    hipStream_t ls = (l == 0) ? st : ln.stream;              // lane 0 stays on the caller's stream
+    if (l > 0) FRTM_HIP(hipStreamWaitEvent(ls, bb->fork, 0));
+    float* tl[5];
+    for (int t = 0; t < 5; ++t) tl[t] = taps[t] ? taps[t] + (size_t)b0 * per_img[t] : nullptr;
+    int rc = forward_lane(bb, ln, image_u8 + (size_t)b0 * 3 * H * W, Bl, H, W, norm_scale3, norm_bias3, tl[0], tl[1], tl[2], tl[3], tl[4],
+                          stop_after_layer, ls);
+    if (rc) return rc;
+    if (l > 0) FRTM_HIP(hipEventRecord(ln.done, ls));
+    b0 += Bl;
+  }
+  for (int l = 1; l < L; ++l) FRTM_HIP(hipStreamWaitEvent(st, bb->lanes[l].done, 0));
   return FRTM_OK;
 }
 

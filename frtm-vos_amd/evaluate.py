@@ -20,9 +20,10 @@ class AttrDict(dict):
 
 class Parameters:
 
-    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=4):
+    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=8, trunk_lanes=2):
         self.device = device
         self.feature_batch = feature_batch
+        self.trunk_lanes = trunk_lanes
         self.weights = weights
         self.num_aug = 5
         self.train_skipping = 8
@@ -71,7 +72,8 @@ class Parameters:
         if self.weights is None:
             torch.manual_seed(1)                                   # seeded default init
             refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
-        mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device, feature_batch=self.feature_batch)
+        mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device, feature_batch=self.feature_batch,
+                      trunk_lanes=self.trunk_lanes)
         if self.weights is not None:
             mdl.load_state_dict(self.weights)
         mdl.to(self.device)

@@ -142,7 +142,25 @@ class ResnetFeatureExtractor:
         self.last_conv_launches = 0
         self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
         self._out_cache = {}
+        self._out_bufs = {}
+        self._buf_serial = 0
         self.output_set = 0            # which persistent tap set to write (double buffering for the prefetch stream)
+        self._lanes = 1
+        self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
+
+    @property
+    def lanes(self):
+        """Number of concurrent sub-batches of a batched call (frtm_backbone_set_lanes); results do not depend on it."""
+        return self._lanes
+
+    @lanes.setter
+    def lanes(self, n):
+        n = int(n)
+        if self._handle is not None:
+            H.call_nostream('frtm_backbone_set_lanes', self._handle, n)
+        elif not 1 <= n <= 8:
+            raise ValueError('lanes must be 1..8')
+        self._lanes = n
 
     def __del__(self):
         try:
@@ -171,6 +189,7 @@ class ResnetFeatureExtractor:
                 h = ctypes.c_void_p()
                 H.call_nostream('frtm_backbone_create', self.arch, ctypes.byref(h))
                 self._handle = h
+                H.call_nostream('frtm_backbone_set_lanes', h, self._lanes)
             pairs = self.resnet.conv_bn_pairs()
             assert L.frtm_backbone_num_convs(self._handle) == len(pairs)
             info = (ctypes.c_int * 6)()
@@ -204,19 +223,51 @@ class ResnetFeatureExtractor:
             if i > 0:
                 ch, cw = (ch + 1) // 2, (cw + 1) // 2
             dims[L] = (self._out_channels[L], ch, cw)
-        if self.reuse_outputs:
-            key = (B, Hh, Ww, tuple(want), self.output_set)
-            out = self._out_cache.get(key)
-            if out is None:
-                out = self._out_cache[key] = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
-        else:
+        args = (B, Hh, Ww, H.ptr(self.norm_weight), H.ptr(self.norm_bias))
+        if not self.reuse_outputs:
             out = {L: torch.empty((B,) + dims[L], device=self.device) for L in want}
+            self._forward(x, out, args, stop)
+            return out
+        # persistent taps: one allocation per (size, tap set) with room for the largest batch seen; smaller batches (the
+        # last pass of a sequence) write a prefix of it, so consumers keyed by tap addresses (the refiner's graphs) stay valid
+        okey = (Hh, Ww, tuple(want), self.output_set)
+        buf = self._out_bufs.get(okey)
+        if buf is None or buf['cap'] < B:
+            self._buf_serial += 1
+            buf = self._out_bufs[okey] = dict(cap=B, serial=self._buf_serial,
+                                              t={L: torch.empty((B,) + dims[L], device=self.device) for L in want})
+        key = (B, okey, buf['serial'])
+        ent = self._out_cache.get(key)
+        if ent is None:
+            if len(self._out_cache) > 64:
+                self._out_cache.clear()
+            ent = self._out_cache[key] = dict(out={L: t[:B] for L, t in buf['t'].items()}, graph=None)
+            self._forward(x, ent['out'], args, stop)           # first call of a shape: eager (allocates arenas / workspaces)
+            ent['stats'] = (self.last_flops, self.last_conv_launches)
+            return ent['out']
+        gen = H.lib().frtm_backbone_generation(self._handle)
+        if self.use_graph and (ent['graph'] is None or ent['gen'] != gen):
+            # one hipGraph per shape: ~105 launches per lane become one host call, the lanes stay parallel branches
+            ent['in'] = x.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._forward(ent['in'], ent['out'], args, stop)
+            ent['stats'] = (self.last_flops, self.last_conv_launches)
+            ent['graph'], ent['gen'] = g, gen
+        if self.use_graph:
+            ent['in'].copy_(x)
+            ent['graph'].replay()
+            self.last_flops, self.last_conv_launches = ent['stats']
+        else:
+            self._forward(x, ent['out'], args, stop)
+        return ent['out']
+
+    def _forward(self, x, out, args, stop):
         ptrs = [H.ptr(out.get(L)) for L in ('layer1', 'layer2', 'layer3', 'layer4', 'layer5')]
-        H.call('frtm_backbone_forward', self._handle, H.ptr(x), B, Hh, Ww, H.ptr(self.norm_weight), H.ptr(self.norm_bias),
-               *ptrs, stop)
+        H.call('frtm_backbone_forward', self._handle, H.ptr(x), *args, *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
         self.last_conv_launches = H.lib().frtm_backbone_last_conv_launches(self._handle)
-        return out
 
     def get_out_channels(self):
         return self._out_channels

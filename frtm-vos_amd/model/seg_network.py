@@ -138,6 +138,8 @@ class SegNetwork(nn.Module):
         self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
         self._graphs = {}
         self._pack_key = None
+        self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
+        self._side = None
 
     def invalidate(self):
         """Drop the packed HIP weights and captured graphs (call after editing parameters in place)."""
@@ -195,9 +197,11 @@ class SegNetwork(nn.Module):
             static_scores = scores.clone()
             self._forward_hip(static_scores, features, image_size)          # warm-up outside capture (allocator, workspaces)
             torch.cuda.synchronize()
+            if self.parallel_levels and self._side is None:
+                self._side = [torch.cuda.Stream(device=scores.device) for _ in range(len(self.ft_channels) - 1)]
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._forward_hip(static_scores, features, image_size)
+                out = self._forward_hip(static_scores, features, image_size, self._side if self.parallel_levels else None)
             entry = self._graphs[key] = (g, static_scores, out, [features[L] for L in self.ft_channels])
         g, static_scores, out, _keepalive = entry
         static_scores.copy_(scores)
@@ -266,26 +270,53 @@ class SegNetwork(nn.Module):
         H.call('frtm_plane_mean', H.ptr(x), n * c, hh * ww, H.ptr(out))
         return out
 
-    def _forward_hip(self, scores, features, image_size):
+    def _branch(self, L, p, ft, scores, deepest):
+        """Everything of one pyramid level that does not need the deeper level's output: TSE (reduce shared by all objects,
+        score channel injected into transform[0]) and RRB1 (reference seg_network.py:168-171) + the CAB's shallow pool."""
+        n, _, sh, sw = scores.shape
+        Hh, Ww = ft.shape[-2:]
+        h = self._conv(self._conv(ft, p['r0']), p['r2'])                       # TSE.reduce, shared by all objects
+        pool0 = self._mean(h) if deepest else None                             # (1,oc): deeper input of the deepest CAB
+        base = self._conv(h, p['base'])                                        # object-independent part of transform[0]
+        C0 = p['base']['cout']
+        t0 = torch.empty(n, C0, Hh, Ww, device=scores.device)
+        H.call('frtm_tse_inject', H.ptr(base), H.ptr(p['b0']), H.ptr(p['ws']), H.ptr(scores), n, C0, sh, sw, Hh, Ww, H.ptr(t0))
+        t = self._conv(self._conv(t0, p['t2']), p['t4'])
+        r = self._rrb_hip(t, p['rrb1'])
+        return r, self._mean(r), pool0, (h, base, t0, t)
+
+    def _forward_hip(self, scores, features, image_size, side_streams=None):
+        """side_streams: optional list of torch streams (one per pyramid level but the last).  The per-level branches do not
+        depend on each other -- only the CAB / RRB2 tail chains the levels, deep to shallow -- so they run concurrently and
+        the small deep-level kernels (15x27, 30x54: a few workgroups each) hide under the 120x214 level.  Used under hipGraph
+        capture, where the fork/join becomes parallel graph branches; intermediates are kept alive until the end so that the
+        allocator cannot hand a block to another stream inside the same pass."""
         P = self._packed()
         scores = scores.float().contiguous()
-        n, _, sh, sw = scores.shape
+        n = scores.shape[0]
         dev = scores.device
-        x, pool0 = None, None
-        for L in self.ft_channels:
-            p = P[L]
+        levels = list(self.ft_channels)
+        cur = torch.cuda.current_stream()
+        keep, br = [], {}
+        for st in (side_streams or []):
+            st.wait_stream(cur)                                 # fork point: everything enqueued so far (scores, taps)
+        for i, L in enumerate(levels):
             ft = features[L].contiguous()
-            Hh, Ww = ft.shape[-2:]
-            h = self._conv(self._conv(ft, p['r0']), p['r2'])                       # TSE.reduce, shared by all objects
-            if x is None:
-                pool0 = self._mean(h)                                            # (1,oc): deeper input of the deepest CAB
-            base = self._conv(h, p['base'])                                      # object-independent part of transform[0]
-            C0 = p['base']['cout']
-            t0 = torch.empty(n, C0, Hh, Ww, device=dev)
-            H.call('frtm_tse_inject', H.ptr(base), H.ptr(p['b0']), H.ptr(p['ws']), H.ptr(scores), n, C0, sh, sw, Hh, Ww, H.ptr(t0))
-            t = self._conv(self._conv(t0, p['t2']), p['t4'])
-            r = self._rrb_hip(t, p['rrb1'])
-            sp = self._mean(r)
+            st = side_streams[i] if (side_streams and i < len(side_streams)) else None
+            if st is None:
+                br[L] = self._branch(L, P[L], ft, scores, i == 0)
+            else:
+                with torch.cuda.stream(st):
+                    br[L] = self._branch(L, P[L], ft, scores, i == 0)
+        x, pool0 = None, br[levels[0]][2]
+        for i, L in enumerate(levels):
+            p = P[L]
+            st = side_streams[i] if (side_streams and i < len(side_streams)) else None
+            if st is not None:
+                cur.wait_stream(st)
+            r, sp, _, tmp = br[L]
+            keep.append(tmp)
+            Hh, Ww = r.shape[-2:]
             dp = pool0.expand(n, -1) if x is None else self._mean(x)
             gate = torch.addmm(p['cab_b2'], torch.relu(torch.addmm(p['cab_b1'], torch.cat((sp, dp), 1), p['cab_w1'])), p['cab_w2']).contiguous()
             out = torch.empty_like(r)
@@ -293,6 +324,7 @@ class SegNetwork(nn.Module):
                 H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(pool0), n, r.shape[1], 1, 1, 1, Hh, Ww, H.ptr(out))
             else:
                 H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(x), n, r.shape[1], x.shape[2], x.shape[3], 0, Hh, Ww, H.ptr(out))
+            keep.append((x, gate, out, dp))
             x = self._rrb_hip(out, p['rrb2'])
         pj = P['project']
         c, hh, ww = x.shape[1:]

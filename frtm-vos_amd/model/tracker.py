@@ -8,9 +8,10 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
    computed once per frame;
  * merge (clamp / background / soft-max / arg-max, tracker.py:214-221) is one HIP kernel, in place;
  * the trunk does not depend on tracking state, so ``run_sequence`` feeds it ``feature_batch`` pre-loaded frames at a time
-   (default 4): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs (47 TFLOP/s, many split-K convs), at batch 4 they
-   do (~70 TFLOP/s, no split-K).  Per-frame results are unchanged up to fp32 summation order; ``track(image)`` without
-   pre-computed features still works frame by frame;
+   (default 8, as ``trunk_lanes`` = 2 concurrent sub-batches of 4): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs
+   (47 TFLOP/s, many split-K convs), at batch 4 they do (80 TFLOP/s, no split-K), and two sub-batches on two streams cover
+   each other's kernel tails (the last, partly filled round of workgroups of every launch): 95 TFLOP/s.  Per-frame results
+   are unchanged up to fp32 summation order; ``track(image)`` without pre-computed features still works frame by frame;
  * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for all objects by
    one kernel; on frames without a filter re-solve it guards the memory insert on the device (no host sync at all), on
    re-solve frames (every 8th) ONE small device->host copy serves all objects.
@@ -48,9 +49,11 @@ class TargetObject:
 
 class Tracker(nn.Module):
 
-    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=4):
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=8, trunk_lanes=2):
         super().__init__()
         self.feature_batch = feature_batch
+        self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
+        self.graph_trunk = True
         self.graph_refiner = True
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
         self.augmenter = augmenter
@@ -151,6 +154,8 @@ class Tracker(nn.Module):
         persistent = hasattr(ext, 'reuse_outputs')
         if persistent:
             ext.reuse_outputs = True
+            ext.lanes = max(1, min(int(self.trunk_lanes), fb))
+            ext.use_graph = self.graph_trunk
             if hasattr(self.refiner, 'use_graphs'):
                 self.refiner.use_graphs = self.graph_refiner
         side = torch.cuda.Stream(device=self.device) if (persistent and self.prefetch_stream and torch.cuda.is_available()) else None

@@ -10,11 +10,13 @@ _workspaces = {}
 
 
 def workspace(device, elems):
-    """Grow-only fp32 scratch per device (split-K partials)."""
-    w = _workspaces.get(device)
+    """Grow-only fp32 scratch (split-K partials) per device AND stream: convs enqueued on different streams may run
+    concurrently and must not share partial sums."""
+    key = (device, H.stream())
+    w = _workspaces.get(key)
     if w is None or w.numel() < elems:
         w = torch.empty(int(elems), device=device, dtype=torch.float32)
-        _workspaces[device] = w
+        _workspaces[key] = w
     return w
 
 

@@ -197,6 +197,16 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* Number of convolutions (k_conv_igemm launches) of the last forward() call. */
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb);
+/* Concurrency of forward(): a batch of B frames is split into min(lanes, B) sub-batches that run on the caller's stream
+ * (lane 0) and on internal streams (lanes 1..), forked from / joined back to the caller's stream with events, so that the
+ * call still behaves as one in-order operation on `stream`.  Frames are independent (feature_extractor.py:40-68), results
+ * do not depend on the lane count.  lanes = 1 (default): everything on the caller's stream.  1 <= lanes <= 8. */
+int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes);
+/* forward() allocates its activation arenas / split-K workspaces on first use and grows them (hipFree + hipMalloc, which
+ * synchronises) when a larger batch or frame size arrives.  The counter returned here is bumped by every such
+ * (re)allocation: a caller that captured forward() into a hipGraph must re-capture when it has changed, and must run a
+ * shape once eagerly before capturing it (allocation is not allowed during stream capture). */
+int frtm_backbone_generation(const frtm_backbone_t* bb);
 
 /* ------------------------------------------------------------------------------------------
  * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).

@@ -19,18 +19,23 @@ scores = torch.randn(n, 1, 30, 54, device='cuda')
 for _ in range(3):
     out = net(scores, feats, (480, 854))
 torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
-    out = net._forward_hip(scores, feats, (480, 854))
-g.replay()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
+ref = net._forward_hip(scores, feats, (480, 854)).clone()
+for par in (False, True):
+    side = [torch.cuda.Stream() for _ in range(3)] if par else None
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = net._forward_hip(scores, feats, (480, 854), side)
     g.replay()
-e1.record()
-torch.cuda.synchronize()
-print('refiner n=%d: %.3f ms per pass (graph replay)' % (n, e0.elapsed_time(e1) / 20))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    print('refiner n=%d parallel_levels=%d: %.3f ms per pass (graph replay), max |diff| vs eager %.2e' %
+          (n, par, e0.elapsed_time(e1) / 20, float((out - ref).abs().max())))
 for _ in range(10):          # eager launches so that a kernel trace attributes them
     net._forward_hip(scores, feats, (480, 854))
 torch.cuda.synchronize()

@@ -10,8 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+LANES = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ext = ResnetFeatureExtractor('resnet101').to('cuda:0')
 ext.reuse_outputs = True
+ext.lanes = LANES
+ext.use_graph = len(sys.argv) > 3 and sys.argv[3] == 'graph'
 img = torch.randint(0, 256, (B, 3, 480, 854), dtype=torch.uint8, device='cuda:0')
 for _ in range(3):
     ext(img)
@@ -24,5 +27,5 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / N
-print('trunk pass B=%d: %.3f ms, %.1f GFLOP, %.1f TFLOP/s, %d conv launches, %.1f us per conv launch' %
-      (B, ms, ext.last_flops / 1e9, ext.last_flops / ms / 1e9, ext.last_conv_launches, 1e3 * ms / ext.last_conv_launches))
+print('trunk pass B=%d lanes=%d graph=%d: %.3f ms, %.1f GFLOP, %.1f TFLOP/s, %d conv launches, %.1f us per conv launch' %
+      (B, LANES, ext.use_graph, ms, ext.last_flops / 1e9, ext.last_flops / ms / 1e9, ext.last_conv_launches, 1e3 * ms / ext.last_conv_launches))
