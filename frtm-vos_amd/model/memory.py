@@ -50,7 +50,7 @@ class Memory:
         self.current_size = 0
         self.device = dev
         self.learning_rates = learning_rates
-        self._slot = torch.tensor([-1, -1], dtype=torch.int32, device=dev)   # {previous_replace_ind, last index}
+        self._slot = torch.full((2,), -1, dtype=torch.int32, device=dev)     # {previous_replace_ind, last index}; a fill, not a blocking H2D copy
         self._have_prev = False
         self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
 

@@ -20,8 +20,13 @@ for _ in range(3):
     out = net(scores, feats, (480, 854))
 torch.cuda.synchronize()
 ref = net._forward_hip(scores, feats, (480, 854)).clone()
-for par in (False, True):
-    side = [torch.cuda.Stream() for _ in range(3)] if par else None
+for par in (0, 3, 1, 0, 3, 1, 0, 3, 1):
+    if par == 3:
+        side = [torch.cuda.Stream() for _ in range(3)]
+    elif par == 1:
+        side = [torch.cuda.Stream()] * 3
+    else:
+        side = None
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
