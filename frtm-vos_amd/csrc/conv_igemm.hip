@@ -553,7 +553,9 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   int tile = d->tile, splitk = d->splitk;
   if (halo) {
     const int ptiles = d->B * ceil_div(p.Ho, 64 / halo_tw) * ceil_div(p.Wo, halo_tw);
-    if (tile == 0) tile = FRTM_TILE_32x64;          // measured best for the halo kernel on every trunk shape
+    // 32-row tiles measured best for the stride-1 trunk / refiner shapes; the stride-2 convs (4x the input patch per output
+    // tile) amortise the patch over 64 rows: 128->105 us (256ch, 60x107, batch 4), 133->114 us (512ch, 30x54)
+    if (tile == 0) tile = (d->stride == 2) ? FRTM_TILE_64x64 : FRTM_TILE_32x64;
     frtm_conv_plan(p.M, ptiles * 64, p.nchunks * 2, 0, &tile, &splitk);
   } else {
     frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);

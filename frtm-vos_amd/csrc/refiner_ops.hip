@@ -146,6 +146,179 @@ __global__ __launch_bounds__(256) void k_plane_mean(const float* __restrict__ in
   if (threadIdx.x == 0) out[blockIdx.x] = acc / (float)HW;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Tail of the upsampler (seg_network.py:115-119): out = conv2(interpolate(up2(y), image_size)) for the single output channel,
+// as ONE kernel.  Unfused, the 32-channel full-resolution tensor is written by the bicubic 2x, read and re-written by the
+// bilinear resize and read again by the 3x3 conv (4 x 105 MB at 480p, 2 objects); here every workgroup rebuilds the patch
+// of it that its 16x64 output tile needs in LDS, channel pair by channel pair, straight from y (26 MB):
+//   A  y patch (replicate-clamped like PyrUpBicubic2d's padding)      -> ybuf
+//   B  horizontal polyphase taps (even/odd output column)             -> hx
+//   C  vertical polyphase taps                                        -> u    (the up2 output, rows/cols the tile needs)
+//   D  ATen bilinear taps, zero outside the image (conv2 padding)     -> z
+//   E  3x3 x 1-channel conv, 4 output rows per thread, accumulated over the channels in registers
+// Same expressions as k_pyrup2x / k_bilinear_resize, so u and z are bit-identical to the unfused tensors.
+// ------------------------------------------------------------------------------------------
+#define PT_TH 16
+#define PT_TW 64
+#define PT_UR 22
+#define PT_UC 76
+#define PT_YR (PT_UR / 2 + 5)
+#define PT_YC (PT_UC / 2 + 5)
+#define PT_ZR (PT_TH + 2)
+#define PT_ZC (PT_TW + 2)
+#define PT_CG 2
+
+__device__ __forceinline__ float pyr_taps(int odd, float a, float b, float c, float d) {
+  const float E0 = -0.10546875f, E1 = 0.87890625f, E2 = 0.26171875f, E3 = -0.03515625f;
+  return odd ? E0 * a + E1 * b + E2 * c + E3 * d : E3 * a + E2 * b + E1 * c + E0 * d;
+}
+
+// Every thread keeps the same elements of each stage for all channels, so all index / tap arithmetic happens once per tile
+// (no per-element divisions inside the channel loop), and the y patch of the next channel pair is fetched into registers while
+// the current pair goes through the stages.
+__global__ __launch_bounds__(256, 4) void k_project_tail(const float* __restrict__ y, int C, int h, int w, const float* __restrict__ wgt,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int Ho, int Wo) {
+  constexpr int NY = PT_YR * PT_YC, NYL = (PT_CG * NY + 255) / 256;          // y patch elements per thread
+  constexpr int NZ = PT_ZR * PT_ZC, NZL = (NZ + 255) / 256;                  // z elements per thread (same for each channel)
+  __shared__ float ybuf[PT_CG][PT_YR][PT_YC];
+  __shared__ float ub[PT_CG][PT_UR][PT_UC];
+  __shared__ float zb[PT_CG][PT_ZR][PT_ZC + 1];
+  __shared__ int ri0[PT_ZR], ri1[PT_ZR], cj0[PT_ZC], cj1[PT_ZC];
+  __shared__ float rl0[PT_ZR], rl1[PT_ZR], cl0[PT_ZC], cl1[PT_ZC];
+  __shared__ int org[2];                                     // ur0, uc0
+  const int tid = threadIdx.x, n = blockIdx.z;
+  const int Y0 = blockIdx.y * PT_TH, X0 = blockIdx.x * PT_TW;
+  const int Hu = 2 * h, Wu = 2 * w;
+  // ---- tap tables of the z rows / columns this tile touches (-1: outside the image -> zero padding of conv2) ----
+  if (tid < PT_ZR) {
+    const int zy = Y0 - 1 + tid;
+    int i0 = -1, i1 = -1; float l0 = 0.f, l1 = 0.f;
+    if (zy >= 0 && zy < Ho) bl_taps(zy, (float)Hu / (float)Ho, Hu, i0, i1, l0, l1);
+    ri0[tid] = i0; ri1[tid] = i1; rl0[tid] = l0; rl1[tid] = l1;
+  }
+  if (tid >= 64 && tid < 64 + PT_ZC) {
+    const int j = tid - 64, zx = X0 - 1 + j;
+    int i0 = -1, i1 = -1; float l0 = 0.f, l1 = 0.f;
+    if (zx >= 0 && zx < Wo) bl_taps(zx, (float)Wu / (float)Wo, Wu, i0, i1, l0, l1);
+    cj0[j] = i0; cj1[j] = i1; cl0[j] = l0; cl1[j] = l1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int lo = 1 << 30;
+    for (int i = 0; i < PT_ZR; ++i) if (ri0[i] >= 0) lo = min(lo, ri0[i]);
+    org[0] = lo;
+    lo = 1 << 30;
+    for (int j = 0; j < PT_ZC; ++j) if (cj0[j] >= 0) lo = min(lo, cj0[j]);
+    org[1] = lo;
+  }
+  __syncthreads();
+  const int ur0 = org[0], uc0 = org[1];
+  const int yr0 = (ur0 >> 1) - 2, yc0 = (uc0 >> 1) - 2;
+  // ---- per-thread constants of each stage ----
+  // A: element e = tid + k*256 of the [PT_CG][PT_YR][PT_YC] patch -> global offset inside one channel plane (replicate clamp)
+  int a_goff[NYL], a_chan[NYL];
+#pragma unroll
+  for (int k = 0; k < NYL; ++k) {
+    const int e = tid + k * 256;
+    const int g = e / NY, r = (e - g * NY) / PT_YC, cc = e - g * NY - r * PT_YC;
+    a_chan[k] = e < PT_CG * NY ? g : -1;
+    a_goff[k] = min(max(yr0 + r, 0), h - 1) * w + min(max(yc0 + cc, 0), w - 1);
+  }
+  // BC: thread (g, j) builds column j of the up2 patch: 16 horizontal-tap values in registers, then the 22 vertical combinations
+  const int bc_g = tid / PT_UC, bc_j = tid - bc_g * PT_UC;
+  const bool bc_on = tid < PT_CG * PT_UC;
+  const int bc_odd = (uc0 + bc_j) & 1, bc_b = ((uc0 + bc_j) >> 1) - 2 + bc_odd - yc0;
+  const int par = ur0 & 1;
+  // D: z elements e = tid + k*256 (same for each channel): LDS offsets into one channel's ub plane and the four weights
+  int d_o00[NZL], d_o01[NZL], d_o10[NZL], d_o11[NZL], d_z[NZL];
+  float d_w00[NZL], d_w01[NZL], d_w10[NZL], d_w11[NZL];
+#pragma unroll
+  for (int k = 0; k < NZL; ++k) {
+    const int e = tid + k * 256;
+    const int i = e / PT_ZC, j = e - i * PT_ZC;
+    d_z[k] = e < NZ ? i * (PT_ZC + 1) + j : -1;
+    const bool ok = e < NZ && ri0[e < NZ ? i : 0] >= 0 && cj0[j] >= 0;
+    const int ii = e < NZ ? i : 0;
+    const int a0 = ok ? ri0[ii] - ur0 : 0, a1 = ok ? ri1[ii] - ur0 : 0, b0 = ok ? cj0[j] - uc0 : 0, b1 = ok ? cj1[j] - uc0 : 0;
+    d_o00[k] = a0 * PT_UC + b0; d_o01[k] = a0 * PT_UC + b1; d_o10[k] = a1 * PT_UC + b0; d_o11[k] = a1 * PT_UC + b1;
+    d_w00[k] = ok ? rl0[ii] * cl0[j] : 0.f; d_w01[k] = ok ? rl0[ii] * cl1[j] : 0.f;
+    d_w10[k] = ok ? rl1[ii] * cl0[j] : 0.f; d_w11[k] = ok ? rl1[ii] * cl1[j] : 0.f;
+  }
+  const int tx = tid & 63, ty = tid >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* yn = y + (size_t)n * C * h * w;
+  const size_t hw = (size_t)h * w;
+  float pre[NYL];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NYL; ++k) pre[k] = (a_chan[k] >= 0 && c0 + a_chan[k] < C) ? yn[(size_t)(c0 + a_chan[k]) * hw + a_goff[k]] : 0.f;
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < C; c0 += PT_CG) {
+    const int ncg = min(PT_CG, C - c0);
+    // A: registers -> ybuf, then start the next pair's loads
+#pragma unroll
+    for (int k = 0; k < NYL; ++k) if (a_chan[k] >= 0) (&ybuf[0][0][0])[tid + k * 256] = pre[k];
+    __syncthreads();
+    if (c0 + PT_CG < C) fetch(c0 + PT_CG);
+    // BC: polyphase taps, horizontal then vertical (the order of k_pyrup2x)
+    if (bc_on) {
+      float hxv[PT_YR];
+#pragma unroll
+      for (int r = 0; r < PT_YR; ++r) {
+        const float* v = &ybuf[bc_g][r][bc_b];
+        hxv[r] = pyr_taps(bc_odd, v[0], v[1], v[2], v[3]);
+      }
+      // u row ur0 + i: odd = (i + par) & 1, first hx row = ((i + par) >> 1) + odd   (relative to yr0 = (ur0 >> 1) - 2)
+      if (par == 0) {
+#pragma unroll
+        for (int i = 0; i < PT_UR; ++i) {
+          const int odd = i & 1, bb = (i >> 1) + odd;
+          ub[bc_g][i][bc_j] = pyr_taps(odd, hxv[bb], hxv[bb + 1], hxv[bb + 2], hxv[bb + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PT_UR; ++i) {
+          const int odd = (i + 1) & 1, bb = ((i + 1) >> 1) + odd;
+          ub[bc_g][i][bc_j] = pyr_taps(odd, hxv[bb], hxv[bb + 1], hxv[bb + 2], hxv[bb + 3]);
+        }
+      }
+    }
+    __syncthreads();
+    // D: bilinear taps (identity when the sizes agree: the second weights are exactly 0), zero outside the image
+#pragma unroll
+    for (int g = 0; g < PT_CG; ++g) {
+      const float* up = &ub[g][0][0];
+#pragma unroll
+      for (int k = 0; k < NZL; ++k)
+        if (d_z[k] >= 0)
+          (&zb[g][0][0])[d_z[k]] = d_w00[k] * up[d_o00[k]] + d_w01[k] * up[d_o01[k]] + d_w10[k] * up[d_o10[k]] + d_w11[k] * up[d_o11[k]];
+    }
+    __syncthreads();
+    // E: 3x3 conv, output rows ty*4 .. ty*4+3 at column tx
+    for (int g = 0; g < ncg; ++g) {
+      const float* f = wgt + (c0 + g) * 9;
+      float zz[6][3];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) zz[r][d] = zb[g][ty * 4 + r][tx + d];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[o] += zz[o + k / 3][k % 3] * f[k];
+    }
+    // next iteration: ybuf is rewritten after BC's barrier above; ub after the next A barrier; zb after two more barriers
+  }
+  const float b = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const int yy = Y0 + ty * 4 + o, xx = X0 + tx;
+    if (yy < Ho && xx < Wo) out[((size_t)n * Ho + yy) * Wo + xx] = acc[o] + b;
+  }
+}
+
 extern "C" {
 
 int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream) {
@@ -180,6 +353,19 @@ int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_str
   FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0, "frtm_pyrup2x: bad argument");
   const size_t quads = (size_t)planes * h * w;
   k_pyrup2x<<<(int)min((quads + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, quads);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_project_tail(const float* y, int n, int C, int h, int w, const float* w3x3, const float* bias, int Ho, int Wo, float* out,
+                      frtm_stream_t stream) {
+  FRTM_CHECK_ARG(y && w3x3 && out && n > 0 && C > 0 && h > 1 && w > 1 && Ho > 0 && Wo > 0, "frtm_project_tail: bad argument");
+  // LDS patch bounds: the rows / columns of the 2x-upsampled map a 16x64 output tile (+1 halo) reads through the bilinear taps
+  const double sy = 2.0 * h / Ho, sx = 2.0 * w / Wo;
+  FRTM_CHECK_ARG((int)(PT_ZR * sy) + 3 <= PT_UR && (int)(PT_ZC * sx) + 3 <= PT_UC,
+                 "frtm_project_tail: resize ratio %.3f x %.3f outside the fused kernel's patch (use pyrup2x + bilinear_resize + filter_scores)", sy, sx);
+  dim3 g(ceil_div(Wo, PT_TW), ceil_div(Ho, PT_TH), n);
+  k_project_tail<<<g, 256, 0, (hipStream_t)stream>>>(y, C, h, w, w3x3, bias, out, Ho, Wo);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

@@ -138,6 +138,7 @@ class SegNetwork(nn.Module):
         self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
         self._graphs = {}
         self._pack_key = None
+        self.fuse_tail = True         # up2 + resize + conv2 as one kernel when the resize ratio allows (frtm_project_tail)
         self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
         self._side = None
 
@@ -335,9 +336,14 @@ class SegNetwork(nn.Module):
         H.call('frtm_pyrup2x', H.ptr(x), n * c, hh, ww, H.ptr(u1))
         y = self._conv(u1, pj['c1'])
         c2 = y.shape[1]
+        Ho, Wo = int(image_size[-2]), int(image_size[-1])
+        if self.fuse_tail and int(18 * 4.0 * hh / Ho) + 3 <= 22 and int(66 * 4.0 * ww / Wo) + 3 <= 76:
+            # up2 + bilinear resize + conv2 in one kernel: the 32-channel full-resolution tensor never exists in HBM
+            out = torch.empty(n, 1, Ho, Wo, device=dev)
+            H.call('frtm_project_tail', H.ptr(y), n, c2, 2 * hh, 2 * ww, H.ptr(pj['w2']), H.ptr(pj['b2']), Ho, Wo, H.ptr(out))
+            return out
         u2 = torch.empty(n, c2, 4 * hh, 4 * ww, device=dev)
         H.call('frtm_pyrup2x', H.ptr(y), n * c2, 2 * hh, 2 * ww, H.ptr(u2))
-        Ho, Wo = int(image_size[-2]), int(image_size[-1])
         if (Ho, Wo) != (4 * hh, 4 * ww):
             z = torch.empty(n, c2, Ho, Wo, device=dev)
             H.call('frtm_bilinear_resize', H.ptr(u2), n * c2, 4 * hh, 4 * ww, H.ptr(z), Ho, Wo)

@@ -230,6 +230,13 @@ int frtm_cab_combine(const float* shallow, const float* gate, const float* deepe
                      int deeper_shared, int H, int W, float* out, frtm_stream_t stream);
 /* PyrUpBicubic2d: 2x polyphase bicubic with replicate border (seg_network.py:75-126); out (planes,2h,2w) */
 int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream);
+/* Tail of BackwardCompatibleUpsampler.forward (model/seg_network.py:117-119) in one kernel:
+ *   out[n,0] = conv2(interpolate(up2(y[n]), (Ho,Wo), bilinear, align_corners=False)) + bias
+ * y (n,C,h,w) is relu(conv1(up1(x))); up2 = PyrUpBicubic2d (2x), conv2 = 3x3, C -> 1, zero padding.  w3x3 (1,C,3,3), bias (1)
+ * or NULL.  The resize ratio 2h/Ho, 2w/Wo must be within ~[0.5, 1.1] (the LDS patch of the fused kernel); otherwise the call
+ * fails with FRTM_ERR_ARG and the caller composes frtm_pyrup2x + frtm_bilinear_resize + frtm_filter_scores. */
+int frtm_project_tail(const float* y, int n, int C, int h, int w, const float* w3x3, const float* bias, int Ho, int Wo, float* out,
+                      frtm_stream_t stream);
 /* adaptive_avg_pool2d(x, 1): out[plane] = mean(in[plane]) */
 int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream_t stream);
 

@@ -440,6 +440,39 @@ def test_refiner_glue_kernels():
     assert rel(m, x.mean((1, 2))) < 1e-5
 
 
+@pytest.mark.parametrize('n,C,h,w,Ho,Wo', [(2, 32, 24, 43, 48, 86), (1, 32, 24, 43, 48, 85), (2, 5, 9, 70, 19, 139), (1, 32, 61, 107, 120, 214),
+                                           (3, 8, 17, 33, 33, 70), (1, 4, 8, 8, 16, 15)])
+def test_project_tail_fused(n, C, h, w, Ho, Wo):
+    """frtm_project_tail == conv2(interpolate(up2(y))) (seg_network.py:117-119): against the unfused HIP kernels (the
+    intermediate maps are bit-identical, only the channel summation order of the final conv differs) and against PyTorch."""
+    from frtm_vos_amd import _hip as H
+    from frtm_vos_amd.model.seg_network import PyrUpBicubic2d
+    g = gen(31)
+    y = torch.relu(torch.randn(n, C, h, w, generator=g)).to(DEV)
+    w3 = (torch.randn(1, C, 3, 3, generator=g) * 0.2).to(DEV)
+    b = torch.tensor([0.3], device=DEV)
+    out = torch.empty(n, 1, Ho, Wo, device=DEV)
+    H.call('frtm_project_tail', H.ptr(y), n, C, h, w, H.ptr(w3), H.ptr(b), Ho, Wo, H.ptr(out))
+    u2 = torch.empty(n, C, 2 * h, 2 * w, device=DEV)
+    H.call('frtm_pyrup2x', H.ptr(y), n * C, h, w, H.ptr(u2))
+    z = torch.empty(n, C, Ho, Wo, device=DEV)
+    H.call('frtm_bilinear_resize', H.ptr(u2), n * C, 2 * h, 2 * w, H.ptr(z), Ho, Wo)
+    from frtm_vos_amd import ops as O
+    unfused = O.filter_scores(z, w3, out=b.view(1, 1, 1, 1).expand(n, 1, Ho, Wo).contiguous(), accumulate=True)
+    assert rel(out, unfused) < 2e-6, rel(out, unfused)
+    ref = F.conv2d(F.interpolate(PyrUpBicubic2d(C).to(DEV)(y), (Ho, Wo), mode='bilinear', align_corners=False), w3, b, padding=1)
+    assert rel(out, ref) < 1e-5, rel(out, ref)
+
+
+def test_project_tail_rejects_large_ratio():
+    from frtm_vos_amd import _hip as H
+    y = torch.zeros(1, 2, 16, 16, device=DEV)
+    w3 = torch.zeros(1, 2, 3, 3, device=DEV)
+    out = torch.empty(1, 1, 20, 20, device=DEV)
+    with pytest.raises(RuntimeError, match='resize ratio'):
+        H.call('frtm_project_tail', H.ptr(y), 1, 2, 16, 16, H.ptr(w3), None, 20, 20, H.ptr(out))
+
+
 def test_device_guarded_memory_update():
     """count < 10 on the device == the reference's early-out: weights, slots and samples untouched; count >= 10 == update."""
     from frtm_vos_amd.model.memory import Memory
