@@ -59,6 +59,7 @@ SIGNATURES = {
     'frtm_cab_combine': (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     'frtm_pyrup2x': (I, [P, I, I, I, P, P]),
     'frtm_plane_mean': (I, [P, I, I, P, P]),
+    'frtm_cab_gate': (I, [P, P, I, P, P, P, P, I, I, P, P]),
     'frtm_project_tail': (I, [P, I, I, I, I, P, P, I, I, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
 }

@@ -94,6 +94,48 @@ __global__ __launch_bounds__(256) void k_cab_combine(const float* __restrict__ s
   }
 }
 
+
+// Channel-attention gate (seg_network.py:34-37): gate[n,:] = W2^T relu(W1^T [sp[n]; dp[n]] + b1) + b2 (the sigmoid is applied by
+// k_cab_combine).  sp / dp: pooled shallower / deeper features (n,oc); dp_stride = 0 broadcasts one deeper vector.  W1 (2oc,oc),
+// W2 (oc,oc) are the 1x1 conv weights transposed to [in][out].  One block per object: four framework launches (cat, addmm, relu,
+// addmm) become one.
+__global__ __launch_bounds__(256) void k_cab_gate(const float* __restrict__ sp, const float* __restrict__ dp, int dp_stride,
+                                                   const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                                                   const float* __restrict__ b2, int oc, float* __restrict__ gate) {
+  extern __shared__ float sm[];                      // [2oc] input, [oc] hidden, [4][oc] partial sums
+  float* v = sm; float* hid = sm + 2 * oc; float* part = sm + 3 * oc;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 2 * oc; i += 256) v[i] = i < oc ? sp[(size_t)n * oc + i] : dp[(size_t)n * dp_stride + i - oc];
+  __syncthreads();
+  // each output is summed by 4 threads over a quarter of the inputs (independent loads in flight), then combined in fixed order
+  const int q = tid >> 6, lane = tid & 63;
+  for (int j0 = 0; j0 < oc; j0 += 64) {
+    const int j = j0 + lane;
+    const int i0 = q * (2 * oc / 4), i1 = (q + 1) * (2 * oc / 4);
+    float a = 0.f;
+    if (j < oc) {
+#pragma unroll 8
+      for (int i = i0; i < i1; ++i) a += v[i] * W1[(size_t)i * oc + j];
+      part[q * oc + j] = a;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < oc; j += 256) hid[j] = fmaxf(b1[j] + ((part[j] + part[oc + j]) + (part[2 * oc + j] + part[3 * oc + j])), 0.f);
+  __syncthreads();
+  for (int k0 = 0; k0 < oc; k0 += 64) {
+    const int k = k0 + lane;
+    const int j0 = q * (oc / 4), j1 = (q + 1) * (oc / 4);
+    float a = 0.f;
+    if (k < oc) {
+#pragma unroll 8
+      for (int j = j0; j < j1; ++j) a += hid[j] * W2[(size_t)j * oc + k];
+      part[q * oc + k] = a;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < oc; k += 256) gate[(size_t)n * oc + k] = b2[k] + ((part[k] + part[oc + k]) + (part[2 * oc + k] + part[3 * oc + k]));
+}
+
 // 2x polyphase bicubic up-sampling, replicate border (seg_network.py:75-126): out = crop1(interleave(conv4x4(pad2(in)))).
 // The taps are the a = -0.75 cubic kernel at d = -0.25 (even phase) / d = -0.75 (odd phase):
 //   even: cubic(1.25), cubic(.25), cubic(.75), cubic(1.75) = -27/256, 225/256, 67/256, -9/256 ; odd: the reverse.
@@ -345,6 +387,15 @@ int frtm_cab_combine(const float* shallow, const float* gate, const float* deepe
   const size_t total = (size_t)n * C * H * W;
   k_cab_combine<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(
       shallow, gate, deeper, C, hd, wd, deeper_shared ? 0 : (size_t)C * hd * wd, H, W, out, total);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_cab_gate(const float* sp, const float* dp, int dp_shared, const float* W1, const float* b1, const float* W2, const float* b2,
+                  int n, int oc, float* gate, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(sp && dp && W1 && b1 && W2 && b2 && gate && n > 0 && oc > 0 && oc <= 4096, "frtm_cab_gate: bad argument");
+  FRTM_CHECK_ARG(oc % 4 == 0, "frtm_cab_gate: oc must be a multiple of 4 (got %d)", oc);
+  k_cab_gate<<<n, 256, 7 * oc * sizeof(float), (hipStream_t)stream>>>(sp, dp, dp_shared ? 0 : oc, W1, b1, W2, b2, oc, gate);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

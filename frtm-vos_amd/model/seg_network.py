@@ -250,8 +250,8 @@ class SegNetwork(nn.Module):
             P[L] = dict(r0=cv(t.reduce[0], relu_=True), r2=cv(t.reduce[2]), base=cv(base), ws=w0[:, oc].reshape(w0.shape[0], 9).contiguous(),
                         b0=t.transform[0].bias.data.float().contiguous(), t2=cv(t.transform[2], relu_=True), t4=cv(t.transform[4], relu_=True),
                         rrb1=rrb(self.RRB1[L]), rrb2=rrb(self.RRB2[L]),
-                        cab_w1=c[0].weight.data.flatten(1).t().contiguous(), cab_b1=c[0].bias.data, cab_w2=c[2].weight.data.flatten(1).t().contiguous(),
-                        cab_b2=c[2].bias.data)
+                        cab_w1=c[0].weight.data.flatten(1).t().contiguous(), cab_b1=c[0].bias.data.contiguous(), cab_w2=c[2].weight.data.flatten(1).t().contiguous(),
+                        cab_b2=c[2].bias.data.contiguous())
         pj = self.project
         P['project'] = dict(c1=cv(pj.conv1, relu_=True), w2=pj.conv2.weight.data.contiguous(), b2=pj.conv2.bias.data)
         self._pack, self._pack_key = P, key
@@ -321,8 +321,10 @@ class SegNetwork(nn.Module):
             r, sp, _, tmp = br[L]
             keep.append(tmp)
             Hh, Ww = r.shape[-2:]
-            dp = pool0.expand(n, -1) if x is None else self._mean(x)
-            gate = torch.addmm(p['cab_b2'], torch.relu(torch.addmm(p['cab_b1'], torch.cat((sp, dp), 1), p['cab_w1'])), p['cab_w2']).contiguous()
+            dp = pool0 if x is None else self._mean(x)
+            gate = torch.empty(n, r.shape[1], device=dev)
+            H.call('frtm_cab_gate', H.ptr(sp), H.ptr(dp), int(x is None), H.ptr(p['cab_w1']), H.ptr(p['cab_b1']), H.ptr(p['cab_w2']),
+                   H.ptr(p['cab_b2']), n, r.shape[1], H.ptr(gate))
             out = torch.empty_like(r)
             if x is None:
                 H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(pool0), n, r.shape[1], 1, 1, 1, Hh, Ww, H.ptr(out))

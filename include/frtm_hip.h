@@ -149,7 +149,8 @@ typedef struct {
   int splitk;              /* 0 = auto */
   int tile;                /* 0 = auto, else FRTM_TILE_* */
   int w_layout;            /* FRTM_WLAYOUT_GEMM (0) or FRTM_WLAYOUT_HALO3X3 (3x3, stride 1 or 2, pad 1 only) */
-  int ws_elems;            /* capacity of `workspace` in floats (0 = no workspace: split-K is disabled); split-K is clamped to it */
+  int ws_elems;            /* capacity of `workspace` in floats (0 = no workspace: split-K is disabled); split-K is clamped to it.
+                              One workspace must not be used by convolutions that may run concurrently (one per stream). */
   int w_pitch;             /* 0: wT is the padded [Kp][Mp] image of frtm_conv_pack_weights;
                               >0: wT is a plain [K][w_pitch] matrix (w_pitch >= Cout, multiple of 4, 16-byte aligned) */
 } frtm_conv_desc;
@@ -228,6 +229,11 @@ int frtm_tse_inject(const float* base, const float* bias, const float* ws, const
  * deeper_shared != 0: one deeper tensor (1,C,hd,wd) for all n. */
 int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd,
                      int deeper_shared, int H, int W, float* out, frtm_stream_t stream);
+/* CAB gate (model/seg_network.py:34-37, before the sigmoid): gate (n,oc) = W2^T relu(W1^T cat(sp, dp) + b1) + b2.
+ * sp, dp: (n,oc) pooled shallower / deeper features (dp_shared != 0: one (1,oc) deeper vector for all objects);
+ * W1 (2oc,oc) and W2 (oc,oc): the two 1x1 conv weights transposed to [in][out]. */
+int frtm_cab_gate(const float* sp, const float* dp, int dp_shared, const float* W1, const float* b1, const float* W2, const float* b2,
+                  int n, int oc, float* gate, frtm_stream_t stream);
 /* PyrUpBicubic2d: 2x polyphase bicubic with replicate border (seg_network.py:75-126); out (planes,2h,2w) */
 int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream);
 /* Tail of BackwardCompatibleUpsampler.forward (model/seg_network.py:117-119) in one kernel:
