@@ -154,6 +154,36 @@ class DiscriminatorLoss(MinimizationProblem):
         H.call('frtm_vec_axpy', H.ptr(self.w2.data), step, H.ptr(delta[n1:]), c * 9)
 
     # ---- reference-style helpers (not on the hot path) ----------------------------------
+    def __call__(self, parameters: TensorList) -> TensorList:
+        """Residual list of the reference (discriminator.py:45-50): [w * (upsample(net(x)) - y), reg_i * parameter_i ...].
+        The solver never evaluates it (it works on the low-resolution normal equations); this is the diagnostic / parity
+        entry point and needs the full-resolution labels and pixel weights: construct the memory with ``keep_hires=True``."""
+        m = self.mem
+        if not m.keep_hires:
+            raise RuntimeError('DiscriminatorLoss.__call__ needs the full-resolution labels: use Memory(..., keep_hires=True) '
+                               '(Discriminator(..., keep_hires=True)); the solver itself only keeps their low-resolution normal form')
+        self.initialize()
+        N, c = self.N, self.c
+        params = list(parameters)
+        w2 = params[-1].detach().float().contiguous()
+        if self.joint:
+            w1 = params[0].detach().float()
+            w1T = ops.transpose2d(w1.reshape(c, self.Cin).contiguous())
+            feats = ops.conv2d(m.samples, w1T, c, shape=(N, self.Cin, self.h, self.w), w_pitch=c)
+        else:
+            feats = m.samples
+        s = ops.filter_scores(feats, w2, n=N)
+        Hh, Ww = m.labels_size[-2:]
+        up = torch.empty(N, 1, Hh, Ww, device=s.device)
+        H.call('frtm_bilinear_resize', H.ptr(s), N, self.h, self.w, H.ptr(up), Hh, Ww)
+        wgt = m.pixel_weights[:N] * m.weights[:N].sqrt().view(-1, 1, 1, 1)                 # :43
+        res = wgt * (up - m.labels[:N])
+        return TensorList([res] + [float(r) * p_ for r, p_ in zip(self.filter_regs, params)])
+
+    def ip(self, a, b):
+        """Reference :52-53: per-tensor flat dot products."""
+        return TensorList([x.reshape(-1) @ y.reshape(-1) for x, y in zip(a, b)])
+
     def ip_input(self, a, b):
         out = TensorList([x.reshape(-1) @ y.reshape(-1) for x, y in zip(a, b)])
         total = sum(o.unsqueeze(0) for o in out)
@@ -169,8 +199,9 @@ class Discriminator(nn.Module):
                  init_iters=(5, 10, 10, 10, 10), update_iters=(10,), update_filters=True,
                  filter_reg=(1e-4, 1e-2), precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=75,
                  memory_size=80, train_skipping=8, learning_rate=0.1,
-                 pixel_weighting=None, device=None, layer=None):
+                 pixel_weighting=None, device=None, layer=None, keep_hires=False):
         super().__init__()
+        self.keep_hires = keep_hires     # also store full-resolution labels / pixel weights (DiscriminatorLoss.__call__)
         if out_channels != 1:
             raise ValueError('the target model scores one channel (reference evaluate.py:78)')
         self.project = conv(in_channels, c_channels, 1, bias=False)
@@ -231,7 +262,8 @@ class Discriminator(nn.Module):
         K = x.shape[0]
         dev = x.device
         # joint fit of (project, filter) on the K raw samples
-        mem0 = Memory(K, x.shape[-3:], y.shape[-3:], dev, self.learning_rate, pixel_weighting=self.pw_params)
+        mem0 = Memory(K, x.shape[-3:], y.shape[-3:], dev, self.learning_rate, pixel_weighting=self.pw_params,
+                      keep_hires=self.keep_hires)
         mem0.initialize(x, y)
         problem = DiscriminatorLoss(mem0, self.filter_reg, self.precond, self.filter.weight, self.project.weight)
         optimizer = GaussNewtonCG(problem, TensorList([self.project.weight, self.filter.weight]), fletcher_reeves=False,
@@ -241,7 +273,7 @@ class Discriminator(nn.Module):
         xp = ops.conv2d(x, self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)   # re-project (:178)
         # memory + filter-only problem used for the rest of the sequence
         memory = Memory(self.memory_size, xp.shape[-3:], y.shape[-3:], dev, self.learning_rate,
-                        pixel_weighting=self.pw_params)
+                        pixel_weighting=self.pw_params, keep_hires=self.keep_hires)
         memory.initialize(xp, y)
         problem = DiscriminatorLoss(memory, self.filter_reg[1:], self.precond[1:], self.filter.weight)
         optimizer = GaussNewtonCG(problem, TensorList([self.filter.weight]), fletcher_reeves=False,

@@ -273,6 +273,37 @@ def test_init_problem_g4(golden):
         assert rel(w2, T(g[tag + '_w2'])) < 5e-3, tag
 
 
+def test_problem_residuals_and_ip(golden):
+    """DiscriminatorLoss.__call__ / ip (reference discriminator.py:45-53): sum of squared residuals == the objective the
+    oracle evaluates on the same data; needs keep_hires memory and says so otherwise."""
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from tests.test_oracle_golden import _init_loss
+    g = golden('g4_init')
+    cin, c, h, w, H, W = [int(v) for v in g['dims']]
+    x, y = T(g['x']), T(g['y'])
+    w1, w2 = T(g['w1_0']).to(DEV), T(g['w2_0']).to(DEV)
+    mem = Memory(5, (cin, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW, keep_hires=True)
+    mem.initialize(x.to(DEV), y.to(DEV))
+    prob = DiscriminatorLoss(mem, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)
+    r = prob(TensorList([w1, w2]))
+    assert len(r) == 3 and r[0].shape == (5, 1, H, W) and r[1].shape == w1.shape and r[2].shape == w2.shape
+    loss = float(sum(prob.ip(r, r)))
+    ref = _init_loss(x, y, w1.cpu(), w2.cpu())
+    assert abs(loss - ref) / ref < 1e-5, (loss, ref)
+    # filter-only problem on projected features
+    xp = F.conv2d(x, w1.cpu()).to(DEV)
+    mem2 = Memory(8, (c, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW, keep_hires=True)
+    mem2.initialize(xp, y.to(DEV))
+    r2 = DiscriminatorLoss(mem2, (1e-2,), (1e-2,), w2)(TensorList([w2]))
+    assert rel(r2[0], r[0]) < 1e-5 and len(r2) == 2
+    with pytest.raises(RuntimeError, match='keep_hires'):
+        m3 = Memory(5, (cin, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+        m3.initialize(x.to(DEV), y.to(DEV))
+        DiscriminatorLoss(m3, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)(TensorList([w1, w2]))
+
+
 def test_discriminator_g5(golden):
     """init -> (apply, update) x 17 against the reference recording.  Gates as in tests/test_oracle_golden.py:
     objective value tight, scores at the algorithm's own fp32 noise floor (see that file's docstring)."""
