@@ -195,12 +195,18 @@ __global__ __launch_bounds__(256) void k_memory_insert(const T* __restrict__ src
 // 3x3 filter scores.  Block = 4 waves: the same 64 consecutive pixels, 4 channel quarters; LDS sum.
 // Reads X exactly once (coalesced rows; the 9 shifted taps of a row hit L1).
 // ------------------------------------------------------------------------------------------
+template <int PX>
 __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__ X, const float* __restrict__ f, int C, int h, int w,
                                                         float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
+  // PX pixels per block; the 64 / PX lane groups of each of the 4 waves take disjoint channel ranges (16 channel groups for
+  // PX = 16: the 1..5-sample calls of Discriminator.apply and of the init problem are only 26 blocks per sample at PX = 64,
+  // each lane walking 24 channels x 9 taps in sequence -- latency bound).  PX = 64 is the plain one-group-per-wave form.
+  constexpr int CGW = 64 / PX, G = 4 * CGW;
+  __shared__ float red[4][PX];
   const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int pl = lane % PX, cg = wid * CGW + lane / PX;
   const int hw = h * w;
-  const int p = blockIdx.x * 64 + lane;
+  const int p = blockIdx.x * PX + pl;
   const bool live = p < hw;
   const int py = live ? p / w : 0, px = live ? p % w : 0;
   bool ok[9]; int off[9];
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__
       ok[dy * 3 + dx] = v;
       off[dy * 3 + dx] = v ? yy * w + xx : 0;
     }
-  const int cper = (C + 3) / 4;
-  const int c0 = wid * cper, c1 = min(C, c0 + cper);
+  const int cper = (C + G - 1) / G;
+  const int c0 = cg * cper, c1 = min(C, c0 + cper);
   const float* Xn = X + (size_t)n * C * hw;
   float acc = 0.f;
   for (int c = c0; c < c1; ++c) {
@@ -226,9 +232,11 @@ __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__
       acc += (ok[k] ? v : 0.f) * fc[k];
     }
   }
-  red[wid][lane] = acc;
+#pragma unroll
+  for (int o = PX; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);     // channel groups of this wave (fixed butterfly order)
+  if (lane < PX) red[wid][lane] = acc;
   __syncthreads();
-  if (wid == 0 && live) {
+  if (wid == 0 && lane < PX && live) {
     const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     float* o = out + (size_t)n * hw + p;
     *o = accumulate ? (*o + s) : s;
@@ -664,8 +672,13 @@ int frtm_memory_insert(const float* src, float* dst_base, int len, const int* sl
 
 int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w, float* out, int accumulate, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && f && out && N > 0 && C > 0 && h > 0 && w > 0, "frtm_filter_scores: bad argument");
-  dim3 g(ceil_div(h * w, 64), N);
-  k_filter_scores<<<g, 256, 0, (hipStream_t)stream>>>(X, f, C, h, w, out, accumulate);
+  if ((long)N * ceil_div(h * w, 64) < 512) {            // few samples: 16-pixel blocks, 16 channel groups
+    dim3 g(ceil_div(h * w, 16), N);
+    k_filter_scores<16><<<g, 256, 0, (hipStream_t)stream>>>(X, f, C, h, w, out, accumulate);
+  } else {
+    dim3 g(ceil_div(h * w, 64), N);
+    k_filter_scores<64><<<g, 256, 0, (hipStream_t)stream>>>(X, f, C, h, w, out, accumulate);
+  }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

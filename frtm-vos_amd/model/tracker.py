@@ -202,6 +202,7 @@ class Tracker(nn.Module):
     def initialize(self, image, labels, new_objects):
         """Reference tracker.py:165-191."""
         self.current_masks = torch.zeros((len(self.targets) + len(new_objects) + 1, *image.shape[-2:]), device=self.device)
+        fresh = []
         for obj_id in new_objects:
             mask = (labels == obj_id).byte()
             target = TargetObject(obj_id=obj_id, index=len(self.targets) + 1, disc_params=self.disc_params,
@@ -210,9 +211,18 @@ class Tracker(nn.Module):
             torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept:
             np.random.seed(0)                  # augmentation draws are identical for every object
             im, msk = self.augment(image, mask)
-            ft = self.feature_extractor(im, [target.disc_layer])
-            target.initialize(ft, msk)
+            fresh.append((target, im, msk))
             self.current_masks[target.index] = mask
+        if fresh:
+            # one trunk call for the augmented stacks of ALL objects that start on this frame (the reference runs one per
+            # object, :186); same per-image results, larger launches and one lane per object
+            layers = sorted({t.disc_layer for t, _, _ in fresh})
+            ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers)
+            b0 = 0
+            for target, im, msk in fresh:
+                k = im.shape[0]
+                target.initialize({L: ft[L][b0:b0 + k] for L in layers}, msk)
+                b0 += k
         return self.current_masks
 
     @torch.no_grad()
