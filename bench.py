@@ -288,7 +288,11 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm (fp32 MFMA implicit-GEMM conv, whole ResNet trunk)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
                      'traffic': traffic,
-                     'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch},
+                     # avg_ms = HIP-event time of the trunk passes / conv launches: the EFFECTIVE duration per launch.  With
+                     # trunk_lanes concurrent sub-batches the kernel-trace mean duration is ~lanes x this (kernels share the GPU);
+                     # profiles/*_trunk_only.json holds the union-of-intervals cross-check from rocprofv3.
+                     'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch,
+                                    'concurrent_lanes': args.trunk_lanes},
                      'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'host_enqueue_ms_per_step': 1e3 * t_host / n,

@@ -13,7 +13,7 @@ import sys
 tag, prof, fetch, write, bench = sys.argv[1:6]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, 'profiles')
-cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8)'
+cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8 --trunk-batch 8 --trunk-lanes 2)'
 
 rows = list(csv.DictReader(open(os.path.join(prof, 'prof_kernel_stats.csv'))))
 with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w') as f:
@@ -34,9 +34,31 @@ for r in tr:
         tot[n] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         cnt[n] += 1
 busy = sum(tot.values())
+
+
+def union_ns(intervals):
+    """Total length of the union of [start, end) intervals (kernels of concurrent lanes / graph branches overlap)."""
+    total, cur_s, cur_e = 0, None, None
+    for s_, e_ in sorted(intervals):
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    if cur_e is not None:
+        total += cur_e - cur_s
+    return total
+
+
+CONV = ('k_conv_igemm', 'k_conv3x3_halo', 'k_splitk_epilogue')
+inwin = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in tr if int(r['Start_Timestamp']) >= t1 - win]
+occupied = union_ns([(a, e) for a, e, _ in inwin])
 with open(os.path.join(out, tag + '_steady_state.csv'), 'w') as f:
     w = csv.writer(f)
-    w.writerow(['# same run; last %.0f ms of the trace = tracked frames of the timed sequence; GPU busy %.1f %% of the window' % (win / 1e6, 100 * busy / win)])
+    w.writerow(['# same run; last %.0f ms of the trace = tracked frames of the timed sequence; at least one kernel running %.1f %% of the '
+                'window; summed kernel durations = %.2f x the occupied time (concurrent trunk lanes / refiner branches overlap)'
+                % (win / 1e6, 100 * occupied / win, busy / max(occupied, 1))])
     w.writerow(['Name', 'Calls', 'TotalMs', 'AvgUs', 'PercentOfBusy'])
     for n, d in tot.most_common(40):
         w.writerow([n, cnt[n], round(d / 1e6, 3), round(d / cnt[n] / 1e3, 2), round(100 * d / busy, 2)])
@@ -45,4 +67,23 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.
                        'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python bench.py --no-cpu-baseline'])
 shutil.copy(os.path.join(out, tag + '_pmc_traffic.json'), os.path.join(out, 'pmc_traffic.json'))
 shutil.copy(bench, os.path.join(out, tag + '_bench.json'))
-print('GPU busy in steady-state window: %.1f %%' % (100 * busy / win))
+print('steady-state window: a kernel is running %.1f %% of the time; summed durations / occupied time = %.2f' % (100 * occupied / win, busy / max(occupied, 1)))
+
+# optional: trace of tools/trunk_bench.py (nothing but trunk kernels) -> the one-to-one cross-check of roofline.per_launch
+if len(sys.argv) > 6:
+    tdir = sys.argv[6]
+    t2 = list(csv.DictReader(open(os.path.join(tdir, 'prof_kernel_trace.csv'))))
+    conv = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in t2 if r['Kernel_Name'].startswith(('void k_conv', 'k_splitk'))]
+    convk = [r for r in t2 if r['Kernel_Name'].startswith('void k_conv')]
+    u = union_ns(conv)
+    ssum = sum(e - a for a, e in conv)
+    with open(os.path.join(out, tag + '_trunk_only.json'), 'w') as f:
+        json.dump({'command': 'rocprofv3 --kernel-trace --output-format csv -- python tools/trunk_bench.py 8 2 graph',
+                   'conv_launches': len(convk), 'conv_family_union_ms': u / 1e6, 'conv_family_summed_ms': ssum / 1e6,
+                   'effective_us_per_conv_launch': u / 1e3 / max(len(convk), 1),
+                   'mean_kernel_duration_us': ssum / 1e3 / max(len(conv), 1),
+                   'note': 'rocprofv3 kernel tracing serialises the dispatches of the two trunk lanes (union ~= sum of durations), so this '
+                           'trace shows the un-overlapped kernel durations, i.e. the single-lane rate (tools/trunk_bench.py prints ~80 TF '
+                           'under the profiler and ~95 TF without it).  bench.py roofline.per_launch.avg_ms is HIP-event time of the '
+                           'pass / launches WITHOUT the profiler: the lanes overlap there, which is what the lanes are for'}, f, indent=1)
+    print('trunk only: %.1f us effective per conv launch (union), %.1f us mean kernel duration' % (u / 1e3 / max(len(convk), 1), ssum / 1e3 / max(len(conv), 1)))
