@@ -113,23 +113,25 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
 }
 
 // One sub-batch through the trunk on one stream (reference feature_extractor.py:40-68).
+// Largest activation of one image anywhere in the pass, in elements (stem output, or a stage output when the frame size is
+// odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2)).
+static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {
+  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
+  size_t need = (size_t)64 * Hs * Ws;
+  int ah = (Hs + 1) / 2, aw = (Ws + 1) / 2;
+  const int exp = bb->bottleneck ? 4 : 1;
+  for (int s = 0; s < 4; ++s) {
+    if (s > 0) { ah = (ah + 1) / 2; aw = (aw + 1) / 2; }
+    need = std::max(need, (size_t)(64 << s) * exp * ah * aw);
+    need = std::max(need, (size_t)(64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
+  }
+  return std::max(need, (size_t)3 * H * W);
+}
+
 static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                         const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
                         int stop_after_layer, hipStream_t st) {
-  const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
-  // arena element count = the largest activation of the pass (stem output, or a stage output when the
-  // frame size is odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2))
-  size_t need = (size_t)B * 64 * Hs * Ws;
-  {
-    int ah = (Hs + 1) / 2, aw = (Ws + 1) / 2;
-    const int exp = bb->bottleneck ? 4 : 1;
-    for (int s = 0; s < 4; ++s) {
-      if (s > 0) { ah = (ah + 1) / 2; aw = (aw + 1) / 2; }
-      need = max(need, (size_t)B * (64 << s) * exp * ah * aw);
-      need = max(need, (size_t)B * (64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
-    }
-    need = max(need, (size_t)B * 3 * H * W);
-  }
+  const size_t need = (size_t)B * arena_elems_per_image(bb, H, W);
   if (ln.buf_elems < need) {
     bb->generation += 1;
     for (auto& b : ln.buf) {
@@ -310,8 +312,8 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   bb->last_flops = 0.0;
   bb->last_launches = 0;
   const int L = std::min(bb->nlanes, B);
-  if (L == 1) return forward_lane(bb, bb->lanes[0], image_u8, B, H, W, norm_scale3, norm_bias3, layer1, layer2, layer3, layer4, layer5,
-                                  stop_after_layer, st);
+  // the conv kernels address activations with 32-bit byte offsets: at most this many images per forward_lane call
+  const int max_imgs = (int)std::max<size_t>(1, (size_t)0x7fffffff / 4 / arena_elems_per_image(bb, H, W));
   // tap geometry (per image element counts) for the per-lane slices of the batched outputs
   const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
   int th = (Hs + 1) / 2, tw = (Ws + 1) / 2;
@@ -323,18 +325,21 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
     per_img[s + 1] = (size_t)(64 << s) * exp * th * tw;
   }
   float* taps[5] = {layer1, layer2, layer3, layer4, layer5};
-  FRTM_HIP(hipEventRecord(bb->fork, st));
+  if (L > 1) FRTM_HIP(hipEventRecord(bb->fork, st));
   int b0 = 0;
   for (int l = 0; l < L; ++l) {
     Lane& ln = bb->lanes[l];
     const int Bl = B / L + (l < B % L ? 1 : 0);
     hipStream_t ls = (l == 0) ? st : ln.stream;              // lane 0 stays on the caller's stream
     if (l > 0) FRTM_HIP(hipStreamWaitEvent(ls, bb->fork, 0));
-    float* tl[5];
-    for (int t = 0; t < 5; ++t) tl[t] = taps[t] ? taps[t] + (size_t)b0 * per_img[t] : nullptr;
-    int rc = forward_lane(bb, ln, image_u8 + (size_t)b0 * 3 * H * W, Bl, H, W, norm_scale3, norm_bias3, tl[0], tl[1], tl[2], tl[3], tl[4],
-                          stop_after_layer, ls);
-    if (rc) return rc;
+    for (int c0 = 0; c0 < Bl; c0 += max_imgs) {              // one call per lane unless the batch is too large for it
+      const int Bc = std::min(max_imgs, Bl - c0);
+      float* tl[5];
+      for (int t = 0; t < 5; ++t) tl[t] = taps[t] ? taps[t] + (size_t)(b0 + c0) * per_img[t] : nullptr;
+      int rc = forward_lane(bb, ln, image_u8 + (size_t)(b0 + c0) * 3 * H * W, Bc, H, W, norm_scale3, norm_bias3, tl[0], tl[1], tl[2], tl[3],
+                            tl[4], stop_after_layer, ls);
+      if (rc) return rc;
+    }
     if (l > 0) FRTM_HIP(hipEventRecord(ln.done, ls));
     b0 += Bl;
   }
