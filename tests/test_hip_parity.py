@@ -81,7 +81,8 @@ def test_memory_weights_g2(golden):
 
 
 # ------------------------------------------------------------------------------------------ small filter kernels
-@pytest.mark.parametrize('N,C,h,w', [(7, 8, 6, 9), (3, 96, 30, 54), (1, 5, 3, 3), (2, 13, 17, 65)])
+@pytest.mark.parametrize('N,C,h,w', [(7, 8, 6, 9), (3, 96, 30, 54), (1, 5, 3, 3), (2, 13, 17, 65), (40, 96, 30, 54), (90, 7, 11, 64),
+                                     (30, 16, 20, 70), (3, 12, 9, 80)])   # pixel form (16- and 64-pixel blocks) and row form of the score kernel
 def test_filter_kernels(ops, N, C, h, w):
     from frtm_vos_amd import _hip as H
     g = gen(N * C)
