@@ -29,7 +29,8 @@ SIGNATURES = {
     'frtm_memory_insert': (I, [P, P, I, P, P]),
     'frtm_filter_scores': (I, [P, P, I, I, I, I, P, I, P]),
     'frtm_stencil': (I, [P, P, P, P, I, I, I, P, P]),
-    'frtm_filter_wgrad': (I, [P, P, I, I, I, I, P, P]),
+    'frtm_filter_wgrad': (I, [P, P, I, I, I, I, I, P, P]),
+    'frtm_filter_wgrad_parts': (I, [I, I]),
     'frtm_filter_wgrad_stencil': (I, [P, P, P, P, P, I, I, I, I, P, P]),
     'frtm_filter_igrad': (I, [P, P, I, I, I, I, P, I, P]),
     'frtm_vec_reduce_slabs': (I, [P, I, I, I, F, P, F, P, P]),

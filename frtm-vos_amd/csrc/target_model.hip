@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ B, co
 template <bool STENCIL>
 __global__ __launch_bounds__(256) void k_filter_wgrad(const float* __restrict__ X, const float* __restrict__ t, int C, int h, int w,
                                                        float* __restrict__ partial, const float* __restrict__ Bm, const float* __restrict__ cm,
-                                                       const float* __restrict__ sw) {
+                                                       const float* __restrict__ sw, int parts) {
   extern __shared__ __attribute__((aligned(16))) float tl[];      // (h+2) x (w+2), zero border  [+ the same for s]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hw = h * w, wp = w + 2;
@@ -373,22 +373,36 @@ __global__ __launch_bounds__(256) void k_filter_wgrad(const float* __restrict__ 
   for (int k = 0; k < WG_CH; ++k)
 #pragma unroll
     for (int j = 0; j < 9; ++j) acc[k][j] = 0.f;
-  int qy = lane / w, qx = lane % w;
-  for (int q = lane; q < hw; q += 64) {
-    float tv[9];
-    const float* tc = tl + (qy + 1) * wp + (qx + 1);
+  // WG_UN pixel groups per trip: all of their X loads are issued before the first FMA (the kernel is bound by bytes in
+  // flight: one group per trip = 4 x 256 B per wave)
+  // blockIdx.z = part: this block sums the pixels [p_lo, p_hi) only and writes slab n*parts + part (few samples would
+  // otherwise leave most CUs idle: the grid is C/16 x N blocks, each wave walking the whole map)
+  const int part = blockIdx.z, per = (hw + parts - 1) / parts;
+  const int p_lo = part * per, p_hi = min(hw, p_lo + per);
+  constexpr int WG_UN = 4;
+  for (int q0 = p_lo + lane; q0 < p_hi; q0 += 64 * WG_UN) {
+    float xv[WG_UN][WG_CH];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int u = 0; u < WG_UN; ++u) {
+      const int q = q0 + u * 64;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) tv[dy * 3 + dx] = tc[-(dy - 1) * wp - (dx - 1)];
-#pragma unroll
-    for (int k = 0; k < WG_CH; ++k) {
-      const float xv = Xc[k][q];
-#pragma unroll
-      for (int j = 0; j < 9; ++j) acc[k][j] += xv * tv[j];
+      for (int k = 0; k < WG_CH; ++k) xv[u][k] = q < p_hi ? Xc[k][q] : 0.f;
     }
-    qx += 64;
-    while (qx >= w) { qx -= w; ++qy; }
+#pragma unroll
+    for (int u = 0; u < WG_UN; ++u) {
+      const int q = min(q0 + u * 64, hw - 1);
+      const int qy = q / w, qx = q - qy * w;
+      float tv[9];
+      const float* tc = tl + (qy + 1) * wp + (qx + 1);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) tv[dy * 3 + dx] = tc[-(dy - 1) * wp - (dx - 1)];
+#pragma unroll
+      for (int k = 0; k < WG_CH; ++k)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[k][j] += xv[u][k] * tv[j];
+    }
   }
 #pragma unroll
   for (int k = 0; k < WG_CH; ++k)
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(256) void k_filter_wgrad(const float* __restrict__ 
     for (int k = 0; k < WG_CH; ++k)
       if (cbase + k < C)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) partial[((size_t)n * C + cbase + k) * 9 + j] = acc[k][j];
+        for (int j = 0; j < 9; ++j) partial[(((size_t)n * parts + part) * C + cbase + k) * 9 + j] = acc[k][j];
   }
 }
 
@@ -752,12 +766,19 @@ int frtm_stencil(const float* B, const float* c, const float* sw, const float* s
   return FRTM_OK;
 }
 
-int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, float* partial, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(X && t && partial && N > 0 && C > 0, "frtm_filter_wgrad: bad argument");
+int frtm_filter_wgrad_parts(int N, int C) {
+  // only for few samples (measured at C = 96: N = 5 / 10: 7.4 / 9.9 us split vs 12 us unsplit; N >= 40: unsplit is faster,
+  // every part re-stages the t map in LDS and adds a slab to the reduction): about one block per CU, at most 8 parts
+  const int blocks = ceil_div(C, 4 * WG_CH) * N;
+  return max(1, min(8, 256 / max(blocks, 1)));
+}
+
+int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, int parts, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && t && partial && N > 0 && C > 0 && parts >= 1 && parts <= 64, "frtm_filter_wgrad: bad argument");
   const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
   FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_wgrad: feature grid %dx%d too large for the LDS tile", h, w);
-  dim3 g(ceil_div(C, 4 * WG_CH), N);
-  k_filter_wgrad<false><<<g, 256, lds, (hipStream_t)stream>>>(X, t, C, h, w, partial, nullptr, nullptr, nullptr);
+  dim3 g(ceil_div(C, 4 * WG_CH), N, parts);
+  k_filter_wgrad<false><<<g, 256, lds, (hipStream_t)stream>>>(X, t, C, h, w, partial, nullptr, nullptr, nullptr, parts);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
@@ -768,7 +789,7 @@ int frtm_filter_wgrad_stencil(const float* X, const float* s, const float* B, co
   const size_t lds = 2 * (size_t)(h + 2) * (w + 2) * sizeof(float);
   FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_filter_wgrad_stencil: feature grid %dx%d too large for the LDS tile", h, w);
   dim3 g(ceil_div(C, 4 * WG_CH), N);
-  k_filter_wgrad<true><<<g, 256, lds, (hipStream_t)stream>>>(X, s, C, h, w, partial, B, c, sw);
+  k_filter_wgrad<true><<<g, 256, lds, (hipStream_t)stream>>>(X, s, C, h, w, partial, B, c, sw, 1);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

@@ -48,7 +48,7 @@ class DiscriminatorLoss(MinimizationProblem):
         dev = memory.samples.device
         self.s = torch.empty(cap, self.hw, device=dev)
         self.t = torch.empty(cap, self.hw, device=dev)
-        self.partial = torch.empty(cap, self.c * 9, device=dev)
+        self.partial = torch.empty(cap * 8, self.c * 9, device=dev)      # per-sample (x up to 8 pixel parts) weight-gradient slabs
         self.N = 0
         if self.joint:
             self.Cin = C
@@ -89,8 +89,9 @@ class DiscriminatorLoss(MinimizationProblem):
                H.ptr(self.s), self.N, self.h, self.w, H.ptr(self.t))
 
     def _filter_grad(self, feats, lam2, pvec, sign, out):
-        H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, H.ptr(self.partial))
-        H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N, self.c * 9, self.c * 9, lam2, pvec, sign, out)
+        parts = H.lib().frtm_filter_wgrad_parts(self.N, self.c)
+        H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
+        H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N * parts, self.c * 9, self.c * 9, lam2, pvec, sign, out)
 
     def apply_A_partials(self, p):
         """Filter-only problem: leaves J^T J p as per-sample partial slabs (the solver's fused step kernel reduces them and
@@ -99,8 +100,9 @@ class DiscriminatorLoss(MinimizationProblem):
             return None
         ops.filter_scores(self.mem.samples, p, out=self.s, n=self.N)
         self._stencil(False)          # separate 4.6 us kernel: fusing it into the weight-gradient kernel measured slower (+8 us)
-        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, H.ptr(self.partial))
-        return self.partial, self.N, self.c * 9, self.filter_regs[0] ** 2
+        parts = H.lib().frtm_filter_wgrad_parts(self.N, self.c)
+        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
+        return self.partial, self.N * parts, self.c * 9, self.filter_regs[0] ** 2
 
     def _project_grad(self, lam2, pvec, sign, out):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""

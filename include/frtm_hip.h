@@ -77,10 +77,13 @@ int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int 
 int frtm_stencil(const float* B, const float* c, const float* sw, const float* s, int N, int h, int w,
                  float* t, frtm_stream_t stream);
 
-/* Filter weight gradient, per-sample partials (the conv backward of optimizer.py:84,155-157):
- * partial[n, c*9+dy*3+dx] = sum_{y,x} X[n,c,y+dy-1,x+dx-1] * t[n,y,x]. */
-int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w,
+/* Filter weight gradient as partial slabs (the conv backward of optimizer.py:84,155-157):
+ *   sum over part of partial[n*parts + part, c*9+dy*3+dx] = sum_{y,x} X[n,c,y+dy-1,x+dx-1] * t[n,y,x].
+ * `parts` >= 1 splits each sample's pixels over that many blocks (more parallelism when N is small);
+ * partial: float[N*parts][C*9].  frtm_filter_wgrad_parts() returns the split the library recommends for (N, C). */
+int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, int parts,
                       float* partial, frtm_stream_t stream);
+int frtm_filter_wgrad_parts(int N, int C);
 
 /* The same with the stencil fused in: t = sw * (B s - c) is formed inside the kernel from the scores s (c may be NULL). */
 int frtm_filter_wgrad_stencil(const float* X, const float* s, const float* B, const float* c, const float* sw,

@@ -94,9 +94,10 @@ def test_filter_kernels(ops, N, C, h, w):
     assert rel(s, O.conv3x3(X, f)) < 1e-5
     s2 = ops.filter_scores(Xd, fd, out=s.clone(), accumulate=True)
     assert rel(s2, 2 * O.conv3x3(X, f)) < 1e-5
-    part = torch.empty(N, C * 9, device=DEV)
-    H.call('frtm_filter_wgrad', H.ptr(Xd), H.ptr(td), N, C, h, w, H.ptr(part))
-    assert rel(part.sum(0).view(1, C, 3, 3), O.conv3x3_wgrad(X, t)) < 2e-5
+    for parts in (1, 3, H.lib().frtm_filter_wgrad_parts(N, C)):
+        part = torch.full((N * parts, C * 9), float('nan'), device=DEV)
+        H.call('frtm_filter_wgrad', H.ptr(Xd), H.ptr(td), N, C, h, w, parts, H.ptr(part))
+        assert rel(part.sum(0).view(1, C, 3, 3), O.conv3x3_wgrad(X, t)) < 2e-5, parts
     D = torch.empty(N, C, h, w, device=DEV)
     H.call('frtm_filter_igrad', H.ptr(td), H.ptr(fd), N, C, h, w, H.ptr(D), 0)
     assert rel(D, O.conv3x3_igrad(t, f)) < 1e-5

@@ -19,12 +19,13 @@ s = torch.empty(N, h * w, device=dev)
 t = torch.empty(N, h * w, device=dev)
 B = torch.randn(N, 9, h, w, device=dev)
 sw = torch.rand(N, device=dev)
-partial = torch.empty(N, c * 9, device=dev)
+parts = H.lib().frtm_filter_wgrad_parts(N, c)
+partial = torch.empty(N * parts, c * 9, device=dev)
 mb = X.numel() * 4 / 1e6
 us = timeit(lambda: ops.filter_scores(X, p, out=s, n=N))
 print('N=%d  X = %.1f MB' % (N, mb))
 print('filter_scores  %7.1f us  %6.2f TB/s' % (us, mb / us))
 us = timeit(lambda: H.call('frtm_stencil', H.ptr(B), None, H.ptr(sw), H.ptr(s), N, h, w, H.ptr(t)))
 print('stencil        %7.1f us' % us)
-us = timeit(lambda: H.call('frtm_filter_wgrad', H.ptr(X), H.ptr(t), N, c, h, w, H.ptr(partial)))
+us = timeit(lambda: H.call('frtm_filter_wgrad', H.ptr(X), H.ptr(t), N, c, h, w, parts, H.ptr(partial)))
 print('filter_wgrad   %7.1f us  %6.2f TB/s' % (us, mb / us))
