@@ -251,7 +251,13 @@ template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __restrict__ X, const float* __restrict__ f, int C, int h, int w,
                                                                  float* __restrict__ out, int accumulate) {
   __shared__ float red[NW][R][64];
-  const int n = blockIdx.y, y0 = blockIdx.x * R, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // Workgroup b runs on XCD b % 8 (private L2 each).  Give every XCD a contiguous range of (sample, row block) pairs, row
+  // blocks fastest, so the two halo rows neighbouring row blocks share are L2 hits instead of a second fetch by another XCD.
+  const int nb = gridDim.x, rbs = (h + R - 1) / R;
+  const int xcd = blockIdx.x & 7, qn = nb >> 3, rn = nb & 7;
+  const int logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+  const int n = logical / rbs, y0 = (logical - n * rbs) * R;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool xin = lane < w, has_l = lane > 0, has_r = lane + 1 < w;
   const int cper = (C + NW - 1) / NW;
   const int c0 = wid * cper, c1 = min(C, c0 + cper);
@@ -745,8 +751,7 @@ int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int 
   hipStream_t st = (hipStream_t)stream;
   if (w <= 64 && N >= 4) {
     // row form, 16 waves = 16 channel groups per block: 18.9 us at N = 80 (pixel form 41.9), 5.9 us at N = 10 (10.3)
-    dim3 g(ceil_div(h, 3), N);
-    k_filter_scores_rows<3, 16><<<g, 1024, 0, st>>>(X, f, C, h, w, out, accumulate);
+    k_filter_scores_rows<3, 16><<<ceil_div(h, 3) * N, 1024, 0, st>>>(X, f, C, h, w, out, accumulate);
   } else if ((long)N * ceil_div(h * w, 64) < 512) {       // few samples (Discriminator.apply: N = 1): 16-pixel blocks
     dim3 g(ceil_div(h * w, 16), N);
     k_filter_scores<16><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate);
