@@ -117,6 +117,13 @@ def call_nostream(name, *args):
         raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
 
 
+def upload(t, device):
+    """CPU tensor -> device without stalling the host: staged through (cached) pinned memory, asynchronous on the current stream."""
+    if t.is_cuda or device is None or torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError('%s: tensor is on %s; the FRTM hot path runs on the GPU only (no CPU fallback)' % (what, t.device))

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 from torch.nn import functional as F
 
+from .. import _hip as H
 from ..lib.image import warp_affine
 
 
@@ -131,7 +132,7 @@ class ImageAugmenter:
     def _blur(x, G):
         if G is None:
             return x
-        k = torch.as_tensor(G, device=x.device)[None, None]
+        k = H.upload(torch.from_numpy(np.ascontiguousarray(G)), x.device)[None, None]
         return F.conv2d(x[:, None], k, padding=(G.shape[0] // 2, G.shape[1] // 2))[:, 0]
 
     def augment_first_frame(self, im, lb):

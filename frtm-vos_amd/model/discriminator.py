@@ -220,9 +220,11 @@ class Discriminator(nn.Module):
         self.pw_params = pixel_weighting
         self.device = device
         self.update_filters = update_filters
-        self.to(device)
+        # the weights are drawn on the CPU (same generator stream as the reference) and uploaded through pinned memory without
+        # blocking: a plain .to(device) waits for the whole GPU queue to drain
         for p in self.parameters():
             p.requires_grad_(False)
+            p.data = H.upload(p.data, device)
         self.frame_num = 0
         self.update_optimizer = None
         self.current_sample = None

@@ -92,7 +92,7 @@ class Memory:
         assert init_labels.shape[0] == K and K <= self._capacity
         self.samples[:K] = init_features.detach()
         w = torch.full((K,), 1.0 / K, device=self.device)
-        w[0] = 2.0 / K
+        w[:1].fill_(2.0 / K)            # (not `w[0] = ...`: a Python scalar assigned by index goes through a blocking H2D copy)
         self.weights[:K] = w / w.sum()
         lab, pw = self._build_normals(init_labels, pixel_weights, K, None, 0)
         if self.keep_hires:

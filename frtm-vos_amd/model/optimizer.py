@@ -75,7 +75,7 @@ class GaussNewtonCG:
         self._n, self._n1, self._n2 = n, n1, n2
         self._buf = torch.zeros(6, n, device=dev)           # b, r, r_prev, p, q, delta
         self._state = torch.zeros(8, device=dev)
-        self._state[0] = 1.0                                # rho = ones(1)  (optimizer.py:29)
+        self._state[:1].fill_(1.0)                          # rho = ones(1)  (optimizer.py:29); fill_, not a blocking indexed scalar store
         self._partial = torch.zeros(4 * 64, device=dev)
         self._has_p = False
 
@@ -101,7 +101,7 @@ class GaussNewtonCG:
     def reset_state(self):
         self._has_p = False
         if self._buf is not None:
-            self._state[0] = 1.0
+            self._state[:1].fill_(1.0)
 
     # ---- solver ---------------------------------------------------------------------------
     def run(self, num_cg_iter, num_gn_iter=None):
