@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--trunk-lanes', type=int, default=2, help='concurrent sub-batches (streams) of a trunk pass')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--init-lanes', type=int, default=2, help='concurrent streams for the target-model fits of objects starting together')
+    ap.add_argument('--update-lanes', type=int, default=4, help='concurrent streams for the per-frame target-model updates of different objects')
+    ap.add_argument('--throttle', type=int, default=None, help='launch-queue throttle depth (events of 512 launches; 0 = off)')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
@@ -82,7 +84,7 @@ class StageTimer:
 def run_sequence(tracker, seq):
     """The reference's per-sequence loop (model/tracker.py:130-157) without label decoding to PNG."""
     tracker.current_frame = 0
-    tracker.targets = dict()
+    tracker.release_targets()
     n = 0
     for image, labels, new_objects, feats in tracker.frames_with_features(seq):
         old = set(tracker.targets.keys())
@@ -224,6 +226,10 @@ def main():
     tracker.prefetch_stream = args.overlap
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
+    tracker.update_lanes = args.update_lanes
+    if args.throttle is not None:
+        from frtm_vos_amd import _hip as _H
+        _H.THROTTLE_DEPTH = args.throttle if args.throttle > 0 else 1 << 30
     tracker.eval()
     torch.set_grad_enabled(False)
 
@@ -252,6 +258,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    dev_allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     t0 = time.time()
     n = run_sequence(tracker, seq)
     t_host = time.time() - t0                 # host-side enqueue time (the GPU may still be working)
@@ -298,6 +305,7 @@ def main():
                      'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'host_enqueue_ms_per_step': 1e3 * t_host / n,
+        'device_mallocs_in_timed_region': torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - dev_allocs0,
     }
     if rank == 0 and world == 1 and not args.no_cg_roofline:
         out['roofline_cg'] = cg_roofline(dev, size)

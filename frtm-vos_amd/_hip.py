@@ -63,6 +63,8 @@ SIGNATURES = {
     'frtm_cab_gate': (I, [P, P, I, P, P, P, P, I, I, P, P]),
     'frtm_project_tail': (I, [P, I, I, I, I, P, P, I, I, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
+    'frtm_blur2d': (I, [P, I, I, I, P, I, I, P, P]),
+    'frtm_blur_gauss2d': (I, [P, I, I, I, I, F, F, F, P, P]),
 }
 
 _lib = None
@@ -102,12 +104,39 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Launch-queue throttle.  The host path has no device synchronisation of its own any more, so during the launch-heavy phases
+# (a GN/CG fit is ~1300 launches per object) the host can run thousands of launches ahead of the GPU; beyond a few thousand
+# queued packets the runtime's enqueue path degrades badly (measured: initialize() of 5 objects 81 -> 192 ms).  Every
+# THROTTLE_EVERY calls an event is recorded, and the host waits for the one recorded THROTTLE_DEPTH events ago, which bounds
+# the backlog to ~THROTTLE_EVERY * THROTTLE_DEPTH launches without ever draining the queue.
+THROTTLE_EVERY = 512
+THROTTLE_DEPTH = 4
+_calls = 0
+_marks = []
+
+
+def _throttle():
+    global _calls
+    _calls = 0
+    if torch.cuda.is_current_stream_capturing():
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    _marks.append(ev)
+    if len(_marks) > THROTTLE_DEPTH:
+        _marks.pop(0).synchronize()
+
+
 def call(name, *args):
     """Calls an int-returning entry point on the current torch stream; raises on error."""
+    global _calls
     L = lib()
     rc = getattr(L, name)(*args, stream())
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
+    _calls += 1
+    if _calls >= THROTTLE_EVERY:
+        _throttle()
 
 
 def call_nostream(name, *args):
@@ -117,11 +146,60 @@ def call_nostream(name, *args):
         raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
 
 
+class _Stager:
+    """One pinned ring buffer per device for small host -> device uploads (filter initialisations, blur kernels, id tables).
+    `tensor.to(device)` from pageable memory blocks until the whole GPU queue has drained, and `pin_memory()` per upload
+    asks the driver for pinned pages at unpredictable moments (tens of ms); here the pinned memory is allocated once, a slot
+    is a host memcpy away, the copy itself is asynchronous on the current stream, and a slot is only reused after the event
+    recorded behind its copy has completed."""
+    RING = 16 << 20
+
+    def __init__(self):
+        self.buf = torch.empty(self.RING, dtype=torch.uint8).pin_memory()
+        self.off = 0
+        self.inflight = []          # (start, end, event), oldest first
+
+    def put(self, t, device):
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0 or nbytes > self.RING // 4:
+            return t.to(device)
+        size = (nbytes + 255) // 256 * 256
+        if self.off + size > self.RING:
+            self.off = 0
+        lo, hi = self.off, self.off + size
+        keep = []
+        for (a, b, ev) in self.inflight:
+            if a < hi and lo < b:
+                ev.synchronize()
+            else:
+                keep.append((a, b, ev))
+        self.inflight = keep
+        slot = self.buf[lo:lo + nbytes].view(t.dtype).view(t.shape)
+        slot.copy_(t)
+        out = torch.empty(t.shape, dtype=t.dtype, device=device)
+        out.copy_(slot, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((lo, hi, ev))
+        self.off = hi
+        return out
+
+
+_stagers = {}
+
+
 def upload(t, device):
-    """CPU tensor -> device without stalling the host: staged through (cached) pinned memory, asynchronous on the current stream."""
+    """CPU tensor -> device without stalling the host (see _Stager)."""
     if t.is_cuda or device is None or torch.device(device).type != 'cuda':
         return t.to(device)
-    return t.contiguous().pin_memory().to(device, non_blocking=True)
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _stagers.get(key)
+    if st is None:
+        st = _stagers[key] = _Stager()
+    with torch.cuda.device(key):
+        return st.put(t, dev)
 
 
 def require_gpu(t, what):

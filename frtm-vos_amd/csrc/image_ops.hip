@@ -68,3 +68,69 @@ extern "C" int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* 
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
+
+// Motion / Gaussian blur of the augmenter (reference augmenter.py:330-345 uses cv2.filter2D; here the same cross-correlation
+// with zero padding that F.conv2d(x, G, padding=k//2) computes, without going through MIOpen: its per-configuration "find"
+// step takes ~100 ms whenever a blur size shows up for the first time, in the middle of a timed sequence).
+// One 16x16 output tile per block; the (16+kh-1) x (16+kw-1) input patch and G sit in LDS.
+#define BL_T 16
+// G == nullptr: the kernel is the normalised anisotropic Gaussian exp(-(qa x^2 + 2 qb x y + qc y^2) / 2), x = j - kw/2,
+// y = i - kh/2, built here from its three numbers -- nothing to upload from the host.
+__global__ __launch_bounds__(256) void k_blur2d(const float* __restrict__ src, int H, int W, const float* __restrict__ G, int kh, int kw,
+                                                 float qa, float qb, float qc, float* __restrict__ dst) {
+  extern __shared__ float sm[];
+  __shared__ float red[16];
+  const int ph = BL_T + kh - 1, pw = BL_T + kw - 1;
+  float* patch = sm;                 // ph x pw
+  float* g = sm + ph * pw;           // kh x kw
+  const int pl = blockIdx.z, y0 = blockIdx.y * BL_T, x0 = blockIdx.x * BL_T;
+  const float* s = src + (size_t)pl * H * W;
+  for (int i = threadIdx.x; i < ph * pw; i += 256) {
+    const int r = i / pw, c = i - r * pw;
+    patch[i] = fetch(s, H, W, y0 + r - kh / 2, x0 + c - kw / 2);
+  }
+  if (G) {
+    for (int i = threadIdx.x; i < kh * kw; i += 256) g[i] = G[i];
+    __syncthreads();
+  } else {
+    float part = 0.f;
+    for (int i = threadIdx.x; i < kh * kw; i += 256) {
+      const float yy = (float)(i / kw - kh / 2), xx = (float)(i % kw - kw / 2);
+      const float v = expf(-0.5f * (qa * xx * xx + 2.f * qb * xx * yy + qc * yy * yy));
+      g[i] = v;
+      part += v;
+    }
+    const float inv = 1.f / block_sum(part, red);        // contains the barriers
+    for (int i = threadIdx.x; i < kh * kw; i += 256) g[i] *= inv;
+    __syncthreads();
+  }
+  const int ty = threadIdx.x / BL_T, tx = threadIdx.x % BL_T;
+  const int y = y0 + ty, x = x0 + tx;
+  if (y >= H || x >= W) return;
+  float acc = 0.f;
+  for (int i = 0; i < kh; ++i)
+    for (int j = 0; j < kw; ++j) acc += g[i * kw + j] * patch[(ty + i) * pw + tx + j];
+  dst[(size_t)pl * H * W + (size_t)y * W + x] = acc;
+}
+
+extern "C" int frtm_blur2d(const float* src, int planes, int H, int W, const float* G, int kh, int kw, float* dst, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(src && dst && G && planes > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && (kh & 1) && (kw & 1), "frtm_blur2d: bad argument (odd kernel sizes only)");
+  const size_t lds = ((size_t)(BL_T + kh - 1) * (BL_T + kw - 1) + (size_t)kh * kw) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_blur2d: %dx%d kernel too large for the LDS tile", kh, kw);
+  dim3 g(ceil_div(W, BL_T), ceil_div(H, BL_T), planes);
+  k_blur2d<<<g, 256, lds, (hipStream_t)stream>>>(src, H, W, G, kh, kw, 0.f, 0.f, 0.f, dst);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+extern "C" int frtm_blur_gauss2d(const float* src, int planes, int H, int W, int half, float qa, float qb, float qc, float* dst,
+                                 frtm_stream_t stream) {
+  FRTM_CHECK_ARG(src && dst && planes > 0 && H > 0 && W > 0 && half >= 0, "frtm_blur_gauss2d: bad argument");
+  const int k = 2 * half + 1;
+  const size_t lds = ((size_t)(BL_T + k - 1) * (BL_T + k - 1) + (size_t)k * k) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_blur_gauss2d: half width %d too large for the LDS tile", half);
+  dim3 g(ceil_div(W, BL_T), ceil_div(H, BL_T), planes);
+  k_blur2d<<<g, 256, lds, (hipStream_t)stream>>>(src, H, W, nullptr, k, k, qa, qb, qc, dst);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}

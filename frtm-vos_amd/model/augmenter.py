@@ -88,11 +88,10 @@ class ImageAugmenter:
             cov = R @ np.diag((bs, 0.1)) @ R.T
             half = int(bs / 2 + 0.5)
             half = half + (half + 1) % 2
-            r = np.arange(-half, half + 1)
-            X = np.stack(np.meshgrid(r, r))
-            q = (X * np.tensordot(np.linalg.inv(cov), X, axes=[1, 0])).sum(0)
-            G = np.exp(-0.5 * q)
-            G = (G / G.sum()).astype(np.float32)
+            # normalised Gaussian exp(-x^T cov^-1 x / 2) on [-half, half]^2; the kernel itself is formed on the device
+            # (frtm_blur_gauss2d) from the inverse covariance: no array to upload
+            icov = np.linalg.inv(cov)
+            G = ('gauss', int(half), float(icov[0, 0]), float(0.5 * (icov[0, 1] + icov[1, 0])), float(icov[1, 1]))
         return T, G
 
     # ---- image pieces -----------------------------------------------------------------------------
@@ -130,10 +129,19 @@ class ImageAugmenter:
 
     @staticmethod
     def _blur(x, G):
+        """x: (C,H,W) planes; G: ('gauss', half, qa, qb, qc) from _transform, or an explicit (kh,kw) numpy kernel -> blurred
+        planes (zero padding).  HIP kernels: no MIOpen on the path."""
         if G is None:
             return x
-        k = H.upload(torch.from_numpy(np.ascontiguousarray(G)), x.device)[None, None]
-        return F.conv2d(x[:, None], k, padding=(G.shape[0] // 2, G.shape[1] // 2))[:, 0]
+        src = x.float().contiguous()
+        out = torch.empty_like(src)
+        if isinstance(G, tuple):
+            _, half, qa, qb, qc = G
+            H.call('frtm_blur_gauss2d', H.ptr(src), src.shape[0], src.shape[1], src.shape[2], half, qa, qb, qc, H.ptr(out))
+            return out
+        k = H.upload(torch.from_numpy(np.ascontiguousarray(G, dtype=np.float32)), x.device)
+        H.call('frtm_blur2d', H.ptr(src), src.shape[0], src.shape[1], src.shape[2], H.ptr(k), G.shape[0], G.shape[1], H.ptr(out))
+        return out
 
     def augment_first_frame(self, im, lb):
         p = self.params

@@ -60,6 +60,16 @@ class DiscriminatorLoss(MinimizationProblem):
             self.g1 = torch.empty(C * self.c, device=dev)
             self._xt_for = None
 
+    def rebind(self, filter_regs, precond, filter_weight, project_weight=None):
+        """Serve another object on the same memory: new variables / regularisation, cached derived data dropped."""
+        assert (project_weight is not None) == self.joint
+        self.w1, self.w2 = project_weight, filter_weight
+        self.filter_regs = TensorList([float(v) for v in filter_regs])
+        self.diag_M = TensorList([float(v) for v in precond])
+        self.N = 0
+        if self.joint:
+            self._xt_for = None
+
     # ---- protocol -----------------------------------------------------------------------
     def initialize(self):
         """Active samples = the first current_size slots (reference discriminator.py:38-43 selects
@@ -206,8 +216,14 @@ class Discriminator(nn.Module):
         self.keep_hires = keep_hires     # also store full-resolution labels / pixel weights (DiscriminatorLoss.__call__)
         if out_channels != 1:
             raise ValueError('the target model scores one channel (reference evaluate.py:78)')
-        self.project = conv(in_channels, c_channels, 1, bias=False)
-        self.filter = conv(c_channels, out_channels, 3, bias=False)
+        # Layers of the reference (:86-87).  Their weights are drawn ON THE DEVICE from the distribution nn.Conv2d's default
+        # initialisation uses, kaiming_uniform_(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)): the reference draws them before
+        # it seeds anything (tracker.py:174-180), so there is no stream to reproduce, and a host-side draw would have to be
+        # uploaded (a blocking copy, or pinned staging) for every new object.
+        dev_ok = device is not None and torch.device(device).type == 'cuda'
+        kw = dict(device=device) if dev_ok else {}
+        self.project = nn.Conv2d(in_channels, c_channels, 1, bias=False, **kw)
+        self.filter = nn.Conv2d(c_channels, out_channels, 3, padding=1, bias=False, **kw)
         self.layer = layer
         self.init_iters = init_iters
         self.update_iters = update_iters
@@ -220,17 +236,48 @@ class Discriminator(nn.Module):
         self.pw_params = pixel_weighting
         self.device = device
         self.update_filters = update_filters
-        # the weights are drawn on the CPU (same generator stream as the reference) and uploaded through pinned memory without
-        # blocking: a plain .to(device) waits for the whole GPU queue to drain
         for p in self.parameters():
             p.requires_grad_(False)
-            p.data = H.upload(p.data, device)
+        if not dev_ok:
+            self.to(device)
         self.frame_num = 0
         self.update_optimizer = None
         self.current_sample = None
         self.memory = None
         self._w1T = None
         self._w1T_key = None
+        self._ws = {}                    # recycled state: memories and problems of the previous object this instance served
+
+    def recycle(self):
+        """Prepares this instance for a NEW object: fresh weights drawn like a newly constructed Discriminator, counters reset; the memories / problem buffers (~150 MB at 480p)
+        stay allocated and are reused by the next init().  Nothing is freed or allocated on the device."""
+        self.project.reset_parameters()        # in place, on the device
+        self.filter.reset_parameters()
+        self.frame_num = 0
+        self.update_optimizer = None
+        self.current_sample = None
+        self.memory = None
+        self._invalidate()
+        return self
+
+    def _memory(self, tag, capacity, feature_size, labels_size, dev):
+        m = self._ws.get(tag)
+        if m is None or not m.matches(capacity, feature_size, labels_size, keep_hires=self.keep_hires) or m.device != torch.device(dev):
+            m = self._ws[tag] = Memory(capacity, feature_size, labels_size, dev, self.learning_rate, pixel_weighting=self.pw_params,
+                                       keep_hires=self.keep_hires)
+            self._ws.pop(tag + '_problem', None)
+        else:
+            m.reset()
+            m.pw_params, m.learning_rates = self.pw_params, self.learning_rate
+        return m
+
+    def _problem(self, tag, memory, regs, precond, joint):
+        pr = self._ws.get(tag)
+        if pr is None or pr.mem is not memory:
+            pr = self._ws[tag] = DiscriminatorLoss(memory, regs, precond, self.filter.weight, self.project.weight if joint else None)
+        else:
+            pr.rebind(regs, precond, self.filter.weight, self.project.weight if joint else None)
+        return pr
 
     # ---- projection weights in GEMM layout ------------------------------------------------
     def _project_T(self):
@@ -266,20 +313,18 @@ class Discriminator(nn.Module):
         K = x.shape[0]
         dev = x.device
         # joint fit of (project, filter) on the K raw samples
-        mem0 = Memory(K, x.shape[-3:], y.shape[-3:], dev, self.learning_rate, pixel_weighting=self.pw_params,
-                      keep_hires=self.keep_hires)
+        mem0 = self._memory('mem0', K, x.shape[-3:], y.shape[-3:], dev)
         mem0.initialize(x, y)
-        problem = DiscriminatorLoss(mem0, self.filter_reg, self.precond, self.filter.weight, self.project.weight)
+        problem = self._problem('mem0_problem', mem0, self.filter_reg, self.precond, True)
         optimizer = GaussNewtonCG(problem, TensorList([self.project.weight, self.filter.weight]), fletcher_reeves=False,
                                   standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
         optimizer.run(self.init_iters)
         self._invalidate()
         xp = ops.conv2d(x, self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)   # re-project (:178)
         # memory + filter-only problem used for the rest of the sequence
-        memory = Memory(self.memory_size, xp.shape[-3:], y.shape[-3:], dev, self.learning_rate,
-                        pixel_weighting=self.pw_params, keep_hires=self.keep_hires)
+        memory = self._memory('memory', self.memory_size, xp.shape[-3:], y.shape[-3:], dev)
         memory.initialize(xp, y)
-        problem = DiscriminatorLoss(memory, self.filter_reg[1:], self.precond[1:], self.filter.weight)
+        problem = self._problem('memory_problem', memory, self.filter_reg[1:], self.precond[1:], False)
         optimizer = GaussNewtonCG(problem, TensorList([self.filter.weight]), fletcher_reeves=False,
                                   standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
         optimizer.run(self.update_iters)

@@ -74,6 +74,17 @@ class Memory:
         self.current_size = 0
         self.weights.zero_()
 
+    def reset(self):
+        """Back to the state after construction (buffers are kept: a recycled memory serves the next object)."""
+        self.clear()
+        self._slot.fill_(-1)
+        self._have_prev = False
+
+    def matches(self, capacity, feature_size, labels_size, grid_size=None, keep_hires=False):
+        grid = tuple(grid_size) if grid_size is not None else tuple(feature_size[-2:])
+        return (self._capacity == capacity and tuple(self.samples.shape[1:]) == tuple(feature_size) and
+                self.labels_size == tuple(labels_size) and self.grid == grid and self.keep_hires == keep_hires)
+
     def _build_normals(self, labels, pixel_weights, n, slot_dev, slot_host):
         Hh, Ww = self.labels_size[-2:]
         lab = labels.reshape(n, Hh, Ww)

@@ -31,9 +31,10 @@ from .discriminator import Discriminator
 
 class TargetObject:
 
-    def __init__(self, obj_id, disc_params, **kwargs):
+    def __init__(self, obj_id, disc_params, discriminator=None, **kwargs):
         self.object_id = obj_id
-        self.discriminator = Discriminator(**disc_params)
+        # `discriminator`: a recycled instance (Tracker.release_targets); it re-draws its weights like a new one would
+        self.discriminator = discriminator.recycle() if discriminator is not None else Discriminator(**disc_params)
         self.disc_layer = disc_params.layer
         self.start_frame = None
         self.start_mask = None
@@ -56,7 +57,9 @@ class Tracker(nn.Module):
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
         self.graph_trunk = True
         self.init_lanes = 2              # objects starting on the same frame are fitted on this many concurrent streams
+        self.update_lanes = 4            # per-frame target-model updates of different objects on this many concurrent streams
         self._init_pool = []
+        self._disc_pool = []
         self.graph_refiner = True
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
         self.augmenter = augmenter
@@ -72,6 +75,15 @@ class Tracker(nn.Module):
         self.current_frame = 0
         self.current_masks = None
         self.num_objects = 0
+        self.targets = dict()
+
+    def release_targets(self):
+        """Ends a sequence: the target models go back to a pool and serve the next sequence's objects, so that the steady
+        state allocates nothing on the device (hipMalloc / hipFree stall the queue for milliseconds at arbitrary moments)."""
+        for t in self.targets.values():
+            if t.discriminator is not None and len(self._disc_pool) < 64:
+                self._disc_pool.append(t.discriminator)
+                t.discriminator = None
         self.targets = dict()
 
     def _init_streams(self, n):
@@ -116,7 +128,7 @@ class Tracker(nn.Module):
         self.eval()
         self.object_ids = sequence.obj_ids
         self.current_frame = 0
-        self.targets = dict()
+        self.release_targets()
         N = 0
         object_ids = H.upload(torch.tensor([0] + list(sequence.obj_ids), dtype=torch.uint8), self.device)
         if speedrun:
@@ -124,7 +136,7 @@ class Tracker(nn.Module):
             self.initialize(image.to(self.device), labels.to(self.device), sequence.obj_ids)
             self.track(image.to(self.device))
             torch.cuda.synchronize()
-            self.targets = dict()
+            self.release_targets()
         outputs = []
         t0 = time()
         for i, (image, labels, new_objects, feats) in enumerate(self.frames_with_features(sequence)):
@@ -214,6 +226,7 @@ class Tracker(nn.Module):
         for obj_id in new_objects:
             mask = (labels == obj_id).byte()
             target = TargetObject(obj_id=obj_id, index=len(self.targets) + 1, disc_params=self.disc_params,
+                                  discriminator=self._disc_pool.pop() if self._disc_pool else None,
                                   start_frame=self.current_frame, start_mask=mask)
             self.targets[obj_id] = target
             torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept:
@@ -267,10 +280,18 @@ class Tracker(nn.Module):
             counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync
             solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
             host = counts.tolist() if solve else None                                        # one D2H only on re-solve frames
+            # the objects' updates (memory insert, every 8th frame a CG re-solve) are independent: round-robin on side streams
+            cur = torch.cuda.current_stream()
+            lanes = self._init_streams(min(len(active), self.update_lanes)) if len(active) > 1 and self.update_lanes > 1 else []
+            for st in lanes:
+                st.wait_stream(cur)
             for k, t in enumerate(active):
                 y = self.current_masks[t.index].unsqueeze(0).unsqueeze(0)
-                if host is not None:
-                    t.discriminator.update(y, num_positive=host[t.index])
-                else:
-                    t.discriminator.update(y, count_dev=counts[t.index:t.index + 1])
+                with torch.cuda.stream(lanes[k % len(lanes)] if lanes else cur):
+                    if host is not None:
+                        t.discriminator.update(y, num_positive=host[t.index])
+                    else:
+                        t.discriminator.update(y, count_dev=counts[t.index:t.index + 1])
+            for st in lanes:
+                cur.wait_stream(st)
         return self.current_masks

@@ -257,6 +257,14 @@ int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream
 int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd,
                      const float* fwd6_host, int mode, frtm_stream_t stream);
 
+/* dst[p,y,x] = sum_{i,j} G[i,j] * src[p, y+i-kh/2, x+j-kw/2], zero outside (the augmenter's blur, model/augmenter.py:330-345:
+ * cv2.filter2D / F.conv2d(padding=k//2) semantics).  G: DEVICE float[kh*kw], odd kh, kw. */
+int frtm_blur2d(const float* src, int planes, int H, int W, const float* G, int kh, int kw, float* dst, frtm_stream_t stream);
+/* The same with G = the normalised Gaussian exp(-(qa x^2 + 2 qb x y + qc y^2)/2) on [-half, half]^2 (x along the row), formed
+ * inside the kernel from the inverse covariance (qa qb; qb qc): the augmenter's motion blur with no host -> device upload. */
+int frtm_blur_gauss2d(const float* src, int planes, int H, int W, int half, float qa, float qb, float qc, float* dst,
+                      frtm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

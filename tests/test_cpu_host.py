@@ -158,7 +158,10 @@ def test_augmenter_transform_and_draws():
     assert G is None and np.allclose(Tm @ np.array([100.0, 50.0, 1.0]), [427.0, 240.0, 1.0])    # target centre -> image centre
     spec.update(fliplr=True, scale=2.0, blur_size=2.0, blur_angle=45)
     Tm, G = aug._transform(spec, (100.0, 50.0, 40, 30), (480, 854))
-    assert np.allclose(Tm[:2, :2], [[-2, 0], [0, 2]]) and G.shape[0] % 2 == 1 and abs(G.sum() - 1) < 1e-5
+    # blur: ('gauss', half, qa, qb, qc) = the inverse covariance of R diag(bs, 0.1) R^T; the kernel is formed on the device
+    assert np.allclose(Tm[:2, :2], [[-2, 0], [0, 2]]) and G[0] == 'gauss' and G[1] >= 1
+    icov = np.array([[G[2], G[3]], [G[3], G[4]]])
+    assert np.allclose(np.sort(np.linalg.eigvalsh(np.linalg.inv(icov))), [0.1, 2.0], atol=1e-6)
 
 
 def test_synthetic_sequence_protocol():

@@ -417,6 +417,28 @@ def test_tracker_mask_flow_g6(golden):
             trk.current_frame += 1
 
 
+def test_blur2d_matches_conv2d():
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    g = gen(41)
+    x = torch.rand(4, 37, 53, generator=g) * 255
+    for kh, kw in ((3, 3), (7, 15), (21, 21), (1, 9)):
+        G = torch.rand(kh, kw, generator=g)
+        G = (G / G.sum()).numpy()
+        out = ImageAugmenter._blur(x.to(DEV), G)
+        ref = F.conv2d(x[:, None], torch.from_numpy(G)[None, None], padding=(kh // 2, kw // 2))[:, 0]
+        assert rel(out, ref) < 1e-5, (kh, kw)
+    # the analytic Gaussian of ImageAugmenter._transform, formed on the device, against the same kernel built with numpy
+    import numpy as np
+    _, Gs = ImageAugmenter._transform(dict(blur_size=9.0, blur_angle=30.0, location=(0.5, 0.5)), (20, 20, 10, 10), (37, 53))
+    half = Gs[1]
+    r = np.arange(-half, half + 1)
+    X = np.stack(np.meshgrid(r, r))
+    q = Gs[2] * X[0] ** 2 + 2 * Gs[3] * X[0] * X[1] + Gs[4] * X[1] ** 2
+    Gn = np.exp(-0.5 * q)
+    Gn = (Gn / Gn.sum()).astype(np.float32)
+    assert rel(ImageAugmenter._blur(x.to(DEV), Gs), ImageAugmenter._blur(x.to(DEV), Gn)) < 1e-5
+
+
 def test_warp_affine():
     from frtm_vos_amd.lib.image import warp_affine
     src = torch.rand(3, 40, 50, generator=gen(4)).to(DEV)

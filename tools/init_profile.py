@@ -18,7 +18,7 @@ seq.preload('cuda:0')
 image, labels, new_objects = seq[0]
 image, labels = image.cuda(), labels.cuda()
 for rep in range(3):
-    trk.targets = dict()
+    trk.release_targets()
     torch.cuda.synchronize()
     t0 = time.time()
     trk.initialize(image, labels, new_objects)
@@ -26,7 +26,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.time()
     print('initialize(): host enqueue %.2f ms, until GPU done %.2f ms' % (1e3 * (t1 - t0), 1e3 * (t2 - t0)))
-trk.targets = dict()
+trk.release_targets()
 pr = cProfile.Profile()
 pr.enable()
 trk.initialize(image, labels, new_objects)
