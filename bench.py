@@ -43,9 +43,7 @@ def parse():
     ap.add_argument('--trunk-batch', type=int, default=8, help='frames per trunk pass (1 = frame by frame like the reference)')
     ap.add_argument('--trunk-lanes', type=int, default=2, help='concurrent sub-batches (streams) of a trunk pass')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
-    ap.add_argument('--init-lanes', type=int, default=2, help='concurrent streams for the target-model fits of objects starting together')
-    ap.add_argument('--update-lanes', type=int, default=4, help='concurrent streams for the per-frame target-model updates of different objects')
-    ap.add_argument('--throttle', type=int, default=None, help='launch-queue throttle depth (events of 512 launches; 0 = off)')
+    ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
@@ -226,10 +224,6 @@ def main():
     tracker.prefetch_stream = args.overlap
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
-    tracker.update_lanes = args.update_lanes
-    if args.throttle is not None:
-        from frtm_vos_amd import _hip as _H
-        _H.THROTTLE_DEPTH = args.throttle if args.throttle > 0 else 1 << 30
     tracker.eval()
     torch.set_grad_enabled(False)
 

@@ -104,39 +104,12 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Launch-queue throttle.  The host path has no device synchronisation of its own any more, so during the launch-heavy phases
-# (a GN/CG fit is ~1300 launches per object) the host can run thousands of launches ahead of the GPU; beyond a few thousand
-# queued packets the runtime's enqueue path degrades badly (measured: initialize() of 5 objects 81 -> 192 ms).  Every
-# THROTTLE_EVERY calls an event is recorded, and the host waits for the one recorded THROTTLE_DEPTH events ago, which bounds
-# the backlog to ~THROTTLE_EVERY * THROTTLE_DEPTH launches without ever draining the queue.
-THROTTLE_EVERY = 512
-THROTTLE_DEPTH = 4
-_calls = 0
-_marks = []
-
-
-def _throttle():
-    global _calls
-    _calls = 0
-    if torch.cuda.is_current_stream_capturing():
-        return
-    ev = torch.cuda.Event()
-    ev.record()
-    _marks.append(ev)
-    if len(_marks) > THROTTLE_DEPTH:
-        _marks.pop(0).synchronize()
-
-
 def call(name, *args):
     """Calls an int-returning entry point on the current torch stream; raises on error."""
-    global _calls
     L = lib()
     rc = getattr(L, name)(*args, stream())
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, L.frtm_last_error().decode()))
-    _calls += 1
-    if _calls >= THROTTLE_EVERY:
-        _throttle()
 
 
 def call_nostream(name, *args):

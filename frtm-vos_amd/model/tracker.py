@@ -56,8 +56,7 @@ class Tracker(nn.Module):
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
         self.graph_trunk = True
-        self.init_lanes = 2              # objects starting on the same frame are fitted on this many concurrent streams
-        self.update_lanes = 4            # per-frame target-model updates of different objects on this many concurrent streams
+        self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
@@ -280,18 +279,10 @@ class Tracker(nn.Module):
             counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync
             solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
             host = counts.tolist() if solve else None                                        # one D2H only on re-solve frames
-            # the objects' updates (memory insert, every 8th frame a CG re-solve) are independent: round-robin on side streams
-            cur = torch.cuda.current_stream()
-            lanes = self._init_streams(min(len(active), self.update_lanes)) if len(active) > 1 and self.update_lanes > 1 else []
-            for st in lanes:
-                st.wait_stream(cur)
             for k, t in enumerate(active):
                 y = self.current_masks[t.index].unsqueeze(0).unsqueeze(0)
-                with torch.cuda.stream(lanes[k % len(lanes)] if lanes else cur):
-                    if host is not None:
-                        t.discriminator.update(y, num_positive=host[t.index])
-                    else:
-                        t.discriminator.update(y, count_dev=counts[t.index:t.index + 1])
-            for st in lanes:
-                cur.wait_stream(st)
+                if host is not None:
+                    t.discriminator.update(y, num_positive=host[t.index])
+                else:
+                    t.discriminator.update(y, count_dev=counts[t.index:t.index + 1])
         return self.current_masks
