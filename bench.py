@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--trunk-lanes', type=int, default=2, help='concurrent sub-batches (streams) of a trunk pass')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')
+    ap.add_argument('--no-windows', action='store_true', help='track frame by frame instead of one window per filter re-solve interval')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
@@ -80,19 +81,10 @@ class StageTimer:
 
 
 def run_sequence(tracker, seq):
-    """The reference's per-sequence loop (model/tracker.py:130-157) without label decoding to PNG."""
-    tracker.current_frame = 0
-    tracker.release_targets()
-    n = 0
-    for image, labels, new_objects, feats in tracker.frames_with_features(seq):
-        old = set(tracker.targets.keys())
-        if len(new_objects) > 0:
-            tracker.initialize(image, labels, new_objects)
-        if len(old) > 0:
-            tracker.track(image, feats)
-        tracker.current_frame += 1
-        n += 1
-    return n
+    """The reference's per-sequence loop (model/tracker.py:103-163), label decoding included, PNG writing not (that is
+    run_dataset's part, outside the reference's timed region as well).  Returns the number of frames."""
+    outputs, _ = tracker.run_sequence(seq)
+    return len(outputs)
 
 
 def cpu_baseline(args, size, n_frames):
@@ -224,6 +216,7 @@ def main():
     tracker.prefetch_stream = args.overlap
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
+    tracker.window_tracking = not args.no_windows
     tracker.eval()
     torch.set_grad_enabled(False)
 
@@ -238,7 +231,8 @@ def main():
 
     # untimed set-up sequence: at least two full trunk passes so that every hipGraph the timed frames replay (trunk pass,
     # refiner per tap slice) has been captured -- W warm-up steps as requested, more if W is shorter than that
-    warm_frames = max(args.warmup, 2 * args.trunk_batch + 1, 2)
+    # + the length of the timed sequence's last (partial) trunk pass / tracking window, so that shape is captured as well
+    warm_frames = max(args.warmup, 2 * args.trunk_batch + 1 + (args.steps - 1) % args.trunk_batch, 2)
     warm = SyntheticSequence('warm', warm_frames, size, args.objects, seed=100 + rank)
     seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank, late_object_at=args.late_object)
     warm.preload(dev)

@@ -56,7 +56,7 @@ SIGNATURES = {
     'frtm_merge_masks': (I, [P, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),
     'frtm_bilinear_resize': (I, [P, I, I, I, P, I, I, P]),
-    'frtm_tse_inject': (I, [P, P, P, P, I, I, I, I, I, I, P, P]),
+    'frtm_tse_inject': (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     'frtm_cab_combine': (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     'frtm_pyrup2x': (I, [P, I, I, I, P, P]),
     'frtm_plane_mean': (I, [P, I, I, P, P]),

@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void k_bilinear_resize(const float* __restrict
 #define INJ_CG 4      // channel groups per object (more workgroups on the small maps)
 __global__ __launch_bounds__(256) void k_tse_inject(const float* __restrict__ base, const float* __restrict__ bias, const float* __restrict__ ws,
                                                      const float* __restrict__ scores, int C, int h, int w, int H, int W,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, int group) {
   __shared__ float S[INJ_T + 2][INJ_T + 2];
   const int n = blockIdx.z / INJ_CG, cg = blockIdx.z % INJ_CG;
+  base += (size_t)(n / group) * C * H * W;                  // `group` consecutive samples (the objects of one frame) share a base map
   const int cper = (C + INJ_CG - 1) / INJ_CG, c_lo = cg * cper, c_hi = min(C, c_lo + cper);
   const int ty0 = blockIdx.y * INJ_T, tx0 = blockIdx.x * INJ_T;
   const float* sc = scores + (size_t)n * h * w;
@@ -80,16 +81,18 @@ __global__ __launch_bounds__(256) void k_tse_inject(const float* __restrict__ ba
 }
 
 // CAB combine (seg_network.py:38-41): out = shallower * sigmoid(gate[n,c]) + bilinear(deeper[n,c], (hd,wd) -> (H,W)).
-// deeper_nstride = 0 broadcasts one deeper tensor over the objects (the pooled vector of the deepest level).
+// deeper_group g > 0: samples s use deeper[s / g] (the pooled vector of the deepest level is shared by the objects of a frame);
+// g = 0: one deeper map per sample.
 __global__ __launch_bounds__(256) void k_cab_combine(const float* __restrict__ shallow, const float* __restrict__ gate, const float* __restrict__ deeper,
-                                                      int C, int hd, int wd, size_t deeper_nstride, int H, int W, float* __restrict__ out,
+                                                      int C, int hd, int wd, int deeper_group, int H, int W, float* __restrict__ out,
                                                       size_t total) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int x = (int)(i % W), y = (int)((i / W) % H);
     const size_t pl = i / ((size_t)W * H);                  // n*C + c
     const int c = (int)(pl % C); const size_t n = pl / C;
     const float g = 1.f / (1.f + __expf(-gate[pl]));
-    const float d = bilinear_at(deeper + n * deeper_nstride + (size_t)c * hd * wd, hd, wd, H, W, y, x);
+    const size_t dn = deeper_group > 0 ? n / deeper_group : n;
+    const float d = bilinear_at(deeper + (dn * C + c) * hd * wd, hd, wd, H, W, y, x);
     out[i] = shallow[i] * g + d;
   }
 }
@@ -99,13 +102,14 @@ __global__ __launch_bounds__(256) void k_cab_combine(const float* __restrict__ s
 // k_cab_combine).  sp / dp: pooled shallower / deeper features (n,oc); dp_stride = 0 broadcasts one deeper vector.  W1 (2oc,oc),
 // W2 (oc,oc) are the 1x1 conv weights transposed to [in][out].  One block per object: four framework launches (cat, addmm, relu,
 // addmm) become one.
-__global__ __launch_bounds__(256) void k_cab_gate(const float* __restrict__ sp, const float* __restrict__ dp, int dp_stride,
+__global__ __launch_bounds__(256) void k_cab_gate(const float* __restrict__ sp, const float* __restrict__ dp, int dp_group,
                                                    const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                                                    const float* __restrict__ b2, int oc, float* __restrict__ gate) {
   extern __shared__ float sm[];                      // [2oc] input, [oc] hidden, [4][oc] partial sums
   float* v = sm; float* hid = sm + 2 * oc; float* part = sm + 3 * oc;
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 2 * oc; i += 256) v[i] = i < oc ? sp[(size_t)n * oc + i] : dp[(size_t)n * dp_stride + i - oc];
+  const size_t dn = dp_group > 0 ? n / dp_group : n;
+  for (int i = tid; i < 2 * oc; i += 256) v[i] = i < oc ? sp[(size_t)n * oc + i] : dp[dn * oc + i - oc];
   __syncthreads();
   // each output is summed by 4 threads over a quarter of the inputs (independent loads in flight), then combined in fixed order
   const int q = tid >> 6, lane = tid & 63;
@@ -372,30 +376,30 @@ int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, 
   return FRTM_OK;
 }
 
-int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int C, int h, int w, int H, int W,
-                    float* out, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(base && bias && ws && scores && out && n > 0 && C > 0, "frtm_tse_inject: bad argument");
+int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int group, int C, int h, int w, int H,
+                    int W, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(base && bias && ws && scores && out && n > 0 && C > 0 && group > 0 && n % group == 0, "frtm_tse_inject: bad argument");
   dim3 g(ceil_div(W, INJ_T), ceil_div(H, INJ_T), n * INJ_CG);
-  k_tse_inject<<<g, 256, 0, (hipStream_t)stream>>>(base, bias, ws, scores, C, h, w, H, W, out);
+  k_tse_inject<<<g, 256, 0, (hipStream_t)stream>>>(base, bias, ws, scores, C, h, w, H, W, out, group);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
 
-int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd, int deeper_shared, int H,
+int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd, int deeper_group, int H,
                      int W, float* out, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(shallow && gate && deeper && out && n > 0 && C > 0, "frtm_cab_combine: bad argument");
+  FRTM_CHECK_ARG(shallow && gate && deeper && out && n > 0 && C > 0 && deeper_group >= 0, "frtm_cab_combine: bad argument");
   const size_t total = (size_t)n * C * H * W;
   k_cab_combine<<<(int)min((total + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(
-      shallow, gate, deeper, C, hd, wd, deeper_shared ? 0 : (size_t)C * hd * wd, H, W, out, total);
+      shallow, gate, deeper, C, hd, wd, deeper_group, H, W, out, total);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
 
-int frtm_cab_gate(const float* sp, const float* dp, int dp_shared, const float* W1, const float* b1, const float* W2, const float* b2,
+int frtm_cab_gate(const float* sp, const float* dp, int dp_group, const float* W1, const float* b1, const float* W2, const float* b2,
                   int n, int oc, float* gate, frtm_stream_t stream) {
   FRTM_CHECK_ARG(sp && dp && W1 && b1 && W2 && b2 && gate && n > 0 && oc > 0 && oc <= 4096, "frtm_cab_gate: bad argument");
   FRTM_CHECK_ARG(oc % 4 == 0, "frtm_cab_gate: oc must be a multiple of 4 (got %d)", oc);
-  k_cab_gate<<<n, 256, 7 * oc * sizeof(float), (hipStream_t)stream>>>(sp, dp, dp_shared ? 0 : oc, W1, b1, W2, b2, oc, gate);
+  k_cab_gate<<<n, 256, 7 * oc * sizeof(float), (hipStream_t)stream>>>(sp, dp, dp_group, W1, b1, W2, b2, oc, gate);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

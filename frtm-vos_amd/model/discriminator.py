@@ -339,6 +339,23 @@ class Discriminator(nn.Module):
         self.current_sample = cft
         return ops.filter_scores(cft, self.filter.weight.data)
 
+    def apply_window(self, ft):
+        """Scores for a WINDOW of frames at once: ft (W,Cin,h,w) -> (projected features (W,c,h,w), scores (W,1,h,w)).  Pure:
+        neither the frame counter nor ``current_sample`` move; the caller replays the per-frame bookkeeping with ``advance``.
+        Valid for frames between two filter re-solves (the filter is constant there, reference :221-227)."""
+        H.require_gpu(ft, 'Discriminator.apply_window')
+        cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)
+        return cft, ops.filter_scores(cft, self.filter.weight.data)
+
+    def advance(self, cft_frame):
+        """The bookkeeping half of apply() (:202-205) for one frame of a window: frame counter and the sample update() stores."""
+        self.frame_num += 1
+        self.current_sample = cft_frame
+
+    def frames_until_solve(self):
+        """Number of coming frames up to and including the next filter re-solve (>= 1)."""
+        return self.train_skipping - (self.frame_num % self.train_skipping)
+
     def update(self, train_y, num_positive=None, count_dev=None):
         """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
         The reference's early-out "fewer than 10 pixels above 0.5" (:214) needs the pixel count:

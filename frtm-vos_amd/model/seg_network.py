@@ -162,8 +162,10 @@ class SegNetwork(nn.Module):
         return red, F.adaptive_avg_pool2d(red[first], (1, 1))
 
     def forward(self, scores, features, image_size, shared=None):
-        """scores: (n,1,h,w) coarse scores of n objects on the same frame; features: backbone taps (batch 1);
-        returns (n,1,H,W) logits (reference seg_network.py:176-189 evaluates one object per call)."""
+        """scores: (F*n,1,h,w) coarse scores of n objects on each of F frames, frame-major (sample = f*n + k); features: backbone
+        taps of those F frames, (F,C,H,W) each (F = 1: the n objects of one frame); returns (F*n,1,H,W) logits.  The reference
+        (seg_network.py:176-189) evaluates one object of one frame per call; frames between two filter re-solves do not depend
+        on each other, so the tracker hands over a whole window of them."""
         if scores.is_cuda and not self.training and not torch.is_grad_enabled() and shared is None:
             if self.use_graphs:
                 return self._forward_graphed(scores, features, image_size)
@@ -172,6 +174,10 @@ class SegNetwork(nn.Module):
 
     def forward_torch(self, scores, features, image_size, shared=None):
         red, pool = shared if shared is not None else self.precompute(features)
+        group = scores.shape[0] // pool.shape[0]
+        if pool.shape[0] > 1:                         # several frames: every frame's maps serve its `group` objects
+            red = {L: t.repeat_interleave(group, 0) for L, t in red.items()}
+            pool = pool.repeat_interleave(group, 0)
         x = None
         for i, L in enumerate(self.ft_channels):
             s = interpolate(scores, red[L].shape[-2:])
@@ -274,16 +280,18 @@ class SegNetwork(nn.Module):
         return out
 
     def _branch(self, L, p, ft, scores, deepest):
-        """Everything of one pyramid level that does not need the deeper level's output: TSE (reduce shared by all objects,
-        score channel injected into transform[0]) and RRB1 (reference seg_network.py:168-171) + the CAB's shallow pool."""
-        n, _, sh, sw = scores.shape
-        Hh, Ww = ft.shape[-2:]
-        h = self._conv(self._conv(ft, p['r0']), p['r2'])                       # TSE.reduce, shared by all objects
-        pool0 = self._mean(h) if deepest else None                             # (1,oc): deeper input of the deepest CAB
+        """Everything of one pyramid level that does not need the deeper level's output: TSE (reduce shared by all objects of a
+        frame, score channel injected into transform[0]) and RRB1 (reference seg_network.py:168-171) + the CAB's shallow pool.
+        ft: (F,fc,H,W) taps of F frames; scores: (F*n,1,h,w), frame-major."""
+        N, _, sh, sw = scores.shape
+        F_, Hh, Ww = ft.shape[0], ft.shape[-2], ft.shape[-1]
+        group = N // F_
+        h = self._conv(self._conv(ft, p['r0']), p['r2'])                       # TSE.reduce, shared by the objects of a frame
+        pool0 = self._mean(h) if deepest else None                             # (F,oc): deeper input of the deepest CAB
         base = self._conv(h, p['base'])                                        # object-independent part of transform[0]
         C0 = p['base']['cout']
-        t0 = torch.empty(n, C0, Hh, Ww, device=scores.device)
-        H.call('frtm_tse_inject', H.ptr(base), H.ptr(p['b0']), H.ptr(p['ws']), H.ptr(scores), n, C0, sh, sw, Hh, Ww, H.ptr(t0))
+        t0 = torch.empty(N, C0, Hh, Ww, device=scores.device)
+        H.call('frtm_tse_inject', H.ptr(base), H.ptr(p['b0']), H.ptr(p['ws']), H.ptr(scores), N, group, C0, sh, sw, Hh, Ww, H.ptr(t0))
         t = self._conv(self._conv(t0, p['t2']), p['t4'])
         r = self._rrb_hip(t, p['rrb1'])
         return r, self._mean(r), pool0, (h, base, t0, t)
@@ -297,7 +305,11 @@ class SegNetwork(nn.Module):
         allocator cannot hand a block to another stream inside the same pass."""
         P = self._packed()
         scores = scores.float().contiguous()
-        n = scores.shape[0]
+        n = scores.shape[0]                                     # samples = frames x objects, frame-major
+        frames = features[next(iter(self.ft_channels))].shape[0]
+        if n % frames != 0:
+            raise ValueError('scores (%d samples) must hold the same number of objects for each of the %d frames' % (n, frames))
+        group = n // frames
         dev = scores.device
         levels = list(self.ft_channels)
         cur = torch.cuda.current_stream()
@@ -323,11 +335,11 @@ class SegNetwork(nn.Module):
             Hh, Ww = r.shape[-2:]
             dp = pool0 if x is None else self._mean(x)
             gate = torch.empty(n, r.shape[1], device=dev)
-            H.call('frtm_cab_gate', H.ptr(sp), H.ptr(dp), int(x is None), H.ptr(p['cab_w1']), H.ptr(p['cab_b1']), H.ptr(p['cab_w2']),
-                   H.ptr(p['cab_b2']), n, r.shape[1], H.ptr(gate))
+            H.call('frtm_cab_gate', H.ptr(sp), H.ptr(dp), group if x is None else 0, H.ptr(p['cab_w1']), H.ptr(p['cab_b1']),
+                   H.ptr(p['cab_w2']), H.ptr(p['cab_b2']), n, r.shape[1], H.ptr(gate))
             out = torch.empty_like(r)
-            if x is None:
-                H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(pool0), n, r.shape[1], 1, 1, 1, Hh, Ww, H.ptr(out))
+            if x is None:       # deepest level: the deeper input is the frame's pooled vector, shared by its objects
+                H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(pool0), n, r.shape[1], 1, 1, group, Hh, Ww, H.ptr(out))
             else:
                 H.call('frtm_cab_combine', H.ptr(r), H.ptr(gate), H.ptr(x), n, r.shape[1], x.shape[2], x.shape[3], 0, Hh, Ww, H.ptr(out))
             keep.append((x, gate, out, dp))

@@ -29,6 +29,15 @@ from ..lib.utils import AverageMeter
 from .discriminator import Discriminator
 
 
+class FrameTaps(dict):
+    """Backbone taps of one frame ({layer: (1,C,H,W)}) that remember the trunk batch they are a slice of, so that consecutive
+    frames can be handed on as one window without copying."""
+
+    def __init__(self, batch, k):
+        super().__init__({L: t[k:k + 1] for L, t in batch.items()})
+        self.batch, self.k = batch, k
+
+
 class TargetObject:
 
     def __init__(self, obj_id, disc_params, discriminator=None, **kwargs):
@@ -56,6 +65,7 @@ class Tracker(nn.Module):
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
         self.graph_trunk = True
+        self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self._init_pool = []
         self._disc_pool = []
@@ -137,28 +147,67 @@ class Tracker(nn.Module):
             torch.cuda.synchronize()
             self.release_targets()
         outputs = []
+        window = []                                          # frames waiting to be tracked together: (image, taps)
+
+        def decode(masks):
+            if len(sequence.obj_ids) == 1:
+                return object_ids[(masks[1:2] > 0.5).long()]
+            return object_ids[ops.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]   # tracker.py:146-150 (merge of merged masks)
+
+        def flush():
+            if window:
+                for masks in self.track_window([im for im, _ in window], [ft for _, ft in window]):
+                    outputs.append(decode(masks))
+                    self.current_frame += 1
+                del window[:]
+
         t0 = time()
         for i, (image, labels, new_objects, feats) in enumerate(self.frames_with_features(sequence)):
-            old_objects = set(self.targets.keys())
             image = image.to(self.device)
             if len(new_objects) > 0:
+                flush()                                      # everything before this frame, with the old set of objects
+                had_objects = len(self.targets) > 0
                 labels = labels.to(self.device)
                 self.initialize(image, labels, new_objects)
-            if len(old_objects) > 0:
-                self.track(image, feats)
-                masks = self.current_masks
-                if len(sequence.obj_ids) == 1:
-                    labels = object_ids[(masks[1:2] > 0.5).long()]
-                else:                                                   # tracker.py:146-150 (merge of merged masks)
-                    labels = object_ids[ops.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]
-            if isinstance(labels, list) and len(labels) == 0:
-                labels = image.new_zeros(1, *image.shape[-2:])
-            outputs.append(labels)
-            self.current_frame += 1
+                if had_objects:
+                    window.append((image, feats))
+                    flush()                                  # this frame on its own: the set of active objects changes after it
+                else:
+                    outputs.append(labels)
+                    self.current_frame += 1
+            elif len(self.targets) > 0:
+                if window and not self._extends(window[-1][1], feats):
+                    flush()
+                window.append((image, feats))
+                if self._window_complete(len(window), image):
+                    flush()
+            else:
+                if isinstance(labels, list) and len(labels) == 0:
+                    labels = image.new_zeros(1, *image.shape[-2:])
+                outputs.append(labels)
+                self.current_frame += 1
             N += 1
+        flush()
         torch.cuda.synchronize()
         T = time() - t0
         return outputs, N / T
+
+    @staticmethod
+    def _extends(prev, nxt):
+        """Are the taps `nxt` the slice right after `prev` in the same trunk batch (one window = one contiguous slice)?"""
+        return (isinstance(prev, FrameTaps) and isinstance(nxt, FrameTaps) and nxt.batch is prev.batch and nxt.k == prev.k + 1)
+
+    def _window_complete(self, length, image):
+        """A window ends with the frame on which some object re-solves its filter (the frames before it all see the same filter,
+        reference discriminator.py:221-227), or when it holds as many samples as the refiner's 32-bit buffer offsets allow."""
+        active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
+        if not self.window_tracking or not active:
+            return True
+        if any(t.discriminator.frames_until_solve() <= length for t in active if t.discriminator.update_filters):
+            return True
+        Hh, Ww = image.shape[-2:]
+        per_sample = 4 * 64 * (Hh // 2 + 1) * (Ww // 2 + 1)      # largest refiner activation of one sample (bytes)
+        return (length + 1) * len(active) * per_sample > 0x7fffffff or length >= 64
 
     def frames_with_features(self, sequence):
         """Yields (image, labels, new_objects, taps).  The trunk runs on up to ``feature_batch`` consecutive frames at once
@@ -210,7 +259,7 @@ class Tracker(nn.Module):
                     taps, ev, idx = pending.pop(i)
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
-                    cache = {j: {L: t[k:k + 1] for L, t in taps.items()} for k, j in enumerate(idx)}
+                    cache = {j: FrameTaps(taps, k) for k, j in enumerate(idx)}
                     bi += 1
                     launch(bi)                              # next batch starts while this one is being tracked
                 feats = cache.pop(i)
@@ -257,6 +306,58 @@ class Tracker(nn.Module):
             for st in lanes:
                 cur.wait_stream(st)
         return self.current_masks
+
+    @torch.no_grad()
+    def track_window(self, images, taps):
+        """track() for W consecutive frames at once (one contiguous slice of a trunk batch, same active objects, no filter
+        re-solve before the last frame): one projection / score / refiner pass over W x n samples instead of W passes over n.
+        Per frame the arithmetic is that of track(); the memory inserts and the re-solve run frame by frame afterwards, in order.
+        Returns the list of per-frame ``current_masks``."""
+        W = len(images)
+        im_size = images[0].shape[-2:]
+        first = taps[0]
+        if W > 1 or isinstance(first, FrameTaps):
+            feats = {L: first.batch[L][first.k:first.k + W] for L in first.batch} if isinstance(first, FrameTaps) else first
+        else:
+            feats = first
+        active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
+        n = len(active)
+        masks = self.current_masks.unsqueeze(0).repeat(W, 1, 1, 1) if W > 1 else self.current_masks.unsqueeze(0)
+        cfts = []
+        if active:
+            per_obj = [t.discriminator.apply_window(feats[t.disc_layer]) for t in active]      # (W,c,h,w), (W,1,h,w)
+            cfts = [c for c, _ in per_obj]
+            scores = torch.stack([s for _, s in per_obj], dim=1).reshape(W * n, 1, *per_obj[0][1].shape[-2:])   # frame-major
+            y = torch.sigmoid(self.refiner(scores, feats, im_size)).view(W, n, *im_size)
+            for k, t in enumerate(active):
+                masks[:, t.index] = y[:, k]
+        for t1 in active:                                                                    # :208-212 (only when W == 1)
+            for t2 in self.targets.values():
+                if t2 is not t1 and t2.start_frame == self.current_frame:
+                    masks[0, t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+        for f in range(W):
+            ops.merge_masks_(masks[f])                                                       # :214-221
+        out = [masks[f] for f in range(W)]
+        if active and self.disc_params.update_filters:
+            K = masks.shape[1]
+            counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)                 # device int32, no sync
+            for f in range(W):
+                for t in active:
+                    t.discriminator.advance(cfts[active.index(t)][f:f + 1])
+                solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
+                host = counts[f].tolist() if solve else None                                 # one D2H only on re-solve frames
+                for t in active:
+                    y1 = masks[f, t.index].unsqueeze(0).unsqueeze(0)
+                    if host is not None:
+                        t.discriminator.update(y1, num_positive=host[t.index])
+                    else:
+                        t.discriminator.update(y1, count_dev=counts[f, t.index:t.index + 1])
+        else:
+            for f in range(W):
+                for k, t in enumerate(active):
+                    t.discriminator.advance(cfts[k][f:f + 1])
+        self.current_masks = masks[W - 1]
+        return out
 
     @torch.no_grad()
     def track(self, image, features=None):

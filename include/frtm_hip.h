@@ -224,18 +224,19 @@ int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, f
  * ------------------------------------------------------------------------------------------ */
 /* F.interpolate(..., 'bilinear', align_corners=False) of `planes` maps (lib/utils.py:33-35) */
 int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream);
-/* TSE: out[n,c] = relu(base[c] + bias[c] + conv3x3(bilinear(scores[n]) , ws[c]))  (seg_network.py:16-21 with the
- * object-independent 64-channel part of transform[0] pre-computed in base (C,H,W)); scores (n,1,h,w), out (n,C,H,W). */
-int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int C,
+/* TSE: out[s,c] = relu(base[s/group,c] + bias[c] + conv3x3(bilinear(scores[s]) , ws[c]))  (seg_network.py:16-21 with the
+ * object-independent 64-channel part of transform[0] pre-computed in base (n/group,C,H,W): `group` consecutive samples = the
+ * objects of one frame share a map); scores (n,1,h,w), out (n,C,H,W). */
+int frtm_tse_inject(const float* base, const float* bias, const float* ws, const float* scores, int n, int group, int C,
                     int h, int w, int H, int W, float* out, frtm_stream_t stream);
-/* CAB: out = shallow * sigmoid(gate[n,c]) + bilinear(deeper[n,c] (hd,wd) -> (H,W))  (seg_network.py:38-41);
- * deeper_shared != 0: one deeper tensor (1,C,hd,wd) for all n. */
-int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd,
-                     int deeper_shared, int H, int W, float* out, frtm_stream_t stream);
+/* CAB (seg_network.py:38-41): out = shallow * sigmoid(gate[s,c]) + bilinear(deeper[d,c], (hd,wd) -> (H,W)), d = s / deeper_group
+ * when deeper_group > 0 (objects of a frame share the deeper map: the pooled vector of the deepest level), d = s when it is 0. */
+int frtm_cab_combine(const float* shallow, const float* gate, const float* deeper, int n, int C, int hd, int wd, int deeper_group,
+                     int H, int W, float* out, frtm_stream_t stream);
 /* CAB gate (model/seg_network.py:34-37, before the sigmoid): gate (n,oc) = W2^T relu(W1^T cat(sp, dp) + b1) + b2.
- * sp, dp: (n,oc) pooled shallower / deeper features (dp_shared != 0: one (1,oc) deeper vector for all objects);
+ * sp: (n,oc) pooled shallower features; dp: pooled deeper features, row s / dp_group when dp_group > 0, row s when it is 0;
  * W1 (2oc,oc) and W2 (oc,oc): the two 1x1 conv weights transposed to [in][out]. */
-int frtm_cab_gate(const float* sp, const float* dp, int dp_shared, const float* W1, const float* b1, const float* W2, const float* b2,
+int frtm_cab_gate(const float* sp, const float* dp, int dp_group, const float* W1, const float* b1, const float* W2, const float* b2,
                   int n, int oc, float* gate, frtm_stream_t stream);
 /* PyrUpBicubic2d: 2x polyphase bicubic with replicate border (seg_network.py:75-126); out (planes,2h,2w) */
 int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream);

@@ -479,6 +479,31 @@ def test_segnetwork_hip_vs_torch(bn, n, size):
     assert rel(hip, ref) < 2e-4, rel(hip, ref)
 
 
+def test_segnetwork_frame_window_equals_per_frame_calls():
+    """A window of F frames x n objects in one refiner call == F single-frame calls (HIP path, eager and graph replay), and
+    matches the PyTorch definition on the same window."""
+    from collections import OrderedDict
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    chans = OrderedDict(layer5=40, layer4=24, layer3=16, layer2=8)
+    torch.manual_seed(5)
+    net = SegNetwork(1, 8, chans, True).eval().to(DEV)
+    g = gen(19)
+    size, Fn, n = (96, 140), 3, 2
+    dims = [((size[0] + 2 ** k - 1) // 2 ** k, (size[1] + 2 ** k - 1) // 2 ** k) for k in (5, 4, 3, 2)]
+    feats = {L: torch.relu(torch.randn(Fn, c, *d, generator=g)).to(DEV) for (L, c), d in zip(chans.items(), dims)}
+    scores = torch.randn(Fn * n, 1, *dims[1], generator=g).to(DEV)
+    with torch.no_grad():
+        win = net(scores, feats, size)
+        ref = net.forward_torch(scores, feats, size)
+        assert rel(win, ref) < 2e-4
+        for f in range(Fn):
+            one = net(scores[f * n:(f + 1) * n], {L: t[f:f + 1] for L, t in feats.items()}, size)
+            assert rel(win[f * n:(f + 1) * n], one) < 1e-5, f
+        net.use_graphs = True
+        assert torch.equal(net(scores, feats, size), win)
+        assert torch.equal(net(scores, feats, size), win)
+
+
 def test_refiner_glue_kernels():
     from frtm_vos_amd import _hip as H
     from frtm_vos_amd.model.seg_network import PyrUpBicubic2d
