@@ -1,30 +1,25 @@
+"""Where do device allocations (hipMalloc behind caching-allocator misses) happen inside a sequence?  Needs a GPU."""
 import sys, os, torch, time
-sys.path.insert(0, '/root/repo')
-import bench
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frtm_vos_amd.evaluate import Parameters
 from frtm_vos_amd.lib.synthetic import SyntheticSequence
 torch.set_grad_enabled(False)
 dev = 'cuda:0'
 nobj = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 trk = Parameters(None, device=dev).get_model().eval()
-warm = SyntheticSequence('warm', 17, (480, 854), nobj, seed=100); warm.preload(dev)
+warm = SyntheticSequence('warm', 24, (480, 854), nobj, seed=100); warm.preload(dev)
 seq = SyntheticSequence('bench', 64, (480, 854), nobj, seed=1); seq.preload(dev)
-bench.run_sequence(trk, warm)
-torch.cuda.synchronize()
+trk.run_sequence(warm)
 def na(): return torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
-for rep in range(3):
-    trk.current_frame = 0
-    trk.release_targets()
+log = []
+orig_tw, orig_init = trk.track_window, trk.initialize
+def tw(images, taps):
+    a = na(); out = orig_tw(images, taps); log.append(('window W=%d' % len(images), na() - a)); return out
+def ini(*a, **k):
+    a0 = na(); out = orig_init(*a, **k); log.append(('initialize', na() - a0)); return out
+trk.track_window, trk.initialize = tw, ini
+for rep in range(2):
+    del log[:]
     a0 = na(); t0 = time.time()
-    log = []
-    for i, (image, labels, new_objects, feats) in enumerate(trk.frames_with_features(seq)):
-        old = set(trk.targets.keys())
-        if len(new_objects) > 0:
-            trk.initialize(image, labels, new_objects)
-        if len(old) > 0:
-            trk.track(image, feats)
-        trk.current_frame += 1
-        log.append(na() - a0)
-    torch.cuda.synchronize()
-    print('rep', rep, 'wall %.1f ms' % (1e3 * (time.time() - t0)), 'mallocs after frame 0: %d, after 1: %d, 8: %d, 16: %d, end: %d' % (log[0], log[1], log[8], log[16], log[-1]),
-          'reserved GB %.2f' % (torch.cuda.memory_reserved(dev) / 1e9))
+    trk.run_sequence(seq)
+    print('rep', rep, 'wall %.1f ms, mallocs %d:' % (1e3 * (time.time() - t0), na() - a0), [(n, c) for n, c in log if c], 'other', na() - a0 - sum(c for _, c in log))
