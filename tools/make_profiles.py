@@ -64,7 +64,7 @@ with open(os.path.join(out, tag + '_steady_state.csv'), 'w') as f:
         w.writerow([n, cnt[n], round(d / 1e6, 3), round(d / cnt[n] / 1e3, 2), round(100 * d / busy, 2)])
 
 subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), fetch, write, os.path.join(out, tag + '_pmc_traffic.json'),
-                       'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) -- python tools/trunk_bench.py 4 1   (the trunk alone, ONE lane of 4 frames = the launches of bench.py, RN101 480x854; with two concurrent lanes the device-wide counters of a kernel also see the other lane: exactly twice these numbers were measured)'])
+                       'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) -- python tools/trunk_bench.py 4 1   (the trunk alone, one lane of 4 frames = the launches of bench.py, RN101 480x854)'])
 shutil.copy(os.path.join(out, tag + '_pmc_traffic.json'), os.path.join(out, 'pmc_traffic.json'))
 shutil.copy(bench, os.path.join(out, tag + '_bench.json'))
 print('steady-state window: a kernel is running %.1f %% of the time; summed durations / occupied time = %.2f' % (100 * occupied / win, busy / max(occupied, 1)))
