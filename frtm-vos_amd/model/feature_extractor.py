@@ -244,17 +244,12 @@ class ResnetFeatureExtractor:
             ent = self._out_cache[key] = dict(out={L: t[:B] for L, t in buf['t'].items()}, graph=None)
             self._forward(x, ent['out'], args, stop)           # first call of a shape: eager (allocates arenas / workspaces)
             ent['stats'] = (self.last_flops, self.last_conv_launches)
+            if self.use_graph:                                 # ... and captured right away: the second call already replays
+                self._capture(ent, x, args, stop)
             return ent['out']
         gen = H.lib().frtm_backbone_generation(self._handle)
         if self.use_graph and (ent['graph'] is None or ent['gen'] != gen):
-            # one hipGraph per shape: ~105 launches per lane become one host call, the lanes stay parallel branches
-            ent['in'] = x.clone()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._forward(ent['in'], ent['out'], args, stop)
-            ent['stats'] = (self.last_flops, self.last_conv_launches)
-            ent['graph'], ent['gen'] = g, gen
+            self._capture(ent, x, args, stop)
         if self.use_graph:
             ent['in'].copy_(x)
             ent['graph'].replay()
@@ -262,6 +257,16 @@ class ResnetFeatureExtractor:
         else:
             self._forward(x, ent['out'], args, stop)
         return ent['out']
+
+    def _capture(self, ent, x, args, stop):
+        """One hipGraph per shape: ~105 launches per lane become one host call, the lanes stay parallel branches."""
+        ent['in'] = x.clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._forward(ent['in'], ent['out'], args, stop)
+        ent['stats'] = (self.last_flops, self.last_conv_launches)
+        ent['graph'], ent['gen'] = g, H.lib().frtm_backbone_generation(self._handle)
 
     def _forward(self, x, out, args, stop):
         ptrs = [H.ptr(out.get(L)) for L in ('layer1', 'layer2', 'layer3', 'layer4', 'layer5')]
