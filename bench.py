@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--backbone', default='resnet101')
     ap.add_argument('--objects', type=int, default=2)
     ap.add_argument('--size', default='480x854')
-    ap.add_argument('--trunk-batch', type=int, default=8, help='frames per trunk pass (1 = frame by frame like the reference)')
+    ap.add_argument('--trunk-batch', type=int, default=16, help='frames per trunk pass (1 = frame by frame like the reference)')
     ap.add_argument('--trunk-lanes', type=int, default=2, help='concurrent sub-batches (streams) of a trunk pass')
     ap.add_argument('--fast', action='store_true', help='README "fast" schedule (fewer CG iterations)')
     ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')

@@ -20,7 +20,7 @@ class AttrDict(dict):
 
 class Parameters:
 
-    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=8, trunk_lanes=2):
+    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2):
         self.device = device
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes

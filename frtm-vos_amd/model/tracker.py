@@ -8,7 +8,7 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
    computed once per frame;
  * merge (clamp / background / soft-max / arg-max, tracker.py:214-221) is one HIP kernel, in place;
  * the trunk does not depend on tracking state, so ``run_sequence`` feeds it ``feature_batch`` pre-loaded frames at a time
-   (default 8, as ``trunk_lanes`` = 2 concurrent sub-batches of 4): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs
+   (default 16, as ``trunk_lanes`` = 2 concurrent sub-batches of 8): at batch 1 the 30x54 / 15x27 stages cannot fill 256 CUs
    (47 TFLOP/s, many split-K convs), at batch 4 they do (80 TFLOP/s, no split-K), and two sub-batches on two streams cover
    each other's kernel tails (the last, partly filled round of workgroups of every launch): 95 TFLOP/s.  Per-frame results
    are unchanged up to fp32 summation order; ``track(image)`` without pre-computed features still works frame by frame;
@@ -60,7 +60,7 @@ class TargetObject:
 
 class Tracker(nn.Module):
 
-    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=8, trunk_lanes=2):
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=16, trunk_lanes=2):
         super().__init__()
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
