@@ -13,7 +13,7 @@ import sys
 tag, prof, fetch, write, bench = sys.argv[1:6]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, 'profiles')
-cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8 --trunk-batch 8 --trunk-lanes 2)'
+cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8 --trunk-batch 16 --trunk-lanes 2)'
 
 rows = list(csv.DictReader(open(os.path.join(prof, 'prof_kernel_stats.csv'))))
 with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w') as f:
@@ -64,7 +64,7 @@ with open(os.path.join(out, tag + '_steady_state.csv'), 'w') as f:
         w.writerow([n, cnt[n], round(d / 1e6, 3), round(d / cnt[n] / 1e3, 2), round(100 * d / busy, 2)])
 
 subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), fetch, write, os.path.join(out, tag + '_pmc_traffic.json'),
-                       'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) -- python tools/trunk_bench.py 4 1   (the trunk alone, one lane of 4 frames = the launches of bench.py, RN101 480x854)'])
+                       'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) -- python tools/trunk_bench.py 8 1   (the trunk alone, one lane of 8 frames = the launches of bench.py, RN101 480x854)'])
 shutil.copy(os.path.join(out, tag + '_pmc_traffic.json'), os.path.join(out, 'pmc_traffic.json'))
 shutil.copy(bench, os.path.join(out, tag + '_bench.json'))
 print('steady-state window: a kernel is running %.1f %% of the time; summed durations / occupied time = %.2f' % (100 * occupied / win, busy / max(occupied, 1)))
@@ -78,12 +78,12 @@ if len(sys.argv) > 6:
     u = union_ns(conv)
     ssum = sum(e - a for a, e in conv)
     with open(os.path.join(out, tag + '_trunk_only.json'), 'w') as f:
-        json.dump({'command': 'rocprofv3 --kernel-trace --output-format csv -- python tools/trunk_bench.py 8 2 graph',
+        json.dump({'command': 'rocprofv3 --kernel-trace --output-format csv -- python tools/trunk_bench.py 16 2 graph',
                    'conv_launches': len(convk), 'conv_family_union_ms': u / 1e6, 'conv_family_summed_ms': ssum / 1e6,
                    'effective_us_per_conv_launch': u / 1e3 / max(len(convk), 1),
                    'mean_kernel_duration_us': ssum / 1e3 / max(len(conv), 1),
-                   'note': 'rocprofv3 kernel tracing serialises the dispatches of the two trunk lanes (union ~= sum of durations), so this '
-                           'trace shows the un-overlapped kernel durations, i.e. the single-lane rate (tools/trunk_bench.py prints ~80 TF '
-                           'under the profiler and ~95 TF without it).  bench.py roofline.per_launch.avg_ms is HIP-event time of the '
-                           'pass / launches WITHOUT the profiler: the lanes overlap there, which is what the lanes are for'}, f, indent=1)
+                   'note': 'two lanes: when the lanes overlap under the tracer the mean kernel duration is up to 2x the effective time per '
+                           'launch (each kernel shares the GPU with the other lane); when the tracer serialises them the two agree and the '
+                           'rate drops to the single-lane one.  effective_us_per_conv_launch (union of the conv intervals / launches) is the '
+                           'quantity bench.py reports as roofline.per_launch.avg_ms from HIP events'}, f, indent=1)
     print('trunk only: %.1f us effective per conv launch (union), %.1f us mean kernel duration' % (u / 1e3 / max(len(convk), 1), ssum / 1e3 / max(len(conv), 1)))
