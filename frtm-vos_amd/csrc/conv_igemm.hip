@@ -252,12 +252,13 @@ constexpr int HK = HCI * 9;             // k rows per chunk
 template <int BM, int WGM, int WGN, int TW, int S = 1>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParams p) {
   constexpr int NT = 64 * WGM * WGN, BN = 64, TH = 64 / TW;
-  constexpr int LDA = BM + 16;
+  constexpr int LDA = BM + 16 + ((BM % 32 == 16) ? 16 : 0);          // == 16 (mod 32) for BM = 32, 64, 80, 128
+  static_assert(LDA % 32 == 16 && BM % (16 * WGM) == 0 && BM % 4 == 0, "A tile");
   constexpr int PW = (TW - 1) * S + 3, PH = (TH - 1) * S + 3;       // input patch of a TH x TW output tile (stride S, 3x3, pad 1)
   constexpr int PLraw = PW * PH, PL = ((PLraw + 15) / 32) * 32 + 16;      // plane pitch == 16 (mod 32), >= PLraw
   static_assert(PL >= PLraw && PL % 32 == 16, "plane pitch");
   constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 16, FN = TN / 16;
-  constexpr int TA = BM / 4, RA = NT / TA, PA = (HK + RA - 1) / RA;
+  constexpr int TA = BM / 4, NA = HK * TA, PA = (NA + NT - 1) / NT;     // A chunk: HK rows of TA dwordx4, element e = tid + i*NT
   constexpr int NB = HCI * PLraw, PB = (NB + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float As[2][HK][LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][HCI * PL];
@@ -277,8 +278,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
 
-  const int acol = (tid % TA) * 4, arow = tid / TA;
-  const unsigned a_off = (unsigned)(m0 + acol) * 4u;
   // B staging: element e = tid + i*NT of the [HCI][PH][PW] patch
   unsigned b_goff[PB]; int b_loff[PB];
 #pragma unroll
@@ -296,8 +295,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   auto gload = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const int row = arow + i * RA;
-      ra[i] = buf_ld4(rw, row < HK ? (unsigned)(kc * HK + row) * (unsigned)(p.Mp * 4) + a_off : OOB);
+      const int e = tid + i * NT, row = e / TA, col = (e - row * TA) * 4;       // TA is a compile-time constant
+      ra[i] = buf_ld4(rw, e < NA ? (unsigned)(kc * HK + row) * (unsigned)(p.Mp * 4) + (unsigned)(m0 + col) * 4u : OOB);
     }
     const unsigned cstep = (unsigned)(kc * HCI) * (unsigned)(HWin * 4);
     const bool tail = (kc * HCI + HCI) > p.Cin;                     // last chunk of a Cin that is not a multiple of 8
@@ -310,7 +309,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) { const int row = arow + i * RA; if (row < HK) *(f32x4*)&As[buf][row][acol] = ra[i]; }
+    for (int i = 0; i < PA; ++i) {
+      const int e = tid + i * NT, row = e / TA, col = (e - row * TA) * 4;
+      if (e < NA) *(f32x4*)&As[buf][row][col] = ra[i];
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i) if (b_loff[i] >= 0) Bs[buf][b_loff[i]] = rb[i];
   };
@@ -452,7 +454,7 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
   if (*tile == 0)
     *tile = vec1x1 ? ((M % 64 == 0 && blocks(64, 64) >= 512) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64)
                    : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
-  const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
+  const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_80x64) ? blocks(80, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
                : (*tile == FRTM_TILE_128x128_8W || *tile == FRTM_TILE_128x128_16W) ? blocks(128, 128)
                : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W || *tile == FRTM_TILE_64x64_K64) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
@@ -556,6 +558,8 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     // 32-row tiles measured best for the stride-1 trunk / refiner shapes; the stride-2 convs (4x the input patch per output
     // tile) amortise the patch over 64 rows: 128->105 us (256ch, 60x107, batch 4), 133->114 us (512ch, 30x54)
     if (tile == 0) tile = (d->stride == 2) ? FRTM_TILE_64x64 : FRTM_TILE_32x64;
+    // 65..80 output channels (the refiner's 65-channel TSE convs): one 80-row tile instead of three 32-row tiles (96 rows)
+    if (d->tile == 0 && d->stride == 1 && p.M > 64 && p.M <= 80) tile = FRTM_TILE_80x64;
     frtm_conv_plan(p.M, ptiles * 64, p.nchunks * 2, 0, &tile, &splitk);
   } else {
     frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
@@ -576,6 +580,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
       case FRTM_TILE_128x64: launch_halo<128, 2, 2>(p, halo_tw, st); break;
       case FRTM_TILE_64x64: launch_halo<64, 2, 2>(p, halo_tw, st); break;
       case FRTM_TILE_32x64: launch_halo<32, 1, 4>(p, halo_tw, st); break;
+      case FRTM_TILE_80x64: launch_halo<80, 1, 4>(p, halo_tw, st); break;
       default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
     }
   } else

@@ -174,6 +174,7 @@ typedef struct {
 #define FRTM_TILE_64x128_8W 7
 #define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
 #define FRTM_TILE_128x128_16W 9
+#define FRTM_TILE_80x64 10       /* halo (3x3) kernel only: 65..80 output channels in one M tile */
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

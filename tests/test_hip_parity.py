@@ -164,6 +164,19 @@ def test_conv2d(ops, case, tile, splitk):
     assert rel(out3, ref.flatten(2).transpose(1, 2)) < 2e-5
 
 
+@pytest.mark.parametrize('cout,splitk', [(65, 1), (80, 1), (72, 3), (40, 1), (100, 1)])
+def test_conv2d_80_row_halo_tile(ops, cout, splitk):
+    """FRTM_TILE_80x64 (one M tile for 65..80 output channels, the refiner's 65-channel convs); also partly filled / two tiles."""
+    g = gen(cout)
+    x = torch.randn(2, 65, 21, 37, generator=g)
+    w = torch.randn(cout, 65, 3, 3, generator=g) / 24.0
+    b = torch.randn(cout, generator=g)
+    wT, ktab, lay = ops.pack_weights(w.to(DEV))
+    out = ops.conv2d(x.to(DEV), wT, cout, 3, 1, 1, scale=torch.ones(cout, device=DEV), shift=b.to(DEV), relu=True, tile=10, splitk=splitk,
+                     w_layout=lay)
+    assert rel(out, torch.relu(F.conv2d(x, w, b, padding=1))) < 2e-5
+
+
 def test_conv_as_weight_gradient(ops):
     """g1[c,ci] = sum_{n,pix} D[n,pix,c] X[n,pix,ci]: the init problem's second GEMM (K = N*h*w)."""
     g = gen(9)
