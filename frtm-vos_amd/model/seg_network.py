@@ -141,6 +141,7 @@ class SegNetwork(nn.Module):
         self.fuse_tail = True         # up2 + resize + conv2 as one kernel when the resize ratio allows (frtm_project_tail)
         self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
         self._side = None
+        self._pool = None
 
     def invalidate(self):
         """Drop the packed HIP weights and captured graphs (call after editing parameters in place)."""
@@ -197,10 +198,10 @@ class SegNetwork(nn.Module):
         shape and the weight versions; scores go through a static input buffer."""
         P = self._packed()
         key = (tuple(features[L].data_ptr() for L in self.ft_channels), tuple(scores.shape), tuple(image_size[-2:]), self._pack_key)
-        entry = self._graphs.get(key)
+        entry = self._graphs.pop(key, None)
         if entry is None:
-            if len(self._graphs) > 64:
-                self._graphs.clear()
+            while len(self._graphs) >= 32:                                   # least recently used first
+                self._graphs.pop(next(iter(self._graphs)))
             static_scores = scores.clone()
             self._forward_hip(static_scores, features, image_size)          # warm-up outside capture (allocator, workspaces)
             torch.cuda.synchronize()
@@ -208,10 +209,15 @@ class SegNetwork(nn.Module):
                 # ONE side stream carries all deep levels (two parallel graph branches).  A stream per level measured slower
                 # and bimodal on MI355X (1.25-1.31 ms vs 1.22 ms serial; this form 1.15 ms, stable).
                 self._side = [torch.cuda.Stream(device=scores.device)] * (len(self.ft_channels) - 1)
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # all refiner graphs (one per window shape / object count / tap set) share one memory pool: they never run
+            # concurrently and each output is consumed before the next replay, so the pool is as large as the largest graph
+            with torch.cuda.graph(g, pool=self._pool):
                 out = self._forward_hip(static_scores, features, image_size, self._side if self.parallel_levels else None)
-            entry = self._graphs[key] = (g, static_scores, out, [features[L] for L in self.ft_channels])
+            entry = (g, static_scores, out, [features[L] for L in self.ft_channels])
+        self._graphs[key] = entry                                            # (re-)insert as most recently used
         g, static_scores, out, _keepalive = entry
         static_scores.copy_(scores)
         g.replay()
