@@ -24,7 +24,7 @@ SIGNATURES = {
     'frtm_version': (I, []),
     'frtm_device_info': (I, [P]),
     'frtm_pixel_weights': (I, [P, I, I, I, I, F, P, P, P]),
-    'frtm_normal_build': (I, [P, I, P, I, I, I, I, I, F, P, I, P, P, P, P]),
+    'frtm_normal_build': (I, [P, I, P, I, I, I, I, I, F, P, I, P, P, P, P, P]),
     'frtm_memory_next_slot': (I, [P, I, F, I, P, P, I, P]),
     'frtm_memory_insert': (I, [P, P, I, P, P]),
     'frtm_filter_scores': (I, [P, P, I, I, I, I, P, I, P]),

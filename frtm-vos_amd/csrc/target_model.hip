@@ -80,7 +80,8 @@ __device__ __forceinline__ float tap_w(int k, int i0, int i1, float l0, float l1
 template <bool U8>
 __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ labels, const float* __restrict__ pw, int H, int W, int h, int w, float tf,
                                                        const float* __restrict__ partial, const int* __restrict__ slot_dev,
-                                                       int slot_host, float* __restrict__ Bmem, float* __restrict__ cmem) {
+                                                       int slot_host, float* __restrict__ Bmem, float* __restrict__ cmem,
+                                                       const int* __restrict__ px_count) {
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int cell = blockIdx.x * 4 + wid;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
   if (slot_dev && slot_dev[0] < 0) return;   // guarded insert
   const int ci = cell / w, cj = cell % w;
   float wf = 1.f, wb = 1.f;
-  if (!pw) hinge_weights(sum_parts(partial, n), (float)(H * W), tf, wf, wb);
+  if (!pw) hinge_weights(px_count ? (float)px_count[n] : sum_parts(partial, n), (float)(H * W), tf, wf, wb);
   const float* pwn = pw ? pw + (size_t)n * H * W : nullptr;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   // conservative pixel window of cell (ci,cj): source coordinate in [ci-1, ci+1)
@@ -714,17 +715,18 @@ int frtm_pixel_weights(const void* y, int y_is_u8, int n, int H, int W, float tf
 }
 
 int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int n, int H, int W, int h, int w, float tf,
-                      const int* slot_dev, int slot_host, float* Bmem, float* cmem, float* scratch, frtm_stream_t stream) {
+                      const int* slot_dev, int slot_host, float* Bmem, float* cmem, float* scratch, const int* px_count_dev,
+                      frtm_stream_t stream) {
   FRTM_CHECK_ARG(labels && Bmem && cmem && scratch && n > 0, "frtm_normal_build: bad argument");
   FRTM_CHECK_ARG(h >= 1 && w >= 1 && H >= h && W >= w, "frtm_normal_build: needs H>=h, W>=w (got %dx%d -> %dx%d)", h, w, H, W);
   hipStream_t st = (hipStream_t)stream;
-  if (!pw) {
+  if (!pw && !px_count_dev) {
     int rc = label_sum(labels, labels_is_u8, 1, n, H * W, scratch, st);
     if (rc) return rc;
   }
   dim3 g(ceil_div(h * w, 4), n);
-  if (labels_is_u8) k_normal_build<true><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem);
-  else k_normal_build<false><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem);
+  if (labels_is_u8) k_normal_build<true><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem, px_count_dev);
+  else k_normal_build<false><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem, px_count_dev);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

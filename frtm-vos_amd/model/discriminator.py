@@ -373,7 +373,7 @@ class Discriminator(nn.Module):
             num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
         if num_positive < 10:
             return
-        self.memory.update(self.current_sample, train_y)     # soft mask as label, weights from (y > 0.5)  (:217-219)
+        self.memory.update(self.current_sample, train_y, px_count=count_dev)     # soft mask as label, weights from (y > 0.5)  (:217-219)
         if not solve:
             return
         self.update_optimizer.run(self.update_iters)

@@ -85,7 +85,7 @@ class Memory:
         return (self._capacity == capacity and tuple(self.samples.shape[1:]) == tuple(feature_size) and
                 self.labels_size == tuple(labels_size) and self.grid == grid and self.keep_hires == keep_hires)
 
-    def _build_normals(self, labels, pixel_weights, n, slot_dev, slot_host):
+    def _build_normals(self, labels, pixel_weights, n, slot_dev, slot_host, px_count=None):
         Hh, Ww = self.labels_size[-2:]
         lab = labels.reshape(n, Hh, Ww)
         if lab.dtype != torch.uint8:
@@ -94,7 +94,7 @@ class Memory:
         pw = None if pixel_weights is None else pixel_weights.reshape(n, Hh, Ww).float().contiguous()
         H.call('frtm_normal_build', H.ptr(lab), int(lab.dtype == torch.uint8), H.ptr(pw), n, Hh, Ww,
                self.grid[0], self.grid[1], self._tf(), slot_dev, slot_host,
-               H.ptr(self.normal_B), H.ptr(self.normal_c), H.ptr(self._scratch))
+               H.ptr(self.normal_B), H.ptr(self.normal_c), H.ptr(self._scratch), None if px_count is None else px_count.data_ptr())
         return lab, pw
 
     def initialize(self, init_features, init_labels, pixel_weights=None):
@@ -126,20 +126,21 @@ class Memory:
                int(self.current_size == 0), H.ptr(self._slot), None if count_dev is None else count_dev.data_ptr(), int(min_count))
         self._have_prev = True
 
-    def insert_at(self, slot_dev_ptr, ft, labels, pixel_weights):
+    def insert_at(self, slot_dev_ptr, ft, labels, pixel_weights, px_count=None):
         """Reference memory.py:50-57; the slot is a device-resident index."""
         ft = ft.detach().contiguous()
         H.call('frtm_memory_insert', H.ptr(ft), H.ptr(self.samples), ft.numel(), slot_dev_ptr)
-        lab, pw = self._build_normals(labels, pixel_weights, 1, slot_dev_ptr, 0)
+        lab, pw = self._build_normals(labels, pixel_weights, 1, slot_dev_ptr, 0, px_count if pixel_weights is None else None)
         if self.keep_hires:
             labf = lab.float().contiguous()          # named: H.ptr() only takes the address
             H.call('frtm_memory_insert', H.ptr(labf), H.ptr(self.labels), labf.numel(), slot_dev_ptr)
             pwt = pw if pw is not None else self._hires_pw(lab)
             H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self.pixel_weights), pwt.numel(), slot_dev_ptr)
 
-    def update(self, features, labels, pixel_weights=None, count_dev=None):
+    def update(self, features, labels, pixel_weights=None, count_dev=None, px_count=None):
         """Reference memory.py:59-63.  With ``count_dev`` the insert is guarded on the device; ``current_size`` is then an
-        upper bound (a skipped insert leaves a zero-weight slot, which contributes nothing to the solver)."""
+        upper bound (a skipped insert leaves a zero-weight slot, which contributes nothing to the solver).  ``px_count``
+        (default: ``count_dev``): device int32 with the number of label pixels > 0.5, if the caller already has it."""
         self.update_sample_weights(count_dev=count_dev)
-        self.insert_at(self._slot[1:].data_ptr(), features, labels, pixel_weights)
+        self.insert_at(self._slot[1:].data_ptr(), features, labels, pixel_weights, px_count if px_count is not None else count_dev)
         self.current_size = min(self.current_size + 1, self._capacity)

@@ -349,7 +349,7 @@ class Tracker(nn.Module):
                 for t in active:
                     y1 = masks[f, t.index].unsqueeze(0).unsqueeze(0)
                     if host is not None:
-                        t.discriminator.update(y1, num_positive=host[t.index])
+                        t.discriminator.update(y1, num_positive=host[t.index], count_dev=counts[f, t.index:t.index + 1])
                     else:
                         t.discriminator.update(y1, count_dev=counts[f, t.index:t.index + 1])
         else:

@@ -50,10 +50,11 @@ int frtm_pixel_weights(const void* y, int y_is_u8, int n, int H, int W, float tf
  * the first slot index is read from that device int32 (Memory.update's argmin, memory.py:80),
  * otherwise slot_host is used.  tf < 0: pw = 1.  pw != NULL: explicit (n,1,H,W) pixel weights are used
  * instead of the hinge rule (Memory.update's generic signature, memory.py:59).
- * scratch: >= n*FRTM_PX_PARTS floats. */
+ * scratch: >= n*FRTM_PX_PARTS floats.  px_count_dev: optional device int32[n] with the number of label pixels > 0.5 per
+ * sample (the caller often has it already: frtm_count_above for the early-out test); NULL: it is computed here. */
 int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int n, int H, int W, int h, int w,
                       float tf, const int* slot_dev, int slot_host, float* Bmem, float* cmem,
-                      float* scratch, frtm_stream_t stream);
+                      float* scratch, const int* px_count_dev, frtm_stream_t stream);
 
 /* Memory.update_sample_weights (model/memory.py:65-92) on the device, no host sync.
  * sw: (cap) sample weights, updated in place.  state: device int32[2] = {previous_replace_ind or -1,

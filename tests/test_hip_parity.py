@@ -62,6 +62,16 @@ def test_normal_build(H, W, h, w):
     mem2.initialize(feats.to(DEV), lab8.to(DEV), pwx.to(DEV))
     B2, c2 = O.lowres_normal(pwx, lab8.float(), (h, w))
     assert rel(mem2.normal_B[:n], B2) < 2e-5 and rel(mem2.normal_c[:n], c2) < 2e-5
+    # pixel counts handed in by the caller (ops.count_above) instead of being summed inside: same bits
+    mem3 = Memory(4, (2, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+    cnt = ops_mod().count_above(soft.to(DEV).reshape(n, H, W))
+    mem3._build_normals(soft.to(DEV), None, n, None, 0, px_count=cnt)
+    assert torch.equal(mem3.normal_B[:n], mem.normal_B[:n]) and torch.equal(mem3.normal_c[:n], mem.normal_c[:n])
+
+
+def ops_mod():
+    from frtm_vos_amd import ops as O_
+    return O_
 
 
 def test_memory_weights_g2(golden):
