@@ -236,6 +236,28 @@ def test_feature_batching_and_graphs_do_not_change_results():
         assert agree > 0.995, agree        # identical up to fp32 summation order inside the convs (split-K vs none)
 
 
+def test_window_tracking_with_a_late_object_matches_frame_by_frame():
+    """An object that appears mid-sequence cuts the tracking windows (its first frame is tracked on its own, its re-solve
+    phase differs from the others'): windowed run_sequence == frame-by-frame run_sequence."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    outs = []
+    for windows in (False, True):
+        torch.manual_seed(0)
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
+        params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+        trk = params.get_model().eval()
+        trk.window_tracking = windows
+        seq = SyntheticSequence('late', 30, (128, 160), 3, seed=4, late_object_at=11)
+        seq.preload(DEV)
+        labels, _ = trk.run_sequence(seq)
+        assert len(labels) == 30
+        outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
+    assert int(outs[1][11:].eq(3).sum()) > 0          # the late object (id 3) is present from its first frame on
+    agree = float((outs[0] == outs[1]).float().mean())
+    assert agree > 0.995, agree
+
+
 def test_trunk_lanes_and_graph_are_bit_identical_per_frame():
     """The lane split only changes which stream a frame's kernels run on: for the same per-lane batch size the taps are bit
     identical to a plain call, also when replayed from the captured graph and when a smaller batch reuses the tap buffers."""
