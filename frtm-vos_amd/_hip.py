@@ -54,6 +54,7 @@ SIGNATURES = {
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),
     'frtm_merge_masks': (I, [P, I, I, P]),
+    'frtm_merge_masks_frames': (I, [P, I, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),
     'frtm_bilinear_resize': (I, [P, I, I, I, P, I, I, P]),
     'frtm_tse_inject': (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),

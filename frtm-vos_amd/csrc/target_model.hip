@@ -636,6 +636,7 @@ __global__ __launch_bounds__(256) void k_transpose2d(const float* __restrict__ i
 // ------------------------------------------------------------------------------------------
 #define MERGE_MAX 16
 __global__ __launch_bounds__(256) void k_merge_masks(float* __restrict__ masks, int K, int HW) {
+  masks += (size_t)blockIdx.y * K * HW;                      // blockIdx.y = frame of a window
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     float p[MERGE_MAX];
     float bg = INFINITY;
@@ -876,8 +877,14 @@ int frtm_transpose2d(const float* in, int rows, int cols, float* out, frtm_strea
 }
 
 int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(masks && n_plus_1 >= 2 && n_plus_1 <= MERGE_MAX && HW > 0, "frtm_merge_masks: needs 2..%d mask planes, got %d", MERGE_MAX, n_plus_1);
-  k_merge_masks<<<min(ceil_div(HW, 256), 1024), 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
+  return frtm_merge_masks_frames(masks, 1, n_plus_1, HW, stream);
+}
+
+int frtm_merge_masks_frames(float* masks, int frames, int n_plus_1, int HW, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(masks && frames > 0 && n_plus_1 >= 2 && n_plus_1 <= MERGE_MAX && HW > 0,
+                 "frtm_merge_masks: needs 2..%d mask planes, got %d", MERGE_MAX, n_plus_1);
+  dim3 g(min(ceil_div(HW, 256), 1024), frames);
+  k_merge_masks<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

@@ -150,14 +150,16 @@ class Tracker(nn.Module):
         window = []                                          # frames waiting to be tracked together: (image, taps)
 
         def decode(masks):
+            """(W,n_obj+1,H,W) merged masks -> (W,1,H,W) uint8 label images (tracker.py:143-150), the whole window at once."""
             if len(sequence.obj_ids) == 1:
-                return object_ids[(masks[1:2] > 0.5).long()]
-            return object_ids[ops.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]   # tracker.py:146-150 (merge of merged masks)
+                return object_ids[(masks[:, 1:2] > 0.5).long()]
+            return object_ids[ops.merge_masks_(masks.clone()).argmax(dim=1, keepdim=True)]   # :146-150 (merge of merged masks)
 
         def flush():
             if window:
-                for masks in self.track_window([im for im, _ in window], [ft for _, ft in window]):
-                    outputs.append(decode(masks))
+                labels_w = decode(self.track_window([im for im, _ in window], [ft for _, ft in window]))
+                for f in range(labels_w.shape[0]):
+                    outputs.append(labels_w[f])
                     self.current_frame += 1
                 del window[:]
 
@@ -312,7 +314,7 @@ class Tracker(nn.Module):
         """track() for W consecutive frames at once (one contiguous slice of a trunk batch, same active objects, no filter
         re-solve before the last frame): one projection / score / refiner pass over W x n samples instead of W passes over n.
         Per frame the arithmetic is that of track(); the memory inserts and the re-solve run frame by frame afterwards, in order.
-        Returns the list of per-frame ``current_masks``."""
+        Returns the per-frame ``current_masks`` stacked: (W, n_obj+1, H, W)."""
         W = len(images)
         im_size = images[0].shape[-2:]
         first = taps[0]
@@ -335,9 +337,7 @@ class Tracker(nn.Module):
             for t2 in self.targets.values():
                 if t2 is not t1 and t2.start_frame == self.current_frame:
                     masks[0, t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
-        for f in range(W):
-            ops.merge_masks_(masks[f])                                                       # :214-221
-        out = [masks[f] for f in range(W)]
+        ops.merge_masks_(masks)                                                              # :214-221, all frames of the window
         if active and self.disc_params.update_filters:
             K = masks.shape[1]
             counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)                 # device int32, no sync
@@ -357,7 +357,7 @@ class Tracker(nn.Module):
                 for k, t in enumerate(active):
                     t.discriminator.advance(cfts[k][f:f + 1])
         self.current_masks = masks[W - 1]
-        return out
+        return masks
 
     @torch.no_grad()
     def track(self, image, features=None):

@@ -93,7 +93,11 @@ def pixel_weights(y, tf):
 
 
 def merge_masks_(masks):
-    """Tracker.track merge, in place on (n_obj+1,H,W)."""
+    """Tracker.track merge, in place on (n_obj+1,H,W), or on a window of frames (W,n_obj+1,H,W) in one launch."""
+    if masks.dim() == 4:
+        Wn, K, Hh, Ww = masks.shape
+        H.call('frtm_merge_masks_frames', H.ptr(masks), Wn, K, Hh * Ww)
+        return masks
     K, Hh, Ww = masks.shape
     H.call('frtm_merge_masks', H.ptr(masks), K, Hh * Ww)
     return masks

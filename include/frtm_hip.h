@@ -218,6 +218,8 @@ int frtm_backbone_generation(const frtm_backbone_t* bb);
  * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).
  * ------------------------------------------------------------------------------------------ */
 int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream);
+/* The same for `frames` consecutive (n_obj+1, H*W) stacks (a tracking window), one launch. */
+int frtm_merge_masks_frames(float* masks, int frames, int n_plus_1, int HW, frtm_stream_t stream);
 /* count[k] = #pixels with masks[k] > 0.5   (the early-out test of discriminator.py:214), int32[n] */
 int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, frtm_stream_t stream);
 
