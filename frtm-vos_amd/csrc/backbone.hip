@@ -12,6 +12,7 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
 struct ConvL {
   int Cout, Cin, ks, stride, pad;
   float* wT = nullptr; float* scale = nullptr; float* shift = nullptr; int* ktab = nullptr;
+  float* wW = nullptr;          // 3x3 stride-1 convs: second image of the weights, Winograd F(2x2,3x3) (FRTM_WLAYOUT_WINO3X3)
   bool loaded = false;
   int layout = 0;
 };
@@ -38,6 +39,7 @@ struct frtm_backbone {
   hipEvent_t fork = nullptr;
   double last_flops = 0.0;
   int last_launches = 0;
+  bool use_winograd = true;
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
@@ -108,7 +110,14 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
   }
   d.ws_elems = (int)std::min<size_t>(ln.ws_elems, 0x7fffffff);
   bb->last_launches += 1;
-  bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
+  bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;      // algorithmic (direct-form) FLOPs
+  // Winograd for the 3x3 stride-1 convs whenever the launch has enough 8x8 output blocks to fill the chip without split-K
+  if (c.wW && bb->use_winograd &&
+      (long)B * ceil_div(*Ho, 8) * ceil_div(*Wo, 8) * ceil_div(c.Cout, 32) >= FRTM_WINO_MIN_BLOCKS) {
+    d.w_layout = FRTM_WLAYOUT_WINO3X3;
+    d.splitk = 1;
+    return frtm_conv2d(&d, in, c.wW, nullptr, c.scale, c.shift, residual, out, ln.ws, st);
+  }
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
 }
 
@@ -240,6 +249,7 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
   if (!bb) return FRTM_OK;
   for (auto& c : bb->convs) {
     if (c.wT) (void)hipFree(c.wT);
+    if (c.wW) (void)hipFree(c.wW);
     if (c.scale) (void)hipFree(c.scale);
     if (c.shift) (void)hipFree(c.shift);
     if (c.ktab) (void)hipFree(c.ktab);
@@ -280,6 +290,11 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
   c.layout = (c.ks == 3 && c.stride <= 2 && c.pad == 1) ? FRTM_WLAYOUT_HALO3X3 : FRTM_WLAYOUT_GEMM;
   int rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, c.ks, c.layout, c.wT, c.ktab, stream);
   if (rc) return rc;
+  if (c.ks == 3 && c.stride == 1 && c.pad == 1) {
+    if (!c.wW) FRTM_HIP(hipMalloc((void**)&c.wW, (size_t)FRTM_CONV_WINO_ELEMS(c.Cout, c.Cin) * sizeof(float)));
+    rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, 3, FRTM_WLAYOUT_WINO3X3, c.wW, nullptr, stream);
+    if (rc) return rc;
+  }
   FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   FRTM_HIP(hipMemcpyAsync(c.shift, bn_shift, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   c.loaded = true;
@@ -289,6 +304,11 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
 int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->generation : 0; }
+int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
+  FRTM_CHECK_ARG(bb, "frtm_backbone_set_winograd: null handle");
+  bb->use_winograd = enable != 0;
+  return FRTM_OK;
+}
 
 int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
   FRTM_CHECK_ARG(bb && lanes >= 1 && lanes <= 8, "frtm_backbone_set_lanes: lanes must be 1..8");

@@ -18,48 +18,11 @@
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_common.h"
 
-struct ConvParams {
-  const float* in; const float* wT; const int* ktab; const float* scale; const float* shift;
-  const float* residual; float* out; float* ws;
-  int B, Cin, Hin, Win, M, Mp, Ho, Wo, K, stride, pad;
-  int Npix, Ntot, relu, out_transposed, splitk, chunks_per_split, nchunks;
-  unsigned in_bytes, w_bytes;
-};
-
-constexpr int BK = 32;                 // K granularity of the packed weights / split-K bookkeeping
-constexpr unsigned OOB = 0x80000000u;   // byte offset beyond any buffer: raw buffer loads return 0 there
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// XCD-aware block order.  Workgroup b runs on XCD b % 8 and each XCD has a private 4 MB L2, so the hardware order
-// scatters neighbouring tiles over all eight L2s and every XCD ends up fetching the whole activation matrix.  The remap
-// gives each XCD one contiguous range of logical tile ids (bijective for any nb), and inside it the M tiles vary fastest:
-// all workgroups that share an activation (N) tile run back to back on ONE XCD and hit its L2; the weights are the
-// small operand and are re-read per XCD.  Placement only affects speed, never results.
-__device__ __forceinline__ void tile_order(int id, int nb, int mt, int& m_tile, int& n_tile) {
-  const int xcd = id & 7, q = nb >> 3, r = nb & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  m_tile = logical % mt;
-  n_tile = logical / mt;
-}
-
-__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-
-__device__ __forceinline__ void store_out(const ConvParams& p, int m, int img, int rem, float v) {
-  if (p.scale) v = v * p.scale[m] + p.shift[m];
-  const size_t idx = ((size_t)img * p.M + m) * p.Npix + rem;
-  if (p.residual) v += p.residual[idx];
-  if (p.relu) v = fmaxf(v, 0.f);
-  if (p.out_transposed) p.out[((size_t)img * p.Npix + rem) * p.M + m] = v;
-  else p.out[idx] = v;
-}
+// conv_wino.hip
+int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_t st);
+int frtm_wino_launch(ConvParams& p, hipStream_t st);
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
@@ -498,6 +461,10 @@ extern "C" {
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout, float* wT, int* ktab,
                            frtm_stream_t stream) {
   FRTM_CHECK_ARG(w_oihw && wT && Cout > 0 && Cin > 0 && ksize > 0, "frtm_conv_pack_weights: bad argument");
+  if (layout == FRTM_WLAYOUT_WINO3X3) {
+    FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd layout is for 3x3 kernels");
+    return frtm_wino_pack(w_oihw, Cout, Cin, wT, (hipStream_t)stream);
+  }
   if (layout == FRTM_WLAYOUT_HALO3X3) {
     FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the halo layout is for 3x3 kernels");
     const size_t total = (size_t)ceil_div(Cin, HCI) * HK * ((Cout + 31) / 32 * 32);
@@ -539,6 +506,11 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   const size_t in_bytes = (size_t)d->B * d->Cin * d->Hin * d->Win * 4;
   FRTM_CHECK_ARG(in_bytes < 0x7fffffffull && w_bytes < 0x7fffffffull, "frtm_conv2d: tensor too large for 32-bit buffer offsets");
   p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
+  if (d->w_layout == FRTM_WLAYOUT_WINO3X3) {
+    FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
+                   "frtm_conv2d: the Winograd layout needs 3x3, stride 1, pad 1, NCHW output");
+    return frtm_wino_launch(p, (hipStream_t)stream);
+  }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");
   const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);

@@ -146,12 +146,25 @@ class ResnetFeatureExtractor:
         self._buf_serial = 0
         self.output_set = 0            # which persistent tap set to write (double buffering for the prefetch stream)
         self._lanes = 1
+        self._winograd = True
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
 
     @property
     def lanes(self):
         """Number of concurrent sub-batches of a batched call (frtm_backbone_set_lanes); results do not depend on it."""
         return self._lanes
+
+    @property
+    def winograd(self):
+        """3x3 stride-1 convs as Winograd F(2x2,3x3) when the launch is large enough (frtm_backbone_set_winograd)."""
+        return self._winograd
+
+    @winograd.setter
+    def winograd(self, on):
+        self._winograd = bool(on)
+        if self._handle is not None:
+            H.call_nostream('frtm_backbone_set_winograd', self._handle, int(self._winograd))
+            self._out_cache.clear()           # captured graphs hold the other kernels
 
     @lanes.setter
     def lanes(self, n):
@@ -190,6 +203,7 @@ class ResnetFeatureExtractor:
                 H.call_nostream('frtm_backbone_create', self.arch, ctypes.byref(h))
                 self._handle = h
                 H.call_nostream('frtm_backbone_set_lanes', h, self._lanes)
+                H.call_nostream('frtm_backbone_set_winograd', h, int(self._winograd))
             pairs = self.resnet.conv_bn_pairs()
             assert L.frtm_backbone_num_convs(self._handle) == len(pairs)
             info = (ctypes.c_int * 6)()

@@ -138,6 +138,7 @@ class SegNetwork(nn.Module):
         self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
         self._graphs = {}
         self._pack_key = None
+        self.use_winograd = True      # 3x3 convs as Winograd F(2x2,3x3) when the launch is large enough (frtm_conv2d, layout 2)
         self.fuse_tail = True         # up2 + resize + conv2 as one kernel when the resize ratio allows (frtm_project_tail)
         self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
         self._side = None
@@ -238,8 +239,9 @@ class SegNetwork(nn.Module):
                 shift = m.bias.data.float() if m.bias is not None else None
             if shift is not None and scale is None:
                 scale = torch.ones(cout, device=dev)
+            wW = ops.pack_weights(m.weight.data, wino=True)[0] if m.weight.shape[2] == 3 else None      # Winograd image of the 3x3s
             return dict(wT=wT, ktab=ktab, lay=lay, cout=cout, k=m.weight.shape[2], scale=None if scale is None else scale.contiguous(),
-                        shift=None if shift is None else shift.contiguous(), relu=relu_)
+                        shift=None if shift is None else shift.contiguous(), relu=relu_, wW=wW)
 
         def rrb(m):
             first = m.bblock[0]
@@ -269,8 +271,12 @@ class SegNetwork(nn.Module):
         self._pack, self._pack_key = P, key
         return P
 
-    @staticmethod
-    def _conv(x, c, residual=None):
+    def _conv(self, x, c, residual=None):
+        if c.get('wW') is not None and self.use_winograd:
+            n, _, hh, ww = x.shape
+            if n * ((hh + 7) // 8) * ((ww + 7) // 8) * ((c['cout'] + 31) // 32) >= 512:     # FRTM_WINO_MIN_BLOCKS
+                return ops.conv2d(x, c['wW'], c['cout'], 3, 1, 1, scale=c['scale'], shift=c['shift'], residual=residual,
+                                  relu=c['relu'], splitk=1, w_layout=2)
         return ops.conv2d(x, c['wT'], c['cout'], c['k'], 1, c['k'] // 2, ktab=c['ktab'], scale=c['scale'], shift=c['shift'],
                           residual=residual, relu=c['relu'], w_layout=c['lay'])
 

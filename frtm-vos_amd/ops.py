@@ -28,13 +28,14 @@ def padded_cols(M):
     return (M + 31) // 32 * 32
 
 
-def pack_weights(w_oihw, halo=None):
+def pack_weights(w_oihw, halo=None, wino=False):
     """(Cout,Cin,k,k) -> packed GEMM weights (+ ktab for k > 1).  3x3 kernels default to the halo layout
-    (valid for pad-1 convs of stride 1 or 2).  Returns (wT, ktab, layout)."""
+    (valid for pad-1 convs of stride 1 or 2); wino=True: Winograd F(2x2,3x3) image (stride 1, pad 1).
+    Returns (wT, ktab, layout)."""
     w = w_oihw.detach().float().contiguous()
     Cout, Cin, k, _ = w.shape
-    layout = 1 if (halo if halo is not None else k == 3) else 0
-    rows = max(padded_rows(Cin * k * k), (Cin + 7) // 8 * 72)
+    layout = 2 if wino else (1 if (halo if halo is not None else k == 3) else 0)
+    rows = max(padded_rows(Cin * k * k), (Cin + 7) // 8 * 72) if layout != 2 else (Cin + 7) // 8 * 128
     wT = torch.zeros(rows, padded_cols(Cout), device=w.device)
     ktab = torch.empty(Cin * k * k * 3, device=w.device, dtype=torch.int32) if (k > 1 and layout == 0) else None
     H.call('frtm_conv_pack_weights', H.ptr(w), Cout, Cin, k, layout, H.ptr(wT), H.ptr(ktab))

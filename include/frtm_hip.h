@@ -164,6 +164,11 @@ typedef struct {
  * (TH+2)x(TW+2) input patch once per 8 channels instead of the 9x redundant im2col image. */
 #define FRTM_WLAYOUT_GEMM 0
 #define FRTM_WLAYOUT_HALO3X3 1
+/* WINO3X3: Winograd F(2x2,3x3) transformed weights G g G^T, [ci/8][16 components][ci%8][Mp] (3x3, stride 1, pad 1 only;
+ * no split-K: meant for launches with enough output blocks, the caller keeps the HALO3X3 image for the small ones). */
+#define FRTM_WLAYOUT_WINO3X3 2
+#define FRTM_CONV_WINO_ELEMS(Cout, Cin) ((((Cin) + 7) / 8 * 128) * (((Cout) + 31) / 32 * 32))
+#define FRTM_WINO_MIN_BLOCKS 512   /* 8x8 output blocks x 32-channel tiles below which callers prefer HALO3X3 + split-K */
 #define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) \
   (((((Cin) * (k) * (k) + 31) / 32 * 32) > (((Cin) + 7) / 8 * 72) ? (((Cin) * (k) * (k) + 31) / 32 * 32) : (((Cin) + 7) / 8 * 72)) * (((Cout) + 31) / 32 * 32))
 #define FRTM_TILE_64x64 1
@@ -213,6 +218,9 @@ int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes);
  * (re)allocation: a caller that captured forward() into a hipGraph must re-capture when it has changed, and must run a
  * shape once eagerly before capturing it (allocation is not allowed during stream capture). */
 int frtm_backbone_generation(const frtm_backbone_t* bb);
+/* The trunk's 3x3 stride-1 convs run as Winograd F(2x2,3x3) when a launch has >= FRTM_WINO_MIN_BLOCKS output blocks
+ * (default on; results differ from the direct kernels by fp32 rounding only). */
+int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable);
 
 /* ------------------------------------------------------------------------------------------
  * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).

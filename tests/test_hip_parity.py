@@ -187,6 +187,28 @@ def test_conv2d_80_row_halo_tile(ops, cout, splitk):
     assert rel(out, torch.relu(F.conv2d(x, w, b, padding=1))) < 2e-5
 
 
+@pytest.mark.parametrize('B,Cin,H,W,Cout', [(1, 8, 8, 8, 32), (2, 64, 30, 54, 64), (1, 65, 21, 37, 65), (3, 20, 9, 11, 40), (1, 256, 15, 27, 96),
+                                             (2, 16, 120, 214, 32)])
+def test_conv2d_winograd(ops, B, Cin, H, W, Cout):
+    """Winograd F(2x2,3x3) kernel (layout 2) == F.conv2d; epilogue (BN, residual, ReLU), channel tails, ragged 8x8 blocks."""
+    g = gen(B * Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    wT, ktab, lay = ops.pack_weights(w.to(DEV), wino=True)
+    assert lay == 2 and ktab is None
+    out = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, w_layout=lay)
+    assert rel(out, ref) < 2e-5, rel(out, ref)
+    out2 = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), relu=True, w_layout=lay)
+    ref2 = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    assert rel(out2, ref2) < 2e-5
+    with pytest.raises(RuntimeError, match='Winograd'):
+        ops.conv2d(x.to(DEV), wT, Cout, 3, 2, 1, w_layout=lay)
+
+
 def test_conv_as_weight_gradient(ops):
     """g1[c,ci] = sum_{n,pix} D[n,pix,c] X[n,pix,ci]: the init problem's second GEMM (K = N*h*w)."""
     g = gen(9)

@@ -54,6 +54,7 @@ def main():
     ap.add_argument('--sweep', action='store_true')
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--set', default='trunk', choices=['trunk', 'refiner'])
+    ap.add_argument('--wino', action='store_true', help='also time the Winograd kernel on the 3x3 stride-1 shapes')
     args = ap.parse_args()
     dev = 'cuda:0'
     total_us, total_fl = 0.0, 0.0
@@ -68,6 +69,10 @@ def main():
         out = torch.empty(args.batch, cout, ho, wo, device=dev)
         t = timeit(lambda: ops.conv2d(x, wT, cout, k, s, pad, ktab=ktab, scale=sc, shift=sh, relu=True, out=out, w_layout=lay))
         line = '%4d->%4d k%d s%d %3dx%3d x%2d  auto %7.1f us %6.1f TF' % (cin, cout, k, s, h, w, cnt, t, fl / t / 1e6)
+        if args.wino and k == 3 and s == 1:
+            wW, _, layW = ops.pack_weights(wt, wino=True)
+            tw = timeit(lambda: ops.conv2d(x, wW, cout, k, s, pad, scale=sc, shift=sh, relu=True, out=out, w_layout=layW))
+            line += '   winograd %7.1f us %6.1f TF(eff)' % (tw, fl / tw / 1e6)
         total_us += t * cnt
         total_fl += fl * cnt
         if args.sweep:
