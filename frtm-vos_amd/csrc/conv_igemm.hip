@@ -22,7 +22,7 @@
 
 // conv_wino.hip
 int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_t st);
-int frtm_wino_launch(ConvParams& p, hipStream_t st);
+int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st);
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
@@ -509,7 +509,8 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if (d->w_layout == FRTM_WLAYOUT_WINO3X3) {
     FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
                    "frtm_conv2d: the Winograd layout needs 3x3, stride 1, pad 1, NCHW output");
-    return frtm_wino_launch(p, (hipStream_t)stream);
+    FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 3, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8)");
+    return frtm_wino_launch(p, d->tile, (hipStream_t)stream);
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");

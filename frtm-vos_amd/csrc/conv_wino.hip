@@ -14,17 +14,17 @@
 // fp32 throughout; the transforms only add, subtract and halve, so the result differs from the direct kernel by rounding
 // (a few 1e-7 relative per layer), far inside the 1e-3 the masks are held to.
 #include <algorithm>
+#include <type_traits>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 #include "conv_common.h"
 
 constexpr int WCI = 8;                 // input channels per chunk
 constexpr int WBM = 32;                // output channels per workgroup
-constexpr int WRAW = 104;              // pitch of one channel's 10x10 raw patch
 constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight block: [xi][lane][(kk,i)]
 
-// LDS carries only the raw input patch (6.6 KB, double buffered) and, at the end, the accumulator planes for the output
-// transform.  A first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
+// LDS carries only the raw input patch (double buffered) and, at the end, the accumulator planes for the output transform.  A
+// first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
 // LDS-bandwidth bound (59 KB of LDS traffic per 64 MFMAs; the skeleton without MFMAs took 73 % of the time).  Now
 //  * the weights are packed in MFMA A-fragment order ([chunk][m_tile][xi][lane][4]) and go from L2 straight into registers:
 //    one dwordx4 per lane per component per chunk, a fully coalesced 1 KB per wave instruction;
@@ -32,126 +32,166 @@ constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight b
 //    B fragments V[wid][0..3] for (channel = kk*4 + lane/16, tile = lane%16) from the two raw rows that row needs -- 8 LDS
 //    values in, 4 MFMA operands out, no transformed image in LDS and no transform stage;
 //  * one barrier per chunk (raw patch double buffer).
+// FN = 1: 8x8 output block (16 tiles).  FN = 2: 32 tiles per workgroup, as 8 rows x 16 columns (TALL = 0) or 16 rows x 8
+// columns (TALL = 1): every weight fragment feeds two MFMAs, which halves the L2 -> register weight traffic per FLOP (the
+// heaviest stream of this kernel: 16 KB per chunk per workgroup).
+template <int FN, int TALL>
 __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
+  constexpr int BH = (FN == 2 && TALL) ? 16 : 8, BW = (FN == 2 && !TALL) ? 16 : 8;      // output block
+  constexpr int PR = BH + 2, PC = BW + 2, PE = PR * PC;                                 // raw patch of one channel
+  constexpr int WRAW = (PE + 3) / 4 * 4 + 4;                                            // its pitch
+  constexpr int NR = (WCI * PE + 255) / 256;                                            // raw elements per thread
   __shared__ __attribute__((aligned(16))) float Raw[2][WCI][WRAW];
-  __shared__ __attribute__((aligned(16))) float Ms[16 * WBM * 16];          // epilogue: M[xi][cout][tile]
+  __shared__ __attribute__((aligned(16))) float Ms[16 * WBM * 16];          // epilogue: M[xi][cout][tile] of one fragment column
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, li = lane & 15;
-  const int tiles_x = (p.Wo + 7) / 8, tiles_y = (p.Ho + 7) / 8;
+  const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
   const int mt = (p.M + WBM - 1) / WBM;
   int m_tile, bt;
   tile_order(blockIdx.x, gridDim.x, mt, m_tile, bt);
   const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
   const int by = bt / tiles_x, bx = bt - by * tiles_x;
-  const int y0 = by * 8, x0 = bx * 8, m0 = m_tile * WBM;
+  const int y0 = by * BH, x0 = bx * BW, m0 = m_tile * WBM;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
 
-  // raw patch staging: 8 channels x 10 x 10, element e = tid + i*256
-  unsigned r_goff[4]; int r_loff[4], r_ci[4];
+  // raw patch staging: 8 channels x PR x PC, element e = tid + i*256
+  unsigned r_goff[NR]; int r_loff[NR], r_ci[NR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NR; ++i) {
     const int e = tid + i * 256;
-    const int ci = e / 100, q = e - ci * 100, r = q / 10, c = q - r * 10;
+    const int ci = e / PE, q = e - ci * PE, r = q / PC, c = q - r * PC;
     const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-    const bool ok = e < WCI * 100 && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
+    const bool ok = e < WCI * PE && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
     r_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
-    r_loff[i] = e < WCI * 100 ? ci * WRAW + q : -1;
+    r_loff[i] = e < WCI * PE ? ci * WRAW + q : -1;
     r_ci[i] = ci;
   }
   // this lane's weight fragments: component q of wave wid, chunk kc  ->  float4 {(kk0,i0), (kk0,i1), (kk1,i0), (kk1,i1)}
   const unsigned a_lane = (unsigned)(((m_tile * 16 + wid * 4) * 64 + lane) * 16);       // bytes inside a chunk's block row
   const unsigned a_chunk = (unsigned)mt * WFRAG * 4u;                                  // bytes per chunk
-  // row `wid` of B^T d:  r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3   ->  u = sa * d[ra] + sb * d[rb]
+  // row `wid` of B^T d:  r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3   ->  u = d[ra] + sb * d[rb]
   const int ra_ = (wid == 0) ? 0 : (wid == 2 ? 2 : 1), rb_ = (wid == 3) ? 3 : (wid == 2 ? 1 : 2);
   const float sb_ = (wid == 1) ? 1.f : -1.f;
-  // raw offsets of this lane's two patch rows (tile li: origin (2*(li>>2), 2*(li&3)) in the 10x10 patch), channel kk*4 + lk
-  const int p_off = (2 * (li >> 2)) * 10 + 2 * (li & 3);
-  const int offA = lk * WRAW + p_off + ra_ * 10, offB = lk * WRAW + p_off + rb_ * 10;
+  // tile of fragment column j: (row, col) among the block's tiles; its 4x4 patch starts at (2*row, 2*col) of the raw patch
+  int t_r[FN], t_c[FN], offA[FN], offB[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    t_r[j] = (li >> 2) + ((FN == 2 && TALL) ? 4 * j : 0);
+    t_c[j] = (li & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
+    const int po = (2 * t_r[j]) * PC + 2 * t_c[j];
+    offA[j] = lk * WRAW + po + ra_ * PC;
+    offB[j] = lk * WRAW + po + rb_ * PC;
+  }
 
-  f32x4 fa[2][4];
-  float rr[4];
+  // Register ring of 4 chunks: the loads of chunk k+3 are issued while chunk k is computed.  A chunk is only 16 (32) MFMAs per
+  // wave, far less than the L2 / HBM latency; with a one-chunk look-ahead every chunk waited for its own loads (the kernel ran
+  // at the same speed with the MFMAs removed).
+  f32x4 fa[4][4];
+  float rr[4][NR];
   auto gloadA = [&](int kc, f32x4* dst) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = buf_ld4(rw, (unsigned)kc * a_chunk + a_lane + (unsigned)(q * 64 * 16));
   };
-  auto gloadR = [&](int kc) {
+  auto gloadR = [&](int kc, float* dst) {
     const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       unsigned o = r_goff[i] == OOB ? OOB : r_goff[i] + cstep;
       if (kc * WCI + r_ci[i] >= p.Cin) o = OOB;                       // channel tail of a Cin that is not a multiple of 8
-      rr[i] = buf_ld1(rin, o);
+      dst[i] = buf_ld1(rin, o);
     }
   };
-  auto lstoreR = [&](int buf) {
+  auto lstoreR = [&](int buf, const float* src) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (r_loff[i] >= 0) (&Raw[buf][0][0])[r_loff[i]] = rr[i];
+    for (int i = 0; i < NR; ++i) if (r_loff[i] >= 0) (&Raw[buf][0][0])[r_loff[i]] = src[i];
   };
 
-  f32x4 acc[4][2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  const int nch = p.nchunks;
-  gloadA(0, fa[0]);
-  gloadR(0);
-  lstoreR(0);
-  __syncthreads();
-  for (int kc = 0; kc < nch; ++kc) {
-    const int cur = kc & 1;
-    const bool more = kc + 1 < nch;
-    if (more) { gloadA(kc + 1, fa[cur ^ 1]); gloadR(kc + 1); }
-    const float* R = &Raw[cur][0][0];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const float* da = R + kk * 4 * WRAW + offA;
-      const float* db = R + kk * 4 * WRAW + offB;
-      const float u0 = da[0] + sb_ * db[0], u1 = da[1] + sb_ * db[1], u2 = da[2] + sb_ * db[2], u3 = da[3] + sb_ * db[3];
-      const float b0 = u0 - u2, b1 = u1 + u2, b2 = u2 - u1, b3 = u1 - u3;                // (B^T d) B, columns 0..3
-      const float bq[4] = {b0, b1, b2, b3};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][q][kk * 2 + 0], bq[q], acc[q][0], 0, 0, 0);
-        acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][q][kk * 2 + 1], bq[q], acc[q][1], 0, 0, 0);
-      }
-    }
-    if (more) lstoreR(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- output transform: the 16 component planes of a (cout, tile) pair sit in 4 different waves -> through LDS ----
+  f32x4 acc[4][2][FN];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ms[(wid * 4 + q) * 512 + (i * 16 + lk * 4 + r) * 16 + li] = acc[q][i][r];
+      for (int j = 0; j < FN; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nch = p.nchunks;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < nch) { gloadA(k, fa[k]); gloadR(k, rr[k]); }
+  lstoreR(0, rr[0]);
   __syncthreads();
+  // one chunk; S = k & 3 is a compile-time constant so that the ring stays in registers
+  auto chunk = [&](int k, auto S_) {
+    constexpr int S = decltype(S_)::value;
+    if (k + 3 < nch) { gloadA(k + 3, fa[(S + 3) & 3]); gloadR(k + 3, rr[(S + 3) & 3]); }
+    const float* R = &Raw[k & 1][0][0];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pidx = tid + j * 256;                           // (cout, tile) pair
-    const int co = pidx >> 4, t = pidx & 15;
-    const int mm = m0 + co;
-    float m[16];
+    for (int kk = 0; kk < 2; ++kk) {
+      float bq[FN][4];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[xi * 512 + pidx];
-    if (mm >= p.M) continue;
-    float s[2][4];
+      for (int j = 0; j < FN; ++j) {
+        const float* da = R + kk * 4 * WRAW + offA[j];
+        const float* db = R + kk * 4 * WRAW + offB[j];
+        const float u0 = da[0] + sb_ * db[0], u1 = da[1] + sb_ * db[1], u2 = da[2] + sb_ * db[2], u3 = da[3] + sb_ * db[3];
+        bq[j][0] = u0 - u2; bq[j][1] = u1 + u2; bq[j][2] = u2 - u1; bq[j][3] = u1 - u3;      // (B^T d) B, columns 0..3
+      }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      s[0][c] = m[c] + m[4 + c] + m[8 + c];
-      s[1][c] = m[4 + c] - m[8 + c] - m[12 + c];
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][q][kk * 2 + 0], bq[j][q], acc[q][0][j], 0, 0, 0);
+          acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][q][kk * 2 + 1], bq[j][q], acc[q][1][j], 0, 0, 0);
+        }
     }
+    if (k + 1 < nch) lstoreR((k + 1) & 1, rr[(S + 1) & 3]);      // loaded two chunks ago
+    __syncthreads();
+  };
+  for (int kc = 0; kc < nch; kc += 4) {
+    chunk(kc, std::integral_constant<int, 0>{});
+    if (kc + 1 < nch) chunk(kc + 1, std::integral_constant<int, 1>{});
+    if (kc + 2 < nch) chunk(kc + 2, std::integral_constant<int, 2>{});
+    if (kc + 3 < nch) chunk(kc + 3, std::integral_constant<int, 3>{});
+  }
+
+  // ---- output transform: the 16 component planes of a (cout, tile) pair sit in 4 different waves -> through LDS, one fragment
+  // column (16 tiles) at a time ----
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int yy = y0 + 2 * (t >> 2) + a;
-      if (yy >= p.Ho) continue;
-      const float v0 = s[a][0] + s[a][1] + s[a][2], v1 = s[a][1] - s[a][2] - s[a][3];
-      const int xx = x0 + 2 * (t & 3);
-      if (xx < p.Wo) store_out(p, mm, img, yy * p.Wo + xx, v0);
-      if (xx + 1 < p.Wo) store_out(p, mm, img, yy * p.Wo + xx + 1, v1);
+  for (int j = 0; j < FN; ++j) {
+    if (j > 0) __syncthreads();                               // Ms of the previous column has been consumed
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ms[(wid * 4 + q) * 512 + (i * 16 + lk * 4 + r) * 16 + li] = acc[q][i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pidx = tid + h * 256;                         // (cout, tile) pair
+      const int co = pidx >> 4, t = pidx & 15;
+      const int mm = m0 + co;
+      float m[16];
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[xi * 512 + pidx];
+      if (mm >= p.M) continue;
+      const int tr = (t >> 2) + ((FN == 2 && TALL) ? 4 * j : 0), tc = (t & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
+      float s[2][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s[0][c] = m[c] + m[4 + c] + m[8 + c];
+        s[1][c] = m[4 + c] - m[8 + c] - m[12 + c];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int yy = y0 + 2 * tr + a;
+        if (yy >= p.Ho) continue;
+        const float v0 = s[a][0] + s[a][1] + s[a][2], v1 = s[a][1] - s[a][2] - s[a][3];
+        const int xx = x0 + 2 * tc;
+        if (xx < p.Wo) store_out(p, mm, img, yy * p.Wo + xx, v0);
+        if (xx + 1 < p.Wo) store_out(p, mm, img, yy * p.Wo + xx + 1, v1);
+      }
     }
   }
 }
@@ -193,12 +233,29 @@ int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_
   return FRTM_OK;
 }
 
-int frtm_wino_launch(ConvParams& p, hipStream_t st) {
+int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
   p.nchunks = ceil_div(p.Cin, WCI);
   p.w_bytes = (unsigned)((size_t)p.nchunks * ceil_div(p.M, WBM) * WFRAG * 4);
   p.splitk = 1;
-  const int blocks = p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * ceil_div(p.M, WBM);
-  k_conv3x3_wino<<<blocks, 256, 0, st>>>(p);
+  const int mt = ceil_div(p.M, WBM);
+  // output block: 8x8 (variant 1), 8 rows x 16 cols (2), 16 rows x 8 cols (3).  0 = auto: the 32-tile forms halve the weight
+  // traffic per FLOP; among them the one with the smaller padded area, unless its padding eats the gain (> 15 % more pixels
+  // than 8x8 blocks) or it would leave fewer than ~2 workgroups per CU.
+  auto padded = [&](int bh, int bw) { return (long)ceil_div(p.Ho, bh) * bh * ceil_div(p.Wo, bw) * bw; };
+  if (variant == 0) {
+    const long a1 = padded(8, 8), a2 = padded(8, 16), a3 = padded(16, 8);
+    variant = a2 <= a3 ? 2 : 3;
+    const long a = variant == 2 ? a2 : a3;
+    const long blocks2 = (long)p.B * (a / 128) * mt;
+    if (mt > 1 || a * 100 > a1 * 115 || blocks2 < 512) variant = 1;     // measured: the 32-tile forms only pay for a single M tile
+  }
+  if (variant == 2) {
+    k_conv3x3_wino<2, 0><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);
+  } else if (variant == 3) {
+    k_conv3x3_wino<2, 1><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
+  } else {
+    k_conv3x3_wino<1, 0><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
+  }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

@@ -200,11 +200,13 @@ def test_conv2d_winograd(ops, B, Cin, H, W, Cout):
     res = torch.randn(ref.shape, generator=g)
     wT, ktab, lay = ops.pack_weights(w.to(DEV), wino=True)
     assert lay == 2 and ktab is None
-    out = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, w_layout=lay)
-    assert rel(out, ref) < 2e-5, rel(out, ref)
-    out2 = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), relu=True, w_layout=lay)
     ref2 = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
-    assert rel(out2, ref2) < 2e-5
+    for tile in (0, 1, 2, 3):                # output block: auto, 8x8, 8 rows x 16 cols, 16 rows x 8 cols
+        out = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, w_layout=lay, tile=tile)
+        assert rel(out, ref) < 2e-5, (tile, rel(out, ref))
+        out2 = ops.conv2d(x.to(DEV), wT, Cout, 3, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), relu=True,
+                          w_layout=lay, tile=tile)
+        assert rel(out2, ref2) < 2e-5, tile
     with pytest.raises(RuntimeError, match='Winograd'):
         ops.conv2d(x.to(DEV), wT, Cout, 3, 2, 1, w_layout=lay)
 

@@ -71,8 +71,9 @@ def main():
         line = '%4d->%4d k%d s%d %3dx%3d x%2d  auto %7.1f us %6.1f TF' % (cin, cout, k, s, h, w, cnt, t, fl / t / 1e6)
         if args.wino and k == 3 and s == 1:
             wW, _, layW = ops.pack_weights(wt, wino=True)
-            tw = timeit(lambda: ops.conv2d(x, wW, cout, k, s, pad, scale=sc, shift=sh, relu=True, out=out, w_layout=layW))
-            line += '   winograd %7.1f us %6.1f TF(eff)' % (tw, fl / tw / 1e6)
+            for var in (0, 1, 2, 3):
+                tw = timeit(lambda: ops.conv2d(x, wW, cout, k, s, pad, scale=sc, shift=sh, relu=True, out=out, w_layout=layW, tile=var))
+                line += '  W%d %6.1f us %5.1f' % (var, tw, fl / tw / 1e6)
         total_us += t * cnt
         total_fl += fl * cnt
         if args.sweep:
