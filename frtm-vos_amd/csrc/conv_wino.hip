@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
     if (kc + 3 < nch) chunk(kc + 3, std::integral_constant<int, 3>{});
   }
 
+  const bool pair_ok = (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
   // ---- output transform: the 16 component planes of a (cout, tile) pair sit in 4 different waves -> through LDS, one fragment
   // column (16 tiles) at a time ----
 #pragma unroll
@@ -183,14 +184,26 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
         s[0][c] = m[c] + m[4 + c] + m[8 + c];
         s[1][c] = m[4 + c] - m[8 + c] - m[12 + c];
       }
+      const float sc = p.scale ? p.scale[mm] : 1.f, sh = p.scale ? p.shift[mm] : 0.f;
+      const int xx = x0 + 2 * tc;
+      const size_t plane = ((size_t)img * p.M + mm) * p.Npix;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int yy = y0 + 2 * tr + a;
-        if (yy >= p.Ho) continue;
-        const float v0 = s[a][0] + s[a][1] + s[a][2], v1 = s[a][1] - s[a][2] - s[a][3];
-        const int xx = x0 + 2 * tc;
-        if (xx < p.Wo) store_out(p, mm, img, yy * p.Wo + xx, v0);
-        if (xx + 1 < p.Wo) store_out(p, mm, img, yy * p.Wo + xx + 1, v1);
+        if (yy >= p.Ho || xx >= p.Wo) continue;
+        float v0 = (s[a][0] + s[a][1] + s[a][2]) * sc + sh, v1 = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
+        const size_t o = plane + (size_t)yy * p.Wo + xx;
+        const bool two = xx + 1 < p.Wo;
+        if (two && (o & 1) == 0 && pair_ok) {                 // both pixels of the row as one 8-byte access
+          if (p.residual) { const float2 rv = *(const float2*)&p.residual[o]; v0 += rv.x; v1 += rv.y; }
+          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          *(float2*)&p.out[o] = make_float2(v0, v1);
+        } else {
+          if (p.residual) { v0 += p.residual[o]; if (two) v1 += p.residual[o + 1]; }
+          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          p.out[o] = v0;
+          if (two) p.out[o + 1] = v1;
+        }
       }
     }
   }
