@@ -286,7 +286,7 @@ def main():
                                 'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.trunk_batch, args.trunk_lanes),
                    'warmup_frames_run': warm_frames,
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm (fp32 MFMA implicit-GEMM conv, whole ResNet trunk)',
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
                      'traffic': traffic,
                      # avg_ms = HIP-event time of the trunk passes / conv launches: the EFFECTIVE duration per launch.  With

@@ -51,7 +51,7 @@ def union_ns(intervals):
     return total
 
 
-CONV = ('k_conv_igemm', 'k_conv3x3_halo', 'k_splitk_epilogue')
+CONV = ('k_conv_igemm', 'k_conv3x3_halo', 'k_conv3x3_wino', 'k_splitk_epilogue')
 inwin = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in tr if int(r['Start_Timestamp']) >= t1 - win]
 occupied = union_ns([(a, e) for a, e, _ in inwin])
 with open(os.path.join(out, tag + '_steady_state.csv'), 'w') as f:

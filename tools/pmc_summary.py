@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-FAMILY = ('k_conv_igemm', 'k_conv3x3_halo', 'k_splitk_epilogue')
+FAMILY = ('k_conv_igemm', 'k_conv3x3_halo', 'k_conv3x3_wino', 'k_splitk_epilogue')
 
 
 def load(d, counter):
