@@ -97,14 +97,24 @@ class ImageAugmenter:
     # ---- image pieces -----------------------------------------------------------------------------
     @staticmethod
     def _bbox(mask):
-        m = mask.squeeze()
-        ys = m.sum(dim=-1).nonzero(as_tuple=False).view(-1)
-        xs = m.sum(dim=-2).nonzero(as_tuple=False).view(-1)
-        if ys.numel() == 0 or xs.numel() == 0:
-            return 0, 0, 0, 0
-        x0, x1, y0, y1 = int(xs[0]), int(xs[-1]), int(ys[0]), int(ys[-1])
+        return ImageAugmenter._count_and_bbox(mask)[1]
+
+    @staticmethod
+    def _count_and_bbox(mask):
+        """(pixel count, (cx, cy, w, h)) of a binary mask with ONE device -> host transfer (each int(tensor) is a stream sync)."""
+        m = mask.squeeze() > 0
+        Hh, Ww = m.shape
+        rows, cols = m.any(dim=-1), m.any(dim=-2)
+        ri = torch.arange(Hh, device=m.device)
+        ci = torch.arange(Ww, device=m.device)
+        big = max(Hh, Ww)
+        vals = torch.stack((m.sum(), torch.where(cols, ci, big).min(), torch.where(cols, ci, -1).max(),
+                            torch.where(rows, ri, big).min(), torch.where(rows, ri, -1).max())).tolist()
+        n_px, x0, x1, y0, y1 = (int(v) for v in vals)
+        if n_px == 0:
+            return 0, (0, 0, 0, 0)
         w, h = x1 - x0 + 1, y1 - y0 + 1
-        return x0 + w / 2, y0 + h / 2, w, h
+        return n_px, (x0 + w / 2, y0 + h / 2, w, h)
 
     @staticmethod
     def _fill_hole(image, hole, iters=None):
@@ -146,11 +156,10 @@ class ImageAugmenter:
     def augment_first_frame(self, im, lb):
         p = self.params
         im_sz = tuple(im.shape[-2:])
-        n_px = int(lb.sum())
+        n_px, box = self._count_and_bbox(lb)
         if n_px < p.min_px_count:
             raise ValueError('Augmentation failed: Target object is too small.')
         no_background = n_px == lb.numel()
-        box = self._bbox(lb)
         if box[-2:] == (0, 0):
             raise ValueError('Augmentation failed: No object to augment.')
         mask = (lb.reshape(1, *im_sz) > 0).float()
@@ -169,6 +178,7 @@ class ImageAugmenter:
                 raise RuntimeError('Augmentation failed: Not enough samples after %d retries.' % self.max_retries)
             fg_specs = self._draw_specs(fg, N)
             bg_specs = self._draw_specs(bg, N) if bg is not None else [None] * N
+            batch = []                                        # this round's candidates; their pixel counts come back in one transfer
             for fs, bs in zip(fg_specs, bg_specs):
                 canvas = background
                 if bs is not None:
@@ -181,10 +191,13 @@ class ImageAugmenter:
                 wl = warp_affine(mask, T, im_sz, 'nearest')
                 alpha = wt[3:4] / 255
                 out = (wt[:3] * alpha + canvas * (1 - alpha)).to(torch.uint8)
-                cnt = int((wl > 0).sum())
-                if cnt >= p.min_px_count and (cnt < wl.numel() - p.min_px_count or no_background):
+                lab = wl > 0
+                batch.append((out, lab, lab.sum()))
+            counts = torch.stack([c for _, _, c in batch]).tolist()
+            for (out, lab, _), cnt in zip(batch, counts):
+                if cnt >= p.min_px_count and (cnt < lab.numel() - p.min_px_count or no_background):
                     images.append(out)
-                    labels.append((wl > 0).to(torch.uint8))
+                    labels.append(lab.to(torch.uint8))
         if len(images) > N:
             order = list(range(len(images)))
             np.random.shuffle(order)
