@@ -36,6 +36,7 @@ class FrameTaps(dict):
     def __init__(self, batch, k):
         super().__init__({L: t[k:k + 1] for L, t in batch.items()})
         self.batch, self.k = batch, k
+        self.last = k + 1 == next(iter(batch.values())).shape[0]      # last frame of its trunk batch
 
 
 class TargetObject:
@@ -181,8 +182,8 @@ class Tracker(nn.Module):
                 if window and not self._extends(window[-1][1], feats):
                     flush()
                 window.append((image, feats))
-                if self._window_complete(len(window), image):
-                    flush()
+                if self._window_complete(len(window), image) or getattr(feats, 'last', True):
+                    flush()                                  # (also at the end of a trunk batch: its taps are about to be overwritten)
             else:
                 if isinstance(labels, list) and len(labels) == 0:
                     labels = image.new_zeros(1, *image.shape[-2:])
@@ -252,18 +253,25 @@ class Tracker(nn.Module):
                 taps, ev = ext(batch), None
             pending[i0] = (taps, ev, idx)
 
-        launch(0)
+        # Single stream: a pass is enqueued when its first frame is asked for -- by then run_sequence has flushed every window of the
+        # previous batch (windows end with the last frame of a trunk batch), so the one persistent tap set can be overwritten.
+        # Side stream: one pass AHEAD, into the other tap set.
+        if side is not None:
+            launch(0)
         cache, bi = {}, 0
         for i, (image, labels, new_objects) in enumerate(frames):
             feats = None
             if i > 0:
                 if i not in cache:
+                    if side is None:
+                        launch(bi)
                     taps, ev, idx = pending.pop(i)
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                     cache = {j: FrameTaps(taps, k) for k, j in enumerate(idx)}
                     bi += 1
-                    launch(bi)                              # next batch starts while this one is being tracked
+                    if side is not None:
+                        launch(bi)                          # next batch runs on the side stream while this one is being tracked
                 feats = cache.pop(i)
             yield image, labels, new_objects, feats
 

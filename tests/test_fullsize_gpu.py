@@ -236,6 +236,67 @@ def test_feature_batching_and_graphs_do_not_change_results():
         assert agree > 0.995, agree        # identical up to fp32 summation order inside the convs (split-K vs none)
 
 
+@pytest.mark.parametrize('prefetch', [False, True])
+def test_yielded_taps_belong_to_their_frames(prefetch):
+    """frames_with_features hands every frame the taps of THAT frame (the persistent tap buffers are overwritten by later trunk
+    passes: a pass must not be enqueued before the frames of the previous one have been consumed)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    trk = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=4).get_model().eval()
+    trk.prefetch_stream = prefetch
+    seq = SyntheticSequence('s', 14, (128, 160), 1, seed=3)
+    seq.preload(DEV)
+    ref_ext = ResnetFeatureExtractor('resnet18').to(DEV)
+    ref_ext.resnet.load_state_dict(trk.feature_extractor.resnet.state_dict())
+    ref_ext.upload()
+    seen = 0
+    for i, (image, labels, new_objects, feats) in enumerate(trk.frames_with_features(seq)):
+        if feats is None:
+            continue
+        for L in ('layer2', 'layer4', 'layer5'):
+            ref = ref_ext(image.to(DEV), [L])[L]
+            assert rel(feats[L], ref) < 1e-4, (i, L)
+        seen += 1
+    assert seen == 13
+
+
+def test_run_sequence_matches_the_literal_per_frame_loop():
+    """run_sequence (batched trunk, window tracking, graphs) against the reference's own loop shape: initialize(), then
+    track(image) frame by frame with the trunk called per frame (tracker.py:130-157)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd import ops as O_
+
+    def make():
+        torch.manual_seed(0)
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
+        params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+        return params.get_model().eval()
+
+    seq = SyntheticSequence('lit', 21, (128, 160), 2, seed=9)
+    seq.preload(DEV)
+    fast, _ = make().run_sequence(seq)
+    fast = torch.stack([l.reshape(128, 160) for l in fast]).cpu()
+    trk = make()
+    ids = torch.tensor([0] + list(seq.obj_ids), dtype=torch.uint8, device=DEV)
+    slow = []
+    for i, (image, labels, new_objects) in enumerate(seq):
+        image = image.to(DEV)
+        had = len(trk.targets) > 0
+        if len(new_objects) > 0:
+            labels = labels.to(DEV)
+            trk.initialize(image, labels, new_objects)
+        if had:
+            masks = trk.track(image)                              # trunk called for this frame only
+            labels = ids[O_.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]
+        slow.append(labels.reshape(128, 160).cpu())
+        trk.current_frame += 1
+    slow = torch.stack(slow)
+    agree = float((fast == slow).float().mean())
+    assert agree > 0.995, agree
+
+
 def test_window_tracking_with_a_late_object_matches_frame_by_frame():
     """An object that appears mid-sequence cuts the tracking windows (its first frame is tracked on its own, its re-solve
     phase differs from the others'): windowed run_sequence == frame-by-frame run_sequence."""
