@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')
     ap.add_argument('--no-windows', action='store_true', help='track frame by frame instead of one window per filter re-solve interval')
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convs on the direct (halo) kernels only')
+    ap.add_argument('--first-pass-overlap', action='store_true', help='first trunk pass on a side stream next to the fits of initialize()')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
@@ -217,6 +218,7 @@ def main():
     tracker.prefetch_stream = args.overlap
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
+    tracker.overlap_first_pass = args.first_pass_overlap
     if args.no_winograd:
         tracker.refiner.use_winograd = False
         tracker.feature_extractor.winograd = False

@@ -66,6 +66,10 @@ class Tracker(nn.Module):
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
         self.graph_trunk = True
+        self.overlap_first_pass = False  # first trunk pass of a sequence on a side stream, next to initialize()'s fits (measured: no gain
+                                         # with 2 objects -- the fits just run slower next to the trunk kernels --, +3 % with 5)
+        self._after_init_trunk = None
+        self._first_stream = None
         self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self._init_pool = []
@@ -95,6 +99,11 @@ class Tracker(nn.Module):
                 self._disc_pool.append(t.discriminator)
                 t.discriminator = None
         self.targets = dict()
+
+    def _first_pass_stream(self):
+        if self._first_stream is None:
+            self._first_stream = torch.cuda.Stream(device=self.device)
+        return self._first_stream
 
     def _init_streams(self, n):
         while len(self._init_pool) < n:
@@ -233,20 +242,21 @@ class Tracker(nn.Module):
         starts = list(range(1, len(frames), fb))
         pending = {}                                        # batch start -> (taps, ready event, set index)
 
-        def launch(bi):
-            if bi >= len(starts):
+        def launch(bi, on=None):
+            if bi >= len(starts) or starts[bi] in pending:
                 return
             i0 = starts[bi]
             idx = list(range(i0, min(i0 + fb, len(frames))))
             batch = torch.stack([frames[j][0].to(self.device) for j in idx])
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())       # the input batch (and the previous use of this tap set)
-                with torch.cuda.stream(side):
-                    ext.output_set = bi & 1
+            st = on if on is not None else side
+            if st is not None:
+                st.wait_stream(torch.cuda.current_stream())         # the input batch (and the previous use of this tap set)
+                with torch.cuda.stream(st):
+                    ext.output_set = (bi & 1) if side is not None else 0
                     taps = ext(batch)
                     ev = torch.cuda.Event()
-                    ev.record(side)
-                batch.record_stream(side)
+                    ev.record(st)
+                batch.record_stream(st)
             else:
                 if persistent:
                     ext.output_set = 0              # single tap set: the refiner's graphs stay keyed to 4 slice addresses
@@ -258,6 +268,12 @@ class Tracker(nn.Module):
         # Side stream: one pass AHEAD, into the other tap set.
         if side is not None:
             launch(0)
+        elif persistent and self.overlap_first_pass and torch.cuda.is_available():
+            # The first pass does not depend on initialize().  initialize() calls this hook right after it has enqueued its own
+            # trunk call: the pass then runs on a side stream next to the target-model fits (chains of small kernels that
+            # leave most of the GPU idle) instead of after them.  One pass only: later passes overwrite the tap set in use.
+            first = self._first_pass_stream()
+            self._after_init_trunk = lambda: launch(0, on=first)
         cache, bi = {}, 0
         for i, (image, labels, new_objects) in enumerate(frames):
             feats = None
@@ -274,6 +290,7 @@ class Tracker(nn.Module):
                         launch(bi)                          # next batch runs on the side stream while this one is being tracked
                 feats = cache.pop(i)
             yield image, labels, new_objects, feats
+            self._after_init_trunk = None                   # only armed while frame 0 is being initialised
 
     # ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -297,6 +314,9 @@ class Tracker(nn.Module):
             # object, :186); same per-image results, larger launches and one lane per object
             layers = sorted({t.disc_layer for t, _, _ in fresh})
             ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers)
+            if self._after_init_trunk is not None:
+                hook, self._after_init_trunk = self._after_init_trunk, None
+                hook()
             # the objects' fits are independent chains of small kernels: enqueue them round-robin on side streams so that
             # they overlap on the GPU (reference :186-187 runs them one after the other)
             cur = torch.cuda.current_stream()
