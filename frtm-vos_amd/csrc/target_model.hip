@@ -266,7 +266,6 @@ __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __r
 #pragma unroll
   for (int o = 0; o < R; ++o) acc[o] = 0.f;
   const float* Xn = X + (size_t)n * C * h * w;
-#pragma unroll 2                                           // two channels' row loads in flight
   for (int c = c0; c < c1; ++c) {
     const float* Xc = Xn + (size_t)c * h * w;
     const float* fc = f + c * 9;
