@@ -233,6 +233,7 @@ def test_feature_batching_and_graphs_do_not_change_results():
         outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
     for o in outs[1:]:
         agree = float((outs[0] == o).float().mean())
+        print('batched / graphed vs frame-by-frame eager: label agreement %.5f' % agree)
         assert agree > 0.995, agree        # identical up to fp32 summation order inside the convs (split-K vs none)
 
 
@@ -276,11 +277,15 @@ def test_run_sequence_matches_the_literal_per_frame_loop():
 
     seq = SyntheticSequence('lit', 21, (128, 160), 2, seed=9)
     seq.preload(DEV)
-    fast, _ = make().run_sequence(seq)
+    trk_fast = make()
+    soft_fast = []
+    tw = trk_fast.track_window
+    trk_fast.track_window = lambda images, taps: (lambda m: (soft_fast.extend(m.clone().unbind(0)), m)[1])(tw(images, taps))
+    fast, _ = trk_fast.run_sequence(seq)
     fast = torch.stack([l.reshape(128, 160) for l in fast]).cpu()
     trk = make()
     ids = torch.tensor([0] + list(seq.obj_ids), dtype=torch.uint8, device=DEV)
-    slow = []
+    slow, soft_slow = [], []
     for i, (image, labels, new_objects) in enumerate(seq):
         image = image.to(DEV)
         had = len(trk.targets) > 0
@@ -289,12 +294,20 @@ def test_run_sequence_matches_the_literal_per_frame_loop():
             trk.initialize(image, labels, new_objects)
         if had:
             masks = trk.track(image)                              # trunk called for this frame only
+            soft_slow.append(masks.clone())
             labels = ids[O_.merge_masks_(masks.clone()).argmax(dim=0, keepdim=True)]
         slow.append(labels.reshape(128, 160).cpu())
         trk.current_frame += 1
     slow = torch.stack(slow)
     agree = float((fast == slow).float().mean())
+    print('run_sequence vs literal loop: label agreement %.5f' % agree)
     assert agree > 0.995, agree
+    # the soft masks themselves (random-weight networks give mostly-background labels: compare what the labels come from)
+    assert len(soft_fast) == len(soft_slow) == 20
+    d = max(float((a - b).abs().mean()) for a, b in zip(soft_fast, soft_slow))
+    spread = float(torch.stack(soft_slow)[:, 1:].std())
+    print('soft masks: max mean |diff| %.2e, spread of the object planes %.3f' % (d, spread))
+    assert d < 2e-3 and spread > 1e-3, (d, spread)
 
 
 def test_window_tracking_with_a_late_object_matches_frame_by_frame():
@@ -316,6 +329,7 @@ def test_window_tracking_with_a_late_object_matches_frame_by_frame():
         outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
     assert int(outs[1][11:].eq(3).sum()) > 0          # the late object (id 3) is present from its first frame on
     agree = float((outs[0] == outs[1]).float().mean())
+    print('windowed vs frame-by-frame with a late object: label agreement %.5f' % agree)
     assert agree > 0.995, agree
 
 
