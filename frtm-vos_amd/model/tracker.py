@@ -12,6 +12,9 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
    (47 TFLOP/s, many split-K convs), at batch 4 they do (80 TFLOP/s, no split-K), and two sub-batches on two streams cover
    each other's kernel tails (the last, partly filled round of workgroups of every launch): 95 TFLOP/s.  Per-frame results
    are unchanged up to fp32 summation order; ``track(image)`` without pre-computed features still works frame by frame;
+ * between two filter re-solves (8 frames) nothing but the memory inserts carries state from frame to frame, so ``run_sequence``
+   scores and refines those frames as ONE window of frames x objects samples (``track_window``); merge, pixel counts, memory
+   inserts and the re-solve follow frame by frame in order;
  * the "fewer than 10 pixels" early-out of Discriminator.update (discriminator.py:214) is evaluated for all objects by
    one kernel; on frames without a filter re-solve it guards the memory insert on the device (no host sync at all), on
    re-solve frames (every 8th) ONE small device->host copy serves all objects.
@@ -222,12 +225,13 @@ class Tracker(nn.Module):
         return (length + 1) * len(active) * per_sample > 0x7fffffff or length >= 64
 
     def frames_with_features(self, sequence):
-        """Yields (image, labels, new_objects, taps).  The trunk runs on up to ``feature_batch`` consecutive frames at once
-        and one batch AHEAD of the frames being tracked.  With ``prefetch_stream`` it runs on a side stream, so that its
-        kernels overlap the refiner / target-model kernels of the current frames (off by default: the gain is small and
-        concurrent kernels make per-kernel timings hard to read).  Tap tensors are persistent and double buffered; an event
-        orders each batch before its first consumer.  Frame 0 of a sequence is never tracked (only initialised),
-        so its taps are not computed."""
+        """Yields (image, labels, new_objects, taps).  The trunk runs on up to ``feature_batch`` consecutive frames at once.
+        Single stream (default): a pass is enqueued when its first frame is asked for; the taps live in ONE persistent set of
+        buffers, which the next pass overwrites -- run_sequence therefore tracks every frame of a batch before it asks for the
+        first frame of the next one (tracking windows end with their trunk batch).  With ``prefetch_stream`` the pass of the NEXT
+        batch runs on a side stream, into a second tap set, while the current batch is tracked (off by default: no gain, the
+        trunk kernels saturate the GPU either way).  Frame 0 of a sequence is never tracked (only initialised), so its taps
+        are not computed."""
         frames = list(sequence)
         fb = max(1, int(self.feature_batch))
         ext = self.feature_extractor
