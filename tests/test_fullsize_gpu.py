@@ -310,6 +310,32 @@ def test_run_sequence_matches_the_literal_per_frame_loop():
     assert d < 2e-3 and spread > 1e-3, (d, spread)
 
 
+def test_winograd_on_off_end_to_end():
+    """The Winograd 3x3 path changes rounding only: same labels, soft masks within the noise of the solver, at a frame size and
+    window length where both the trunk and the refiner really take it (>= 512 output blocks per launch)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    res = []
+    for wino in (False, True):
+        torch.manual_seed(0)
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
+        params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+        trk = params.get_model().eval()
+        trk.feature_extractor.winograd = wino
+        trk.refiner.use_winograd = wino
+        soft = []
+        tw = trk.track_window
+        trk.track_window = lambda images, taps, tw=tw, soft=soft: (lambda m: (soft.extend(m.clone().unbind(0)), m)[1])(tw(images, taps))
+        seq = SyntheticSequence('w', 17, (256, 448), 2, seed=6)
+        seq.preload(DEV)
+        labels, _ = trk.run_sequence(seq)
+        res.append((torch.stack([l.reshape(256, 448) for l in labels]).cpu(), torch.stack(soft).cpu()))
+    agree = float((res[0][0] == res[1][0]).float().mean())
+    d = float((res[0][1] - res[1][1]).abs().mean())
+    print('winograd on/off: label agreement %.5f, mean |soft mask diff| %.2e' % (agree, d))
+    assert agree > 0.995 and d < 2e-3, (agree, d)
+
+
 def test_window_tracking_with_a_late_object_matches_frame_by_frame():
     """An object that appears mid-sequence cuts the tracking windows (its first frame is tracked on its own, its re-solve
     phase differs from the others'): windowed run_sequence == frame-by-frame run_sequence."""
