@@ -283,9 +283,11 @@ def main():
         'ms_per_step': 1e3 * T / n, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
-                               '%s iterations, memory 80, c=96, random-init weights, trunk fed %d frames per pass in %d concurrent lanes' %
+                               '%s iterations, memory 80, c=96, random-init weights, trunk fed %d frames per pass in %d concurrent lanes, '
+                               'frames between two filter re-solves tracked as one window%s, 3x3 stride-1 convs %s (fp32)' %
                                (args.backbone, size[0], size[1], args.objects, args.steps,
-                                'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.trunk_batch, args.trunk_lanes),
+                                'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.trunk_batch, args.trunk_lanes,
+                                ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else 'Winograd F(2x2,3x3)'),
                    'warmup_frames_run': warm_frames,
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',

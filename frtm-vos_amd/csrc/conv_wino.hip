@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
     for (int q = 0; q < 4; ++q) dst[q] = buf_ld4(rw, (unsigned)kc * a_chunk + a_lane + (unsigned)(q * 64 * 16));
   };
   auto gloadR = [&](int kc, float* dst) {
+    // OOB + cstep stays beyond the buffer (cstep < in_bytes < 2^31), so padding elements need no select
     const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);
+    const bool tail = (kc + 1) * WCI > p.Cin;                         // only the last chunk of a Cin that is not a multiple of 8
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      unsigned o = r_goff[i] == OOB ? OOB : r_goff[i] + cstep;
-      if (kc * WCI + r_ci[i] >= p.Cin) o = OOB;                       // channel tail of a Cin that is not a multiple of 8
+      unsigned o = r_goff[i] + cstep;
+      if (tail && kc * WCI + r_ci[i] >= p.Cin) o = OOB;
       dst[i] = buf_ld1(rin, o);
     }
   };
