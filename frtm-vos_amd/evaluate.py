@@ -102,6 +102,7 @@ def main(argv=None):
     ap.add_argument('--yt2018', default=os.environ.get('YTVOS_ROOT', '/path/to/ytvos2018'))
     ap.add_argument('--jjval-list', default=None, help="id list of the reference's jjval split (lib/ytvos_jjvalid.txt upstream)")
     ap.add_argument('--output', default='results')
+    ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -120,6 +121,8 @@ def main(argv=None):
         dset = YouTubeVOSDataset(args.yt2018, '2018', 'valid_all_frames')
     out_path = Path(args.output).expanduser().resolve() / (dset.name + '-' + Path(args.model).stem + ('_fast' if args.fast else ''))
     tracker = Parameters(weights, fast=args.fast, device=args.dev).get_model()
+    if args.prewarm:
+        tracker.prewarm(tuple(int(v) for v in args.prewarm.lower().split('x')))
 
     class _Shard:
         name = dset.name

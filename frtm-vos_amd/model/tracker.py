@@ -145,6 +145,20 @@ class Tracker(nn.Module):
         print('Average frame rate: %.2f fps' % dset_fps.avg)
         return dset_fps.avg
 
+    def prewarm(self, size, object_counts=(1, 2, 3), seed=0):
+        """Optional: pay the one-off costs (kernel code objects, trunk arenas, the hipGraphs of every trunk batch / tracking
+        window shape) for frames of ``size`` and the given numbers of objects BEFORE any timed sequence, on synthetic frames.
+        A sequence then only replays.  Sequence lengths are chosen so that every window length 1..8 and a full trunk batch occur."""
+        from ..lib.synthetic import SyntheticSequence
+        fb = max(1, int(self.feature_batch))
+        for n in object_counts:
+            for residual in range(1, 9):
+                seq = SyntheticSequence('prewarm', 1 + fb + residual, tuple(size), n, seed=seed + n)
+                seq.preload(self.device)
+                self.run_sequence(seq)
+        self.release_targets()
+        torch.cuda.synchronize()
+
     def run_sequence(self, sequence, speedrun=False):
         """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included."""
         self.eval()

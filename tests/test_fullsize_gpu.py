@@ -336,6 +336,24 @@ def test_winograd_on_off_end_to_end():
     assert agree > 0.995 and d < 2e-3, (agree, d)
 
 
+def test_prewarm_leaves_nothing_to_capture():
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
+    params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+    trk = params.get_model().eval()
+    trk.prewarm((96, 128), object_counts=(2,))
+    graphs = len(trk.refiner._graphs)
+    trunk_graphs = sum(1 for e in trk.feature_extractor._out_cache.values() if e.get('graph') is not None)
+    for L in (14, 23):
+        seq = SyntheticSequence('p', L, (96, 128), 2, seed=L)
+        seq.preload(DEV)
+        labels, _ = trk.run_sequence(seq)
+        assert len(labels) == L
+    assert len(trk.refiner._graphs) == graphs
+    assert sum(1 for e in trk.feature_extractor._out_cache.values() if e.get('graph') is not None) == trunk_graphs
+
+
 def test_window_tracking_with_a_late_object_matches_frame_by_frame():
     """An object that appears mid-sequence cuts the tracking windows (its first frame is tracked on its own, its re-solve
     phase differs from the others'): windowed run_sequence == frame-by-frame run_sequence."""
