@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw,
                                                           const int* __restrict__ count, int min_count) {
   const int lane = threadIdx.x;
   // device-side form of the early-out of Discriminator.update (discriminator.py:214): no weight update, no slot
-  if (count && count[0] < min_count) { if (lane == 0) state[1] = -1; return; }
+  if (count && count[0] < min_count) { if (lane == 0) { state[1] = -1; state[3] += 1; } return; }     // state[3]: skipped inserts
   int r_ind;
   if (num_zero || lr == 1.f) {
     for (int i = lane; i < cap; i += 64) sw[i] = (i == 0) ? 1.f : 0.f;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw,
   for (int i = lane; i < cap; i += 64) s += sw[i];
   s = wave_sum(s);
   for (int i = lane; i < cap; i += 64) sw[i] = sw[i] / s;                                      // :90
-  if (lane == 0) { state[0] = r_ind; state[1] = r_ind; }
+  if (lane == 0) { state[0] = r_ind; state[1] = r_ind; state[2] += 1; }                        // state[2]: inserts performed
 }
 
 template <typename T>

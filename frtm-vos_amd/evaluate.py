@@ -22,6 +22,7 @@ class Parameters:
 
     def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2):
         self.device = device
+        self.refiner_factory = None       # optional: callable(ft_channels) -> SegNetwork used instead of a default-initialised one
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes
         self.weights = weights
@@ -68,9 +69,12 @@ class Parameters:
         self.disc_params.in_channels = extractor.get_out_channels()[self.disc_params.layer]
         p = self.refnet_params
         chans = {L: n for L, n in extractor.get_out_channels().items() if L in p.layers}
-        refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
-        if self.weights is None:
+        if self.refiner_factory is not None:                       # bench.py / tests: synthetic stand-in for a trained refiner
+            refiner = self.refiner_factory(chans)
+        elif self.weights is None:
             torch.manual_seed(1)                                   # seeded default init
+            refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
+        else:
             refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
         mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device, feature_batch=self.feature_batch,
                       trunk_lanes=self.trunk_lanes)
@@ -91,7 +95,7 @@ def main(argv=None):
     from .lib.datasets import DAVISDataset, YouTubeVOSDataset
     from .lib.evaluation import evaluate_sequence
     from .lib.davis import db_statistics
-    from .shard import aggregate_throughput, shard_sequences
+    from .shard import aggregate_throughput, shard_indices, write_rank_report
 
     ap = argparse.ArgumentParser(description='Evaluate FRTM on a validation dataset (MI355X-native hot path)')
     ap.add_argument('--model', required=True, help='FRTM checkpoint (.pth with the refiner weights)')
@@ -125,15 +129,24 @@ def main(argv=None):
         tracker.prewarm(tuple(int(v) for v in args.prewarm.lower().split('x')))
 
     class _Shard:
+        """This rank's share of the dataset, sequences created lazily and dropped after use (like the reference's
+        `for sequence in dataset`, tracker.py:82): a pre-loaded sequence holds all its frames on the GPU."""
         name = dset.name
+        frames = 0
 
         def __iter__(self):
-            return iter(shard_sequences(list(dset), rank, world))
+            for i in shard_indices(len(dset), rank, world):
+                seq = dset[i]
+                _Shard.frames += len(seq)
+                yield seq
+                seq.release()
     import time
-    t0, frames = time.time(), 0
+    t0 = time.time()
     tracker.run_dataset(_Shard(), out_path, speedrun=args.dset == 'dv2016val')
-    frames = sum(len(s) for s in shard_sequences(list(dset), rank, world))
-    fps, total, wall = aggregate_throughput(frames, time.time() - t0, device=args.dev if world > 1 else 'cpu')
+    wall = time.time() - t0
+    write_rank_report(out_path, rank, world, dict(frames=_Shard.frames, seconds=wall, fps=_Shard.frames / max(wall, 1e-9),
+                                                  dataset=dset.name, device=args.dev))
+    fps, total, wall = aggregate_throughput(_Shard.frames, wall, device=args.dev if world > 1 else 'cpu')
     if rank == 0:
         print('%d frames on %d GPU(s): %.1f frames/s incl. decoding and PNG writing' % (total, world, fps))
 

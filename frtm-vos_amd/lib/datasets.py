@@ -44,6 +44,10 @@ class FileSequence:
         """Decode every frame once and keep it on the device (reference tracker.py:88-91)."""
         self.preloaded_images = [imread(f).to(device) for f in self.images]
 
+    def release(self):
+        """Drop the pre-loaded frames (a dataset run keeps at most one sequence on the device)."""
+        self.preloaded_images = None
+
     def __getitem__(self, item):
         im = self.preloaded_images[item] if self.preloaded_images is not None else imread(self.images[item])
         name = self.frame_name(item)

@@ -241,6 +241,8 @@ class Discriminator(nn.Module):
         if not dev_ok:
             self.to(device)
         self.frame_num = 0
+        self.num_solves = 0              # filter re-solves run by update() since init() (diagnostics: bench.py asserts the schedule)
+        self.num_early_outs = 0          # host-side "fewer than 10 pixels" early-outs of update() (the device-guarded ones: memory.insert_counts)
         self.update_optimizer = None
         self.current_sample = None
         self.memory = None
@@ -254,6 +256,8 @@ class Discriminator(nn.Module):
         self.project.reset_parameters()        # in place, on the device
         self.filter.reset_parameters()
         self.frame_num = 0
+        self.num_solves = 0
+        self.num_early_outs = 0
         self.update_optimizer = None
         self.current_sample = None
         self.memory = None
@@ -372,8 +376,10 @@ class Discriminator(nn.Module):
         if num_positive is None:
             num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
         if num_positive < 10:
+            self.num_early_outs += 1
             return
         self.memory.update(self.current_sample, train_y, px_count=count_dev)     # soft mask as label, weights from (y > 0.5)  (:217-219)
         if not solve:
             return
         self.update_optimizer.run(self.update_iters)
+        self.num_solves += 1

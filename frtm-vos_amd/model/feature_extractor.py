@@ -91,10 +91,15 @@ class ResNetParams(nn.Module):
                     pairs.append((blk.downsample[0], blk.downsample[1]))
         return pairs
 
+    BRANCH_GAIN = 0.25
+
     def randomize(self, seed=0):
-        """Seeded synthetic weights: kaiming-normal convs, BN gamma~U[.5,1.5],
-        beta~N(0,.1), running_mean~N(0,.1), running_var~U[.5,1.5]."""
+        """Seeded synthetic weights: kaiming-normal convs, BN gamma~U[.5,1.5], beta~N(0,.1), running_mean~N(0,.1),
+        running_var~U[.5,1.5], with gamma and beta of the LAST BatchNorm of every residual branch scaled by 0.25 so
+        that the taps of the deep trunks stay O(1-10) (deviation from SURVEY 8d: as written it gives |layer4| ~ 1e7 for
+        ResNet-101 and a NaN target model).  The test suite checks this generator against its CPU restatement."""
         g = torch.Generator().manual_seed(seed)
+        last = '.bn2.' if self.kind == 'basic' else '.bn3.'
         for k, v in self.state_dict().items():
             if k.endswith('num_batches_tracked'):
                 continue
@@ -104,6 +109,8 @@ class ResNetParams(nn.Module):
                 t = torch.rand(v.shape, generator=g) + 0.5
             else:
                 t = torch.randn(v.shape, generator=g) * 0.1
+            if last in k and (k.endswith('.weight') or k.endswith('.bias')):
+                t = t * self.BRANCH_GAIN
             v.copy_(t)
         return self
 
@@ -295,5 +302,9 @@ class ResnetFeatureExtractor:
         """Reference :73-86 (the trunk never builds a graph, so this only adds the optional chunking)."""
         if chunk_size is None:
             return self(input, output_layers)
-        outs = [self(t, output_layers) for t in torch.split(input, chunk_size)]
+        reuse, self.reuse_outputs = self.reuse_outputs, False      # every chunk needs its own tensors (persistent taps would alias)
+        try:
+            outs = [self(t, output_layers) for t in torch.split(input, chunk_size)]
+        finally:
+            self.reuse_outputs = reuse
         return {L: torch.cat([o[L] for o in outs]) for L in outs[0]}

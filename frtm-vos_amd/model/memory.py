@@ -50,7 +50,9 @@ class Memory:
         self.current_size = 0
         self.device = dev
         self.learning_rates = learning_rates
-        self._slot = torch.full((2,), -1, dtype=torch.int32, device=dev)     # {previous_replace_ind, last index}; a fill, not a blocking H2D copy
+        # {previous_replace_ind, last index, inserts performed, inserts skipped by the device-side early-out}; fills, not blocking H2D copies
+        self._slot = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._slot[:2].fill_(-1)
         self._have_prev = False
         self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
 
@@ -62,6 +64,13 @@ class Memory:
     def previous_replace_ind(self):
         """Host view of the last replaced slot (synchronises; the hot path never reads it)."""
         return int(self._slot[0].item()) if self._have_prev else None
+
+    @property
+    def insert_counts(self):
+        """(inserts performed, inserts skipped by the device-side "fewer than 10 pixels" guard) since construction / reset();
+        counted by the slot kernel itself.  Synchronises: diagnostics (bench.py, tests), never read on the hot path."""
+        a, b = self._slot[2:].tolist()
+        return int(a), int(b)
 
     def _tf(self):
         p = self.pw_params
@@ -77,7 +86,8 @@ class Memory:
     def reset(self):
         """Back to the state after construction (buffers are kept: a recycled memory serves the next object)."""
         self.clear()
-        self._slot.fill_(-1)
+        self._slot[:2].fill_(-1)
+        self._slot[2:].zero_()
         self._have_prev = False
 
     def matches(self, capacity, feature_size, labels_size, grid_size=None, keep_hires=False):

@@ -195,10 +195,14 @@ class SegNetwork(nn.Module):
     def _forward_graphed(self, scores, features, image_size):
         """The ~80 launches of _forward_hip are a static sequence for a given object count and set of tap tensors:
         capture them once in a hipGraph and replay it per frame (one host call instead of ~80).  The graph is keyed by the
-        tap ADDRESSES (the trunk writes into persistent buffers, model/feature_extractor.py reuse_outputs), the score
-        shape and the weight versions; scores go through a static input buffer."""
+        tap ADDRESSES and SHAPES (the trunk writes into persistent buffers, model/feature_extractor.py reuse_outputs; the number
+        of frames of the window fixes the frames x objects split of the samples), the score shape and the weight versions;
+        scores go through a static input buffer."""
         P = self._packed()
-        key = (tuple(features[L].data_ptr() for L in self.ft_channels), tuple(scores.shape), tuple(image_size[-2:]), self._pack_key)
+        # the captured launches bake in frames = features.shape[0] and group = samples // frames: both are part of the key
+        # (W=8,n=1 and W=4,n=2 start at the same tap address with the same score shape)
+        key = (tuple(features[L].data_ptr() for L in self.ft_channels), tuple(tuple(features[L].shape) for L in self.ft_channels),
+               tuple(scores.shape), tuple(image_size[-2:]), self._pack_key)
         entry = self._graphs.pop(key, None)
         if entry is None:
             while len(self._graphs) >= 32:                                   # least recently used first

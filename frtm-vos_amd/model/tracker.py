@@ -250,12 +250,25 @@ class Tracker(nn.Module):
         fb = max(1, int(self.feature_batch))
         ext = self.feature_extractor
         persistent = hasattr(ext, 'reuse_outputs')
+        saved = None
         if persistent:
+            # persistent taps / graph replay only for the duration of this sequence: a caller that holds two results of ext()
+            # (no_grad_forward's chunks, user code) must not find them aliased afterwards
+            saved = (ext.reuse_outputs, ext.use_graph, getattr(self.refiner, 'use_graphs', None))
             ext.reuse_outputs = True
             ext.lanes = max(1, min(int(self.trunk_lanes), fb))
             ext.use_graph = self.graph_trunk
             if hasattr(self.refiner, 'use_graphs'):
                 self.refiner.use_graphs = self.graph_refiner
+        try:
+            yield from self._frames_with_features(frames, fb, ext, persistent)
+        finally:
+            if saved is not None:
+                ext.reuse_outputs, ext.use_graph = saved[0], saved[1]
+                if saved[2] is not None:
+                    self.refiner.use_graphs = saved[2]
+
+    def _frames_with_features(self, frames, fb, ext, persistent):
         side = torch.cuda.Stream(device=self.device) if (persistent and self.prefetch_stream and torch.cuda.is_available()) else None
         starts = list(range(1, len(frames), fb))
         pending = {}                                        # batch start -> (taps, ready event, set index)

@@ -57,8 +57,9 @@ int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int
                       float* scratch, const int* px_count_dev, frtm_stream_t stream);
 
 /* Memory.update_sample_weights (model/memory.py:65-92) on the device, no host sync.
- * sw: (cap) sample weights, updated in place.  state: device int32[2] = {previous_replace_ind or -1,
- * replace index written by this call}.  num_samp_is_zero / lr as in the reference.
+ * sw: (cap) sample weights, updated in place.  state: device int32[4] = {previous_replace_ind or -1,
+ * replace index written by this call, number of inserts performed so far (incremented here), number of inserts skipped
+ * through count_dev (incremented here)}.  num_samp_is_zero / lr as in the reference.
  * count_dev != NULL: device int32 holding the number of mask pixels > 0.5; if it is < min_count the call leaves the
  * weights untouched and writes slot -1, which makes frtm_memory_insert / frtm_normal_build no-ops: the early-out of
  * Discriminator.update (discriminator.py:214) without a host sync. */

@@ -522,10 +522,18 @@ def resnet_param_shapes(name):
     return sh
 
 
+BRANCH_GAIN = 0.25      # scale of the last BatchNorm (gamma, beta) of every residual branch, see resnet_random_params
+
+
 def resnet_random_params(name, seed=0):
-    """Seeded synthetic weights: kaiming-normal convs, BN gamma~U[.5,1.5],
-    beta~N(0,.1), running_mean~N(0,.1), running_var~U[.5,1.5]."""
+    """Seeded synthetic weights: kaiming-normal convs, BN gamma~U[.5,1.5], beta~N(0,.1), running_mean~N(0,.1),
+    running_var~U[.5,1.5] -- EXCEPT the last BatchNorm of every residual branch (bn2 of a BasicBlock, bn3 of a
+    Bottleneck), whose gamma and beta are scaled by BRANCH_GAIN = 0.25.  Deviation from SURVEY 8d, on purpose: the running
+    statistics are random, not the activations' own, so with gamma ~ 1 every block multiplies the variance and the 33 blocks of
+    ResNet-101 end at |layer4| ~ 1e7 (NaN target model, round-1 VERDICT weak #1).  With 0.25 the taps stay O(1-10) for all four
+    trunks (measured: RN101 layer4 max 6.4 / mean 0.93, RN18 1.8 / 0.13 on a 240x432 synthetic frame)."""
     g = torch.Generator().manual_seed(seed)
+    last = '.bn2.' if RESNET_SPECS[name][0] == 'basic' else '.bn3.'
     P = OrderedDict()
     for k, s in resnet_param_shapes(name).items():
         if len(s) == 4:
@@ -537,6 +545,8 @@ def resnet_random_params(name, seed=0):
             P[k] = torch.randn(s, generator=g) * 0.1
         else:
             P[k] = torch.rand(s, generator=g) + 0.5
+        if last in k and (k.endswith('.weight') or k.endswith('.bias')):
+            P[k] = P[k] * BRANCH_GAIN
     return P
 
 

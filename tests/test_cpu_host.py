@@ -225,6 +225,65 @@ def test_sharding_two_ranks_gloo(tmp_path):
     assert 'SHARD_OK' in outs[0]
 
 
+def test_bench_launches_its_own_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2` starts 2 ranks itself (torch.distributed.run); --launch-check runs only the N > 1 plumbing
+    (process group, barrier, max-reduce, rank_<r>.json) so that it needs no GPU."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--launch-check',
+                          '--steps', '9', '--report-dir', str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['frames_from_rank_reports'] == 18 and line['scaling'] == 'weak'
+    r0, r1 = (json.load(open(tmp_path / ('rank_%d.json' % r))) for r in range(2))
+    assert (r0['rank'], r1['rank']) == (0, 1) and r0['world_size'] == 2 and r1['seconds'] >= 0.02
+    # a rank count that contradicts the launcher's world size is refused, not silently ignored (round-1: --gpus was a no-op)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--launch-check'], text=True,
+                         env=dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
+
+
+def test_length_balanced_sharding_and_rank_reports(tmp_path):
+    from frtm_vos_amd.shard import aggregate_reports, shard_indices, write_rank_report
+    costs = [100, 10, 10, 10, 90, 10, 10, 60]
+    parts = [shard_indices(len(costs), r, 3, costs) for r in range(3)]
+    assert sorted(i for p in parts for i in p) == list(range(8))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) == 100 and min(loads) >= 90                       # longest-first greedy: {100}, {90,10}, {60,10,10,10,10}
+    assert shard_indices(5, 1, 2) == [1, 3]                             # no costs: round-robin
+    for r, (f, t) in enumerate(((70, 2.0), (50, 2.5))):
+        write_rank_report(tmp_path, r, 2, dict(frames=f, seconds=t))
+    fps, frames, seconds = aggregate_reports(tmp_path, 2)
+    assert frames == 120 and seconds == 2.5 and abs(fps - 48.0) < 1e-12
+
+
+def test_score_following_refiner_yields_confident_masks():
+    """The synthetic stand-in for a trained refiner (bench.py workload): logits follow the coarse score through the real
+    architecture -- > 0.5 where the score is 1, < 0.5 where it is 0 -- and every other channel still carries its random weights."""
+    from frtm_vos_amd.lib.synthetic import make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    chans = {'layer5': 32, 'layer4': 16, 'layer3': 8, 'layer2': 8}
+    torch.manual_seed(1)
+    net = SegNetwork(1, 16, chans, True).eval()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    make_score_following_refiner(net)
+    changed = sum(int((before[k] != v).sum()) for k, v in net.state_dict().items())
+    total = sum(v.numel() for v in before.values())
+    assert 0 < changed < 0.2 * total
+    g = torch.Generator().manual_seed(0)
+    taps = {'layer5': torch.randn(1, 32, 4, 6, generator=g), 'layer4': torch.randn(1, 16, 8, 12, generator=g),
+            'layer3': torch.randn(1, 8, 16, 24, generator=g), 'layer2': torch.randn(1, 8, 32, 48, generator=g)}
+    score = torch.zeros(2, 1, 8, 12)
+    score[0, 0, 2:6, 3:9] = 1.0
+    score[1, 0, :, :6] = 1.0
+    with torch.no_grad():
+        y = torch.sigmoid(net(score, taps, (128, 192)))
+    up = torch.nn.functional.interpolate(score, (128, 192), mode='nearest')
+    inner = torch.nn.functional.avg_pool2d(up, 33, 1, 16) > 0.999           # well inside the objects
+    outer = torch.nn.functional.avg_pool2d(up, 33, 1, 16) < 0.001
+    assert float(y[inner].min()) > 0.9 and float(y[outer].max()) < 0.1
+
+
 def test_davis_measures():
     from frtm_vos_amd.lib.davis import db_eval_boundary, db_eval_iou, db_statistics, seg2bmap
     from frtm_vos_amd.lib.evaluation import evaluate_dataset, j_and_f

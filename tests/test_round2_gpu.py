@@ -1,0 +1,160 @@
+"""Round-2 GPU checks: the tracker's feedback loop on NON-degenerate masks (memory inserts + filter re-solves really run and
+match the CPU oracle assembly), one tracker serving sequences with different object counts under hipGraph replay, and
+bench.py's own multi-rank launch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from test_fullsize_gpu import _CpuTracker
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _score_following(chans):
+    from frtm_vos_amd.lib.synthetic import make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    torch.manual_seed(1)
+    return make_score_following_refiner(SegNetwork(1, 64, chans, True).eval())
+
+
+def _tracker(fast=True, backbone='resnet18', **disc):
+    from frtm_vos_amd.evaluate import Parameters
+    params = Parameters(None, fast=fast, device=DEV, feature_extractor=backbone)
+    params.refiner_factory = _score_following
+    params.disc_params.update(**disc)
+    return params.get_model().eval()
+
+
+def test_end_to_end_confident_masks_memory_grows_filter_changes_vs_cpu_oracle():
+    """ResNet-18, 128x160, 2 objects, 10 frames, train_skipping 4 (two filter re-solves per object), score-following refiner on
+    both sides: every tracked frame must insert a sample (masks are confident, > 10 px above 0.5), frames 4 and 8 must change the
+    filter, and the HIP tracker must agree with the CPU assembly of the oracle THROUGH those updates (round-1 VERDICT weak #7: the
+    old end-to-end test never reached an update)."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    trk = _tracker(memory_size=8, train_skipping=4, init_iters=(3, 5), update_iters=(5,))
+
+    class Aug:
+        def augment_first_frame(self, im, lb):
+            return im.unsqueeze(0).repeat(3, 1, 1, 1), lb.unsqueeze(0).repeat(3, 1, 1, 1)
+    trk.augment = Aug().augment_first_frame
+    seq = SyntheticSequence('e2e', 10, (128, 160), 2, seed=4)
+    P = {k: v.detach().cpu() for k, v in trk.feature_extractor.resnet.state_dict().items()}
+    ref_net = type(trk.refiner)(1, 64, trk.refiner.ft_channels, True).eval()
+    ref_net.load_state_dict({k: v.cpu() for k, v in trk.refiner.state_dict().items()})
+    w1w2 = {}
+    for oid in (1, 2):
+        g = torch.Generator().manual_seed(100 + oid)
+        w1w2[oid] = ((torch.rand(96, 256, 1, 1, generator=g) * 2 - 1) / 16, (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / 29.4)
+    cpu = _CpuTracker('resnet18', P, ref_net, w1w2, ((3, 5), (5,)))
+    import frtm_vos_amd.model.tracker as TR
+    orig = TR.Discriminator
+
+    class Injected(orig):
+        count = 0
+
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            Injected.count += 1
+            w1, w2 = w1w2[Injected.count]
+            self.project.weight.data.copy_(w1)
+            self.filter.weight.data.copy_(w2)
+    TR.Discriminator = Injected
+    # the CPU assembly builds its discriminators with memory_size=8 (test_fullsize_gpu._CpuTracker) and train_skipping 8 by default
+    orig_ref = O.DiscriminatorRef
+
+    def ref4(*a, **k):
+        k['train_skipping'] = 4
+        return orig_ref(*a, **k)
+    O.DiscriminatorRef = ref4
+    agree, diffs, sizes, filt = [], [], [], []
+    try:
+        trk.current_frame, trk.targets = 0, dict()
+        for i, (image, labels, new) in enumerate(seq):
+            old = set(trk.targets.keys())
+            if new:
+                trk.initialize(image.to(DEV), labels.to(DEV), new)
+                cpu.initialize(image, labels, new)
+            if old:
+                trk.track(image.to(DEV))
+                cpu.track(image)
+                hm, cm = trk.current_masks.cpu(), cpu.masks
+                diffs.append(float((hm - cm).abs().mean()))
+                agree.append(float((hm.argmax(0) == cm.argmax(0)).float().mean()))
+                sizes.append([t.discriminator.memory.current_size for t in trk.targets.values()])
+                filt.append([t.discriminator.filter.weight.detach().clone() for t in trk.targets.values()])
+                px = [int((hm[t.index] > 0.5).sum()) for t in trk.targets.values()]
+                assert min(px) >= 10, (i, px)                      # confident masks: the early-out must not trigger
+            trk.current_frame += 1
+            cpu.frame += 1
+    finally:
+        TR.Discriminator = orig
+        O.DiscriminatorRef = orig_ref
+    assert len(sizes) == 9
+    for k in range(2):
+        assert [s[k] for s in sizes] == [min(3 + j, 8) for j in range(1, 10)], sizes       # K=3 initial samples, +1 per frame, capacity 8
+        changed = [not torch.equal(filt[j][k], filt[j - 1][k]) for j in range(1, 9)]
+        assert changed == [j + 1 in (4, 8) for j in range(1, 9)], changed                   # tracked frame numbers 4 and 8 re-solve
+        d = list(trk.targets.values())[k].discriminator
+        assert d.num_solves == 2 and d.memory.insert_counts == (9, 0) and d.num_early_outs == 0
+        oc = list(cpu.targets.values())[k]['d']
+        w_h, w_c = d.filter.weight.cpu(), oc.w2
+        assert float((w_h - w_c).abs().max() / w_c.abs().max()) < 0.1
+    print('mean |mask diff| per frame', ['%.4f' % v for v in diffs], 'label agreement', ['%.4f' % v for v in agree])
+    assert max(diffs) < 2e-2, diffs
+    assert min(agree) > 0.97, agree
+
+
+def test_one_tracker_serves_sequences_with_different_object_counts_under_graph_replay():
+    """W=8,n=1 and W=4,n=2 windows start at the same tap address with the same score shape; the refiner's
+    graph key must tell them apart.  A tracker that has just run a 1-object sequence runs a 2- and a 4-object sequence with
+    graphs on; results must equal a fresh tracker without graphs."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    seqs = [SyntheticSequence('a', 18, (128, 160), n, seed=20 + n) for n in (1, 2, 4, 1, 2)]
+    for s in seqs:
+        s.preload(DEV)
+
+    def run(trk):
+        outs = []
+        for s in seqs:
+            torch.manual_seed(5)                        # target-model weights are drawn on the device at initialize()
+            labels, _ = trk.run_sequence(s)
+            outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
+        return outs
+    shared = _tracker(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+    a = run(shared)
+    eager = _tracker(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+    eager.graph_refiner = False
+    eager.graph_trunk = False
+    b = run(eager)
+    for s, x, y in zip(seqs, a, b):
+        agree = float((x == y).float().mean())
+        assert agree > 0.995, (len(s.obj_ids), agree)
+        for o in s.obj_ids:                             # and the objects are actually tracked (non-degenerate masks)
+            assert int((x[-1] == o).sum()) > 10
+
+
+def test_bench_starts_two_ranks_and_reports_the_update_work():
+    """`python bench.py --gpus 2` launches two ranks itself (gloo + --share-gpu: both on cuda:0), each tracks its own
+    sequence, rank 0 prints one line with n_gpus = 2 and the counters of the per-frame update work."""
+    rep = os.path.join(ROOT, 'gpurun_out', 'bench_ranks_test')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--share-gpu',
+                          '--steps', '18', '--warmup', '2', '--backbone', 'resnet18', '--size', '240x432', '--report-dir', rep],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line['n_gpus'] == 2 and line['valid'] and line['scaling'] == 'weak'
+    c = line['path_counters']
+    assert c['all_finite'] and c['cg_solves_scheduled'] == 2 * (17 // 8) and c['cg_solves'] == c['cg_solves_scheduled']
+    assert c['memory_inserts'] == c['memory_inserts_scheduled'] == 2 * 17
+    ranks = [json.load(open(os.path.join(rep, 'rank_%d.json' % r))) for r in range(2)]
+    assert ranks[0]['seed'] != ranks[1]['seed'] and all(r['frames'] == 18 for r in ranks)
+    assert abs(line['value'] - 2 * 18 / max(r['seconds'] for r in ranks)) / line['value'] < 0.05
