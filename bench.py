@@ -59,6 +59,7 @@ def parse(argv=None):
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convs on the direct (halo) kernels only')
     ap.add_argument('--first-pass-overlap', action='store_true', help='first trunk pass on a side stream next to the fits of initialize()')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
+    ap.add_argument('--init-graph', action='store_true', help='first-frame fits replayed as one hipGraph per target model (default: launch by launch; no gain measured)')
     ap.add_argument('--random-refiner', action='store_true',
                     help='default-initialised refiner (round-1 workload: no mask ever exceeds 0.5, updates early-out; counters are reported, not asserted)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -73,6 +74,7 @@ def parse(argv=None):
     ap.add_argument('--launch-check', action='store_true',
                     help='exercise only the multi-process machinery (self-launch, process group, barrier, max-reduce, rank reports) with a '
                          'stub workload; needs no GPU with --dist-backend gloo (CPU test of the N > 1 path)')
+    ap.add_argument('--debug-allocs', action='store_true', help='print the Python stacks of device allocations (hipMalloc) made inside the timed region')
     ap.add_argument('--report-dir', default=os.path.join(ROOT, 'gpurun_out', 'bench_ranks'), help='where every rank writes rank_<r>.json')
     return ap.parse_args(argv)
 
@@ -396,6 +398,9 @@ def main():
         tracker.refiner.use_winograd = False
         tracker.feature_extractor.winograd = False
     tracker.window_tracking = not args.no_windows
+    if args.init_graph:
+        from frtm_vos_amd.model.discriminator import Discriminator
+        Discriminator.graph_init = True
     tracker.eval()
     torch.set_grad_enabled(False)
 
@@ -418,7 +423,9 @@ def main():
     # Untimed warm-up: a throw-away sequence (other seed) of the SAME length and object count as the timed one, so that every
     # hipGraph the timed frames replay (trunk pass per batch size, refiner per window shape) exists and the caching allocator holds
     # every block size the timed sequence asks for; preceded by a W-frame sequence when W asks for more than that.
-    warm_lengths = ([args.warmup] if args.warmup > args.steps else []) + [args.steps]
+    # The same-length sequence runs TWICE: hipGraph capture empties the caching allocator (torch.cuda.graph does), so only a pass
+    # without captures leaves every block the timed sequence needs in the cache (device_mallocs_in_timed_region must be 0).
+    warm_lengths = ([args.warmup] if args.warmup > args.steps else []) + [args.steps, args.steps]
     seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank, late_object_at=args.late_object)
     seq.preload(dev)
     for i, wl in enumerate(warm_lengths):
@@ -435,9 +442,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dev_allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+    if args.debug_allocs:
+        torch.cuda.memory._record_memory_history(enabled='all', context='alloc', stacks='python')
     t0 = time.time()
     outputs = run_sequence(tracker, seq)
     torch.cuda.synchronize()
+    if args.debug_allocs:
+        snap = torch.cuda.memory._snapshot()
+        torch.cuda.memory._record_memory_history(enabled=None)
+        for tr in snap.get('device_traces', []):
+            for ev in tr:
+                if ev.get('action') == 'segment_alloc':
+                    frames = [f for f in ev.get('frames', []) if 'site-packages' not in f['filename']][:6]
+                    print('hipMalloc of %d bytes on stream %s:' % (ev['size'], ev.get('stream')), file=sys.stderr)
+                    for f in frames:
+                        print('    %s:%d %s' % (f['filename'], f['line'], f['name']), file=sys.stderr)
     if dist is not None:
         dist.barrier()
     T_rank = T = time.time() - t0

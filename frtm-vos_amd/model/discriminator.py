@@ -58,6 +58,10 @@ class DiscriminatorLoss(MinimizationProblem):
             self.Xt = torch.empty(cap, self.hw, C, device=dev)       # NHWC copy of the raw features
             self.w1T = torch.empty(C, self.c, device=dev)
             self.g1 = torch.empty(C * self.c, device=dev)
+            self.d1 = torch.empty(self.c, C, device=dev)
+            # split-K scratch of THIS problem's GEMMs: first-frame fits of different objects replay as hipGraphs on concurrent
+            # streams and must not meet in the per-stream scratch of ops.conv2d
+            self.ws = torch.empty(max(4 * cap * self.c * self.hw, 32 * C * self.c), device=dev)
             self._xt_for = None
 
     def rebind(self, filter_regs, precond, filter_weight, project_weight=None):
@@ -118,7 +122,7 @@ class DiscriminatorLoss(MinimizationProblem):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
         H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)
         ops.conv2d(self.Xt, self.D, self.c, out=self.g1, out_transposed=True, shape=(1, self.N * self.hw, 1, self.Cin),
-                   w_pitch=self.c)
+                   w_pitch=self.c, ws=self.ws)
         H.call('frtm_vec_reduce_slabs', H.ptr(self.g1), 1, 0, self.Cin * self.c, lam2, pvec, sign, out)
 
     def linearize(self, x, b):
@@ -131,7 +135,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return
         n1 = self.Cin * c
         ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
-        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c)
+        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
         self._stencil(True)
         self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
@@ -147,7 +151,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return
         n1 = self.Cin * c
         p1, p2 = p[:n1], p[n1:]
-        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c)
+        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         ops.filter_scores(self.P, self.w2.data, out=self.s, n=N)
         ops.filter_scores(self.Z, p2, out=self.s, n=N, accumulate=True)
         self._stencil(False)
@@ -161,8 +165,8 @@ class DiscriminatorLoss(MinimizationProblem):
             H.call('frtm_vec_axpy', H.ptr(self.w2.data), step, H.ptr(delta), c * 9)
             return
         n1 = self.Cin * c
-        d1 = ops.transpose2d(delta[:n1].view(self.Cin, c))
-        H.call('frtm_vec_axpy', H.ptr(self.w1.data), step, H.ptr(d1), n1)
+        ops.transpose2d(delta[:n1].view(self.Cin, c), out=self.d1)
+        H.call('frtm_vec_axpy', H.ptr(self.w1.data), step, H.ptr(self.d1), n1)
         H.call('frtm_vec_axpy', H.ptr(self.w2.data), step, H.ptr(delta[n1:]), c * 9)
 
     # ---- reference-style helpers (not on the hot path) ----------------------------------
@@ -310,30 +314,80 @@ class Discriminator(nn.Module):
         H.require_gpu(y, 'compute_pixel_weights')
         return ops.pixel_weights(y, self._tf())
 
+    # True: replay the first-frame fit as ONE hipGraph per instance.  Off by default -- measured on MI355X (round 2): the fit is bound
+    # by its chain of ~750 DEPENDENT small kernels (4.5-9 us each on the device, 134 us per CG iteration of kernel time), not by
+    # the host's launch rate: initialize() takes 23.4 ms for 2 objects either way, and ~800-node graphs per target model are a
+    # memory / driver burden for nothing.
+    graph_init = False
+
     def init(self, x, y):
-        """x: (K,Cin,h,w) features of the augmented first frame; y: (K,1,H,W) masks (reference :154-199)."""
+        """x: (K,Cin,h,w) features of the augmented first frame; y: (K,1,H,W) masks (reference :154-199).
+
+        The head -- copying the features into the joint problem's memory and building the low-resolution normal equations from
+        the label images -- reads the caller's tensors and runs eagerly.  Everything after it (5 GN / 45 CG iterations of the
+        joint fit, re-projection, memory fill, 10 CG iterations of the filter fit: ~750 small dependent launches) touches only
+        buffers this instance owns; with ``graph_init`` it is captured ONCE per instance as a hipGraph and replayed for every
+        later object this (recycled) instance serves."""
         H.require_gpu(x, 'Discriminator.init')
         x = x.detach().float().contiguous()
         K = x.shape[0]
         dev = x.device
-        # joint fit of (project, filter) on the K raw samples
+        c = self.project.out_channels
         mem0 = self._memory('mem0', K, x.shape[-3:], y.shape[-3:], dev)
         mem0.initialize(x, y)
-        problem = self._problem('mem0_problem', mem0, self.filter_reg, self.precond, True)
-        optimizer = GaussNewtonCG(problem, TensorList([self.project.weight, self.filter.weight]), fletcher_reeves=False,
-                                  standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
-        optimizer.run(self.init_iters)
+        memory = self._memory('memory', self.memory_size, (c,) + tuple(x.shape[-2:]), y.shape[-3:], dev)
+        if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing():
+            opt = self._init_body(mem0, memory, None if not self.keep_hires else y)
+            self.memory, self.update_optimizer = memory, opt
+            return
+        key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
+               tuple(self.filter_reg), tuple(self.precond), self.direction_forget_factor)
+        ent = self._ws.get('init_graph')
+        if ent is None or ent['key'] != key or ent['mem0'] is not mem0 or ent['memory'] is not memory:
+            self._init_problems(mem0, memory)                    # buffers of problems / solvers exist before the capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                opt = self._init_body(mem0, memory, None)
+            ent = self._ws['init_graph'] = dict(key=key, graph=g, mem0=mem0, memory=memory, opt=opt, w1T=self._w1T)
+        ent['graph'].replay()
+        # host-side state as the eager path leaves it
+        memory.current_size = K
+        opt = ent['opt']
+        opt._has_p = True
+        self._w1T, self._w1T_key = ent['w1T'], (self.project.weight.data_ptr(), self.project.weight._version)
+        self.memory, self.update_optimizer = memory, opt
+
+    def _init_problems(self, mem0, memory):
+        p0 = self._problem('mem0_problem', mem0, self.filter_reg, self.precond, True)
+        p1 = self._problem('memory_problem', memory, self.filter_reg[1:], self.precond[1:], False)
+        o0 = self._solver('mem0_solver', p0, TensorList([self.project.weight, self.filter.weight]))
+        o1 = self._solver('memory_solver', p1, TensorList([self.filter.weight]))
+        return p0, p1, o0, o1
+
+    def _solver(self, tag, problem, variable):
+        o = self._ws.get(tag)
+        if o is None or o.problem is not problem or o.direction_forget_factor != self.direction_forget_factor:
+            o = self._ws[tag] = GaussNewtonCG(problem, variable, fletcher_reeves=False, standard_alpha=True,
+                                              direction_forget_factor=self.direction_forget_factor)
+        o.x = variable
+        o._alloc()
+        return o
+
+    def _init_body(self, mem0, memory, y):
+        """Reference :165-199 after the memory of raw samples has been filled.  Device work on this instance's buffers only."""
+        K = mem0.current_size
+        p0, p1, o0, o1 = self._init_problems(mem0, memory)
+        # joint fit of (project, filter) on the K raw samples
+        o0.rewind().run(self.init_iters)
         self._invalidate()
-        xp = ops.conv2d(x, self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)   # re-project (:178)
+        xp = ops.conv2d(mem0.samples[:K], self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels, ws=p0.ws)   # re-project (:178)
         # memory + filter-only problem used for the rest of the sequence
-        memory = self._memory('memory', self.memory_size, xp.shape[-3:], y.shape[-3:], dev)
-        memory.initialize(xp, y)
-        problem = self._problem('memory_problem', memory, self.filter_reg[1:], self.precond[1:], False)
-        optimizer = GaussNewtonCG(problem, TensorList([self.filter.weight]), fletcher_reeves=False,
-                                  standard_alpha=True, direction_forget_factor=self.direction_forget_factor)
-        optimizer.run(self.update_iters)
-        self.memory = memory
-        self.update_optimizer = optimizer
+        if y is None:
+            memory.initialize_like(xp, mem0)
+        else:
+            memory.initialize(xp, y)
+        o1.rewind().run(self.update_iters)
+        return o1
 
     def apply(self, ft):
         """Per-frame scoring (reference :201-206)."""

@@ -121,6 +121,18 @@ class Memory:
             self.pixel_weights[:K] = (pw if pw is not None else self._hires_pw(lab)).view(K, *self.labels_size)
         self.current_size = K
 
+    def initialize_like(self, init_features, other):
+        """initialize() with the labels / pixel weights of ``other`` (a memory initialised from the same label images on the same
+        grid): their low-resolution normal equations are copied instead of being rebuilt from the full-resolution labels.  Only
+        static device buffers are touched, so the call can be part of a captured hipGraph (Discriminator.init)."""
+        K = init_features.shape[0]
+        assert K == other.current_size and K <= self._capacity and self.grid == other.grid and not self.keep_hires
+        self.samples[:K] = init_features.detach()
+        self.weights[:K] = other.weights[:K]          # (2, 1, ..., 1) / (K + 1): memory.py:38-46, same for both memories
+        self.normal_B[:K] = other.normal_B[:K]
+        self.normal_c[:K] = other.normal_c[:K]
+        self.current_size = K
+
     def _hires_pw(self, lab):
         n = lab.shape[0]
         out = torch.empty(lab.shape, device=self.device, dtype=torch.float32)

@@ -57,6 +57,7 @@ class GaussNewtonCG:
         self.x = variable
         self.cg_eps = cg_eps
         self.step_alpha = step_alpha
+        self._step_alpha0 = step_alpha
         self.residuals = torch.zeros(0)
         self.external_losses = []
         self.internal_losses = []
@@ -97,6 +98,17 @@ class GaussNewtonCG:
 
     def clear_temp(self):
         pass
+
+    def rewind(self):
+        """Back to the state of a newly constructed solver, keeping the device buffers (a recycled target model re-runs its
+        first-frame fit through the same buffers, possibly as a replayed hipGraph: only device-side fills, no allocation)."""
+        self._alloc()
+        self._buf.zero_()
+        self._state.zero_()
+        self._state[:1].fill_(1.0)
+        self._has_p = False
+        self.step_alpha = self._step_alpha0
+        return self
 
     def reset_state(self):
         self._has_p = False

@@ -43,7 +43,7 @@ def pack_weights(w_oihw, halo=None, wino=False):
 
 
 def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=None, residual=None, relu=False,
-           out=None, out_transposed=False, splitk=0, tile=0, shape=None, w_pitch=0, w_layout=0):
+           out=None, out_transposed=False, splitk=0, tile=0, shape=None, w_pitch=0, w_layout=0, ws=None):
     """fp32 MFMA implicit-GEMM convolution.  x: (B,Cin,H,W) dense (or any dense buffer when ``shape``
     = (B,Cin,H,W) is given explicitly); wT: packed weights from pack_weights(), or a plain [K, w_pitch]
     matrix when w_pitch > 0.  Returns (B,Cout,Ho,Wo) (or (B,Ho*Wo,Cout)
@@ -55,7 +55,9 @@ def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=N
         out = torch.empty((B, Ho * Wo, Cout) if out_transposed else (B, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
     out_elems = Cout * B * Ho * Wo
     # split-K only happens for small outputs (< ~800 workgroups); the library clamps the factor to the capacity given here
-    ws = workspace(x.device, min(32 * out_elems, max(2 * out_elems, 1 << 24))) if splitk != 1 else None
+    # `ws`: the caller's own split-K scratch (hipGraphs that may replay concurrently must not share the per-stream one)
+    if ws is None and splitk != 1:
+        ws = workspace(x.device, min(32 * out_elems, max(2 * out_elems, 1 << 24)))
     d = H.ConvDesc(B, Cin, Hin, Win, Cout, ksize, stride, pad, int(relu), int(out_transposed), int(splitk), int(tile), int(w_layout),
                    0 if ws is None else min(ws.numel(), 0x7fffffff), int(w_pitch))
     H.call('frtm_conv2d', ctypes.byref(d), H.ptr(x), H.ptr(wT), H.ptr(ktab), H.ptr(scale), H.ptr(shift),

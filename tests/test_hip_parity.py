@@ -261,7 +261,7 @@ def _hip_memory_from(g, tag, cap, dims):
     return mem
 
 
-def test_update_problem_g3(golden):
+def test_update_problem_g3(golden, spread_gate):
     from frtm_vos_amd.model.discriminator import DiscriminatorLoss
     from frtm_vos_amd.model.optimizer import GaussNewtonCG
     from frtm_vos_amd.lib.tensorlist import TensorList
@@ -281,17 +281,17 @@ def test_update_problem_g3(golden):
         for p, Ap in zip(T(g[tag + '_p']), T(g[tag + '_Ap'])):
             assert rel(opt.A(TensorList([p.to(DEV)]))[0], Ap) < 5e-5
         opt.run((10,))
-        assert rel(wv, T(g[tag + '_filters'][0])) < 2e-3, tag
+        assert rel(wv, T(g[tag + '_filters'][0])) < spread_gate('g3_%s_filters' % tag, mult=3.0, at_most=2e-3), tag
         for t in range(3):
             mem.update(T(g[tag + '_ins_x'][t:t + 1]).to(DEV), T(g[tag + '_ins_y'][t:t + 1]).to(DEV),
                        T(g[tag + '_ins_pw'][t:t + 1]).to(DEV))
             assert (mem.weights.cpu() - T(g[tag + '_sws'][t + 1])).abs().max() < 1e-6
             opt.run((10,))
-            assert rel(wv, T(g[tag + '_filters'][t + 1])) < 5e-3, (tag, t)
+            assert rel(wv, T(g[tag + '_filters'][t + 1])) < spread_gate('g3_%s_filters' % tag, mult=3.0, at_most=5e-3), (tag, t)
         assert opt.p is not None and opt.rho.numel() == 1
 
 
-def test_init_problem_g4(golden):
+def test_init_problem_g4(golden, spread_gate):
     from frtm_vos_amd.model.discriminator import DiscriminatorLoss
     from frtm_vos_amd.model.memory import Memory
     from frtm_vos_amd.model.optimizer import GaussNewtonCG
@@ -318,8 +318,10 @@ def test_init_problem_g4(golden):
                 q = opt.A(flat)
                 assert rel(q[0], a1) < 5e-5 and rel(q[1], a2) < 5e-5
         opt.run(iters)
-        assert rel(w1, T(g[tag + '_w1'])) < 5e-3, tag
-        assert rel(w2, T(g[tag + '_w2'])) < 5e-3, tag
+        e1, e2 = rel(w1, T(g[tag + '_w1'])), rel(w2, T(g[tag + '_w2']))
+        print('g4 %s: w1 %.2e (gate %.2e)  w2 %.2e (gate %.2e)' % (tag, e1, spread_gate('g4_%s_w1' % tag, mult=3.0), e2, spread_gate('g4_%s_w2' % tag, mult=3.0)))
+        assert e1 < spread_gate('g4_%s_w1' % tag, mult=3.0, at_most=5e-3), tag
+        assert e2 < spread_gate('g4_%s_w2' % tag, mult=3.0, at_most=5e-3), tag
 
 
 def test_problem_residuals_and_ip(golden):
@@ -353,7 +355,7 @@ def test_problem_residuals_and_ip(golden):
         DiscriminatorLoss(m3, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)(TensorList([w1, w2]))
 
 
-def test_discriminator_g5(golden):
+def test_discriminator_g5(golden, spread_gate):
     """init -> (apply, update) x 17 against the reference recording.  Gates as in tests/test_oracle_golden.py:
     objective value tight, scores at the algorithm's own fp32 noise floor (see that file's docstring)."""
     from frtm_vos_amd.model.discriminator import Discriminator
@@ -369,11 +371,13 @@ def test_discriminator_g5(golden):
     l_ref = _init_loss(x, y, T(g['w1_init']), T(g['w2_init']))
     l_hip = _init_loss(x, y, d.project.weight.detach().cpu(), d.filter.weight.detach().cpu())
     assert abs(l_hip - l_ref) / l_ref < 2e-3
+    smax = float(np.abs(g['scores']).max())
+    gate = spread_gate('g5_scores', mult=3.0, at_most=0.06 / smax) * smax          # 3 x the reference's own spread, never looser than round 1's 0.06
     for t in range(17):
         s = d.apply(T(g['fts'][t:t + 1]).to(DEV))
         d.update(T(g['ys'][t:t + 1]).to(DEV))
         assert s.shape == (1, 1, h, w)
-        assert (s.cpu() - T(g['scores'][t:t + 1])).abs().max() < 0.06, t
+        assert (s.cpu() - T(g['scores'][t:t + 1])).abs().max() < gate, t
         assert (d.memory.weights.cpu() - T(g['sws'][t])).abs().max() < 1e-6, t
     assert d.frame_num == 17 and set(d.state_dict().keys()) == {'project.weight', 'filter.weight'}
 

@@ -55,7 +55,7 @@ def _mem_from(g, tag, cap):
     return m
 
 
-def test_g3_update_problem(golden):
+def test_g3_update_problem(golden, spread_gate):
     g = golden('g3_update')
     c, h, w, H, W, cap = [int(v) for v in g['dims']]
     for tag in ('a', 'b'):
@@ -72,15 +72,15 @@ def test_g3_update_problem(golden):
         for p, Ap in zip(T(g[tag + '_p']), T(g[tag + '_Ap'])):
             assert rel(prob.A([p])[0], Ap) < 2e-5
         opt.run((10,))
-        assert rel(wv, T(g[tag + '_filters'][0])) < 1e-3, tag
+        assert rel(wv, T(g[tag + '_filters'][0])) < spread_gate('g3_%s_filters' % tag, at_most=1e-3), tag
         for t in range(3):
             mem.update(T(g[tag + '_ins_x'][t]), T(g[tag + '_ins_y'][t]), T(g[tag + '_ins_pw'][t]))
             assert (mem.weights - T(g[tag + '_sws'][t + 1])).abs().max() < 1e-6
             opt.run((10,))
-            assert rel(wv, T(g[tag + '_filters'][t + 1])) < 2e-3, (tag, t)
+            assert rel(wv, T(g[tag + '_filters'][t + 1])) < spread_gate('g3_%s_filters' % tag, at_most=2e-3), (tag, t)
 
 
-def test_g4_init_problem(golden):
+def test_g4_init_problem(golden, spread_gate):
     g = golden('g4_init')
     x, y = T(g['x']), T(g['y'])
     pw = O.pixel_weights(y, PW)
@@ -99,8 +99,8 @@ def test_g4_init_problem(golden):
                 q = prob.A([p1, p2])
                 assert rel(q[0], a1) < 2e-5 and rel(q[1], a2) < 2e-5
         opt.run(iters)
-        assert rel(w1, T(g[tag + '_w1'])) < 2e-3
-        assert rel(w2, T(g[tag + '_w2'])) < 2e-3
+        assert rel(w1, T(g[tag + '_w1'])) < spread_gate('g4_%s_w1' % tag, at_most=2e-3)
+        assert rel(w2, T(g[tag + '_w2'])) < spread_gate('g4_%s_w2' % tag, at_most=2e-3)
 
 
 def _init_loss(x, y, w1, w2):
@@ -113,14 +113,15 @@ def _init_loss(x, y, w1, w2):
     return float((f * f).sum() + 1e-8 * (w1 * w1).sum() + 1e-4 * (w2 * w2).sum())
 
 
-def test_g5_discriminator(golden):
+def test_g5_discriminator(golden, spread_gate):
     """End-to-end init -> (apply, update) x 17.  The truncated GN/CG trajectory is chaotic under fp32
     rounding on this ill-conditioned fixture: b and A(p) agree with the reference to ~3e-7, three CG
     steps to ~6e-6, but after 35 CG steps weights differ by ~5 % and scores by ~2-3 % between two
     fp32 CPU evaluations that differ only in summation order (reference autograd vs this explicit
     operator).  An fp64 run of the same recurrences is as far from the reference as this fp32 run is,
     so the trajectory-level gates are: (1) the objective value reached, tight; (2) scores, at the
-    measured fp32 noise floor of the algorithm."""
+    measured fp32 noise floor of the algorithm: 2 x the reference's own run-to-run spread (tests/golden/g_spread.npz:
+    3.2 % of max|score| over 7 re-runs with ulp-level input changes / other thread counts), never looser than the 0.06 of round 1."""
     g = golden('g5_disc')
     x, y = T(g['x']), T(g['y'])
     d = O.DiscriminatorRef(T(g['w1_0']), T(g['w2_0']), init_iters=(5, 10, 10, 10), update_iters=(5,),
@@ -133,6 +134,7 @@ def test_g5_discriminator(golden):
                              update_iters=(5,), CG_forgetting_rate=750, memory_size=8, pixel_weighting=PW)
     d64.init(x.double(), y)
     floor = 0.0
+    gate = spread_gate('g5_scores', at_most=0.06 / float(np.abs(g['scores']).max())) * float(np.abs(g['scores']).max())
     for t in range(17):
         ft, yy = T(g['fts'][t:t + 1]), T(g['ys'][t:t + 1])
         s = d.apply(ft)
@@ -141,7 +143,7 @@ def test_g5_discriminator(golden):
         d64.update(yy.double())
         ref = T(g['scores'][t:t + 1])
         floor = max(floor, float((s64.float() - ref).abs().max()))       # reference's own distance to fp64
-        assert (s - ref).abs().max() < 0.06, t
+        assert (s - ref).abs().max() < gate, t
         assert (d.memory.weights - T(g['sws'][t])).abs().max() < 1e-6, t
     assert floor > 5e-3      # documents the noise floor: the reference itself is this far from fp64
 
@@ -215,3 +217,74 @@ def test_resnet_taps():
         for L, ch, st in zip(('layer1', 'layer2', 'layer3', 'layer4', 'layer5'), chans, (4, 4, 8, 16, 32)):
             assert out[L].shape == (1, ch, 64 // st, 96 // st), (name, L, out[L].shape)
             assert torch.isfinite(out[L]).all()
+
+
+def _joint_inputs(seed, K, cin, c, h, w, H, W):
+    """Mirrors oracle/make_golden_r2.py: joint_inputs (same draw order)."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.relu(torch.randn(K, cin, h, w, generator=g))
+    Y = torch.zeros(K, 1, H, W)
+    for i in range(K):
+        y0 = int(torch.randint(0, H // 2, (1,), generator=g)); x0 = int(torch.randint(0, W // 2, (1,), generator=g))
+        hh = int(torch.randint(20, H // 2, (1,), generator=g)); ww = int(torch.randint(20, W // 2, (1,), generator=g))
+        Y[i, 0, y0:y0 + hh, x0:x0 + ww] = 1
+    w1 = (torch.rand(c, cin, 1, 1, generator=g) * 2 - 1) / cin ** 0.5
+    w2 = (torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / (9 * c) ** 0.5
+    p1 = torch.randn(c, cin, 1, 1, generator=g) * 0.03
+    p2 = torch.randn(1, c, 3, 3, generator=g)
+    idx = torch.randint(0, c * cin, (4096,), generator=g)
+    return X, Y, w1, w2, p1, p2, idx
+
+
+def test_g9_joint_problem_fullsize(golden):
+    """The JOINT first-frame problem at BASELINE size (K=5, c=96, 30x54 grid, 480x854 labels, Cin = 256 and 1024): b and
+    A(p1,p2) of the restatement vs the reference's autograd double-backward (fixture G9, reference discriminator.py:165-176)."""
+    g = golden('g9_init_fullsize')
+    for cin in (256, 1024):
+        t = 'c%d_' % cin
+        K, cin_, c, h, w, H, W = [int(v) for v in g[t + 'dims']]
+        X, Y, w1, w2, p1, p2, idx = _joint_inputs(int(g[t + 'seed']), K, cin_, c, h, w, H, W)
+        mem = O.MemoryRef(K, X.shape[1:], Y.shape[1:], 0.1)
+        mem.initialize(X, Y, O.pixel_weights(Y, PW))
+        prob = O.InitProblemRef(mem, (1e-4, 1e-2), (1e-4, 1e-2))
+        prob.initialize()
+        for name, v in (('b', prob.linearize([w1, w2])), ('Ap', prob.A([p1, p2]))):
+            v1 = v[0].reshape(-1)
+            assert float((v1[idx] - T(g[t + name + '1_sample'])).abs().max()) / float(g[t + name + '1_absmax']) < 2e-5, (cin, name)
+            assert abs(float(v1.norm()) - float(g[t + name + '1_norm'])) / float(g[t + name + '1_norm']) < 1e-5, (cin, name)
+            assert rel(v[1], T(g[t + name + '2'])) < 2e-5, (cin, name)
+
+
+def _fullsize_update_inputs(seed, N, c, h, w, H, W):
+    """Mirrors oracle/make_golden.py: full_size_inputs."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.relu(torch.randn(N, c, h, w, generator=g))
+    Y = torch.zeros(N, 1, H, W)
+    for i in range(N):
+        y0 = int(torch.randint(0, H // 2, (1,), generator=g)); x0 = int(torch.randint(0, W // 2, (1,), generator=g))
+        hh = int(torch.randint(20, H // 2, (1,), generator=g)); ww = int(torch.randint(20, W // 2, (1,), generator=g))
+        Y[i, 0, y0:y0 + hh, x0:x0 + ww] = 0.55 + 0.45 * torch.rand(hh, ww, generator=g)
+    sw = torch.rand(N, generator=g) + 0.1
+    sw = sw / sw.sum()
+    w2 = (torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / (9 * c) ** 0.5
+    p = torch.randn(1, c, 3, 3, generator=g)
+    return X, Y, sw, w2, p
+
+
+def test_g8_full_memory_n80(golden, spread_gate):
+    """The per-frame update problem with a FULL memory (N = 80, 480p, c = 96): b, A p and the filter after run((10,))."""
+    g = golden('g8_fullsize_n80')
+    N, c, h, w, H, W = [int(v) for v in g['dims']]
+    X, Y, sw, w2, p = _fullsize_update_inputs(int(g['seed']), N, c, h, w, H, W)
+    mem = O.MemoryRef(N, X.shape[1:], Y.shape[1:], 0.1)
+    mem.samples[:], mem.labels[:], mem.weights[:] = X, Y, sw
+    mem.pixel_weights[:] = O.pixel_weights((Y > 0.5).float(), PW)
+    mem.current_size = N
+    wv = w2.clone()
+    prob = O.UpdateProblemRef(mem, 1e-2, 1e-2)
+    opt = O.GaussNewtonCGRef(prob, [wv], fletcher_reeves=False, standard_alpha=True, direction_forget_factor=0.9 ** 750)
+    prob.initialize()
+    assert rel(prob.linearize([wv])[0], T(g['b'])) < 2e-5
+    assert rel(prob.A([p])[0], T(g['Ap'])) < 2e-5
+    opt.run((10,))
+    assert rel(wv, T(g['filt'])) < spread_gate('g8n80_filt')
