@@ -79,3 +79,72 @@ def db_statistics(per_frame_values):
     ids = np.round(np.linspace(1, len(v), 5) + 1e-10).astype(np.int64) - 1
     bins = [v[ids[i]:ids[i + 1] + 1] for i in range(4)]
     return float(v.mean()), float((v > 0.5).mean()), float(np.mean(bins[0]) - np.mean(bins[3]))
+
+
+# ---- the reference's names (lib/davis.py:19-236), pinned by tests/golden/g10_davis.npz --------------------------------------
+
+def davis_jaccard_measure(fg_mask, gt_mask):
+    """Reference lib/davis.py:54-71 (argument order: segmentation first)."""
+    return db_eval_iou(gt_mask, fg_mask)
+
+
+def davis_f_measure(foreground_mask, gt_mask, bound_th=0.008):
+    """Reference lib/davis.py:75-131."""
+    return db_eval_boundary(foreground_mask, gt_mask, bound_th)
+
+
+def nanmean(*args, **kwargs):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        return np.nanmean(*args, **kwargs)
+
+
+def mean(X):
+    return nanmean(np.asarray(X, dtype=np.float64))
+
+
+def std(X):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=RuntimeWarning)
+        return np.nanstd(np.asarray(X, dtype=np.float64))
+
+
+def recall(X, threshold=0.5):
+    x = np.asarray(X, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    return nanmean(x > threshold) if x.size else float('nan')
+
+
+def decay(X, n_bins=4):
+    """First-quarter mean minus last-quarter mean over the non-NaN values (reference lib/davis.py:214-227; the bin edges go
+    through uint8 there, so sequences beyond 256 evaluated frames wrap -- kept: DAVIS / YouTube-VOS sequences are shorter)."""
+    x = np.asarray(X, dtype=np.float64)
+    x = x[~np.isnan(x)]
+    ids = (np.round(np.linspace(1, len(x), n_bins + 1) + 1e-10) - 1).astype(np.uint8)
+    bins = [x[ids[i]:ids[i + 1] + 1] for i in range(4)]
+    return nanmean(bins[0]) - nanmean(bins[3])
+
+
+def evaluate_sequence(segmentations, annotations, object_info, measure='J'):
+    """Reference lib/davis.py:19-50.  segmentations / annotations: ordered dicts frame name -> label image ((1,H,W) tensor or
+    (H,W) array); object_info: {object id: name of its first frame}.  A frame counts for an object strictly after the
+    object's first frame and strictly before the last frame of the sequence; the others stay NaN."""
+    fn = {'J': davis_jaccard_measure, 'F': davis_f_measure}[measure]
+    names = list(annotations.keys())
+    out = dict(raw={})
+
+    def arr(v):
+        v = v.numpy() if hasattr(v, 'numpy') else np.asarray(v)
+        return v.reshape(v.shape[-2:])
+    for obj_id, first in object_info.items():
+        r = np.full(len(names), np.nan)
+        i0 = names.index(first)
+        for i, (an, sg) in enumerate(zip(annotations, segmentations)):
+            if i0 < i < len(names) - 1:
+                r[i] = fn(arr(segmentations[sg]) == obj_id, arr(annotations[an]) == obj_id)
+        out['raw'][obj_id] = r
+    for name, f in (('decay', decay), ('mean', mean), ('recall', recall), ('std', std)):
+        out[name] = [float(f(r)) for r in out['raw'].values()]
+    return out

@@ -2,6 +2,7 @@
 PNGs from disk).  Frames 0 and the last one are skipped like in the DAVIS protocol (lib/evaluation.py:35-41)."""
 import numpy as np
 
+from . import davis as _davis
 from .davis import db_eval_boundary, db_eval_iou, db_statistics
 
 
@@ -15,8 +16,18 @@ def evaluate_sequence(pred_labels, gt_labels, obj_ids, measure='J', skip_first_l
     return out
 
 
-def evaluate_dataset(results, measure='J'):
-    """results: iterable of (name, pred_labels, gt_labels, obj_ids) -> dict(mean, recall, decay, per_sequence)."""
+def evaluate_dataset(dset, results_path=None, measure='J', to_file=True):
+    """Two call forms:
+      evaluate_dataset(dset, results_path, measure='J', to_file=True)   the reference's (lib/evaluation.py:9-85; driver:
+          evaluate.py:159-165): ``dset`` yields sequences with .name / .annos / .obj_ids / .start_frames / .merge_objects, the
+          tracker's PNGs are read from results_path/<sequence>/<frame>.png, per-sequence lines and the final
+          "<measure>: mean, recall, decay" line go to stdout and results_path/evaluation-<measure>.txt.  Returns the summary dict.
+      evaluate_dataset(results, measure)   in-memory: iterable of (name, pred_labels, gt_labels, obj_ids)."""
+    if results_path is not None and not isinstance(results_path, str) or hasattr(dset, 'name'):
+        return _evaluate_dataset_files(dset, results_path, measure, to_file)
+    if isinstance(results_path, str) and results_path in ('J', 'F'):
+        measure = results_path
+    results = dset
     per_seq, all_means = {}, []
     for name, pred, gt, ids in results:
         vals = evaluate_sequence(pred, gt, ids, measure)
@@ -34,3 +45,53 @@ def j_and_f(pred_labels, gt_labels, obj_ids):
     jm = np.mean([np.mean(v) for v in j.values()])
     fm = np.mean([np.mean(v) for v in f.values()])
     return 100.0 * (jm + fm) / 2.0, 100.0 * jm, 100.0 * fm
+
+
+def _evaluate_dataset_files(dset, results_path, measure='J', to_file=True):
+    from collections import OrderedDict as odict
+    from pathlib import Path
+    from .image import imread
+    from .utils import text_bargraph
+    results_path = Path(results_path)
+    scores, decays, recalls, results = [], [], [], odict()
+    f = open(results_path / ('evaluation-%s.txt' % measure), 'w') if to_file else None
+
+    def out(msg):
+        print(msg)
+        if f is not None:
+            print(msg, file=f)
+            f.flush()
+    n_seqs = len(dset)
+    for j, sequence in enumerate(dset):
+        annotations, segmentations = odict(), odict()
+        for file in sequence.annos:
+            lb = imread(file)
+            annotations[file.stem] = (lb != 0).to(lb.dtype) if sequence.merge_objects else lb
+            segmentations[file.stem] = imread(results_path / sequence.name / file.name)
+        object_info = {}
+        for obj_id in sequence.obj_ids:                       # one start frame per object, no background object
+            for frame, ids in sequence.start_frames.items():
+                if obj_id in ids:
+                    assert obj_id not in object_info
+                    object_info[obj_id] = frame
+        assert 0 not in object_info
+        n_objs = len(object_info)
+        out('%d/%d: %s: %d object%s' % (j + 1, n_seqs, sequence.name, n_objs, 's' if n_objs > 1 else ''))
+        r = _davis.evaluate_sequence(segmentations, annotations, object_info, measure=measure)
+        results[sequence.name] = r
+        per_obj, per_frame = [], []
+        for obj_id, score in r['raw'].items():
+            per_frame.append(score)
+            per_obj.append(_davis.mean(score))
+            if n_objs > 1:
+                out('joint {obj}: acc {score:.3f} \u250a{apf}\u250a'.format(obj=obj_id, score=per_obj[-1], apf=text_bargraph(score)))
+        decays.extend(r['decay'])
+        recalls.extend(r['recall'])
+        scores.extend(per_obj)
+        out('final  : acc {seq:.3f} ({dset:.3f}) \u250a{apf}\u250a'.format(
+            seq=_davis.mean(per_obj), dset=float(np.mean(scores)), apf=text_bargraph(_davis.nanmean(np.array(per_frame), axis=0))))
+    out('%s: %.3f, recall: %.3f, decay: %.3f' % (measure, _davis.mean(scores), _davis.mean(recalls), _davis.mean(decays)))
+    if f is not None:
+        f.close()
+    return dict(measure=measure, mean=float(_davis.mean(scores)), recall=float(_davis.mean(recalls)), decay=float(_davis.mean(decays)),
+                per_sequence=results)

@@ -33,8 +33,32 @@ class DiscriminatorLoss(MinimizationProblem):
     Flat vector layout used by the solver: [ project^T as (Cin,c) | filter as (c,9) ].
     """
 
-    def __init__(self, memory: Memory, filter_regs, precond, filter_weight, project_weight=None):
+    def __init__(self, *args, **kwargs):
+        """Two call forms:
+          DiscriminatorLoss(memory, filter_regs, precond, filter_weight, project_weight=None)       the hot path's own form
+          DiscriminatorLoss(x, y, filter_regs, precond, sample_weights, net, pixel_weighting, compute_norm=False)
+              the reference's signature (discriminator.py:13-14): x / y / pixel_weighting / sample_weights are the memory's
+              buffers and stay ALIASED (their normal equations are rebuilt from them on every initialize(), i.e. every
+              run(), like the reference re-gathers them, :38-43); net is the filter conv or Sequential(project, filter)."""
         super().__init__()
+        x = args[0] if args else kwargs.get('x', kwargs.get('memory'))
+        self._aliased = torch.is_tensor(x)
+        if self._aliased:
+            names = ('x', 'y', 'filter_regs', 'precond', 'sample_weights', 'net', 'pixel_weighting', 'compute_norm')
+            a = dict(zip(names, args), **kwargs)
+            net = a['net']
+            convs = [m for m in net.modules() if isinstance(m, nn.Conv2d)]
+            if len(convs) not in (1, 2) or any(m.bias is not None for m in convs):
+                raise TypeError('net must be the bias-free filter conv or Sequential(project, filter)')
+            H.require_gpu(a['x'], 'DiscriminatorLoss')
+            memory = Memory.aliasing(a['x'], a['y'], a['pixel_weighting'], a['sample_weights'])
+            self._setup(memory, a['filter_regs'], a['precond'], convs[-1].weight, convs[0].weight if len(convs) == 2 else None)
+        else:
+            names = ('memory', 'filter_regs', 'precond', 'filter_weight', 'project_weight')
+            a = dict(zip(names, args), **kwargs)
+            self._setup(a['memory'], a['filter_regs'], a['precond'], a['filter_weight'], a.get('project_weight'))
+
+    def _setup(self, memory, filter_regs, precond, filter_weight, project_weight=None):
         self.mem = memory
         self.joint = project_weight is not None
         self.w1, self.w2 = project_weight, filter_weight
@@ -78,6 +102,9 @@ class DiscriminatorLoss(MinimizationProblem):
     def initialize(self):
         """Active samples = the first current_size slots (reference discriminator.py:38-43 selects
         weight > 0; slots fill in index order and weights stay positive, so the two coincide)."""
+        if self._aliased:
+            self.mem.refresh_normals()
+            self._xt_for = None
         self.N = self.mem.current_size
         if self.joint and self._xt_for != (self.mem.samples.data_ptr(), self.N):
             for n in range(self.N):

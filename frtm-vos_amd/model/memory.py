@@ -12,7 +12,7 @@ full-resolution tensor.  Sample weights live on the device and the replacement i
 comes back to the host (``frtm_memory_next_slot``): no ``.item()`` sync (reference memory.py:80-81).
 
 ``keep_hires=True`` additionally stores ``labels`` / ``pixel_weights`` like the reference
-(debugging / API completeness; not read by the solver).
+(debugging / API completeness; not read by the solver); without it the two attributes are allocated on first access.
 """
 import torch
 
@@ -42,9 +42,9 @@ class Memory:
         self.normal_B = torch.zeros(capacity, 9, *self.grid, device=dev)
         self.normal_c = torch.zeros(capacity, *self.grid, device=dev)
         self.keep_hires = keep_hires
+        self._labels = self._pixel_weights = None
         if keep_hires:
-            self.labels = torch.zeros(capacity, *labels_size, device=dev)
-            self.pixel_weights = torch.zeros(capacity, *labels_size, device=dev)
+            self._alloc_hires()
         self.pw_params = pixel_weighting
         self._capacity = capacity
         self.current_size = 0
@@ -55,6 +55,67 @@ class Memory:
         self._slot[:2].fill_(-1)
         self._have_prev = False
         self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
+
+    def _alloc_hires(self):
+        self._labels = torch.zeros(self._capacity, *self.labels_size, device=self.device)
+        self._pixel_weights = torch.zeros(self._capacity, *self.labels_size, device=self.device)
+        self.keep_hires = True
+
+    @property
+    def labels(self):
+        """Full-resolution label maps like the reference's Memory.labels (memory.py:15).  The solver only needs their
+        low-resolution normal form, so without ``keep_hires=True`` the buffers do not exist until somebody asks: the first access
+        allocates them and switches recording on -- samples stored BEFORE that moment read as zeros (their maps were never kept)."""
+        if self._labels is None:
+            self._alloc_hires()
+        return self._labels
+
+    @property
+    def pixel_weights(self):
+        """Full-resolution pixel-weight maps (reference memory.py:16); allocated lazily like ``labels``."""
+        if self._pixel_weights is None:
+            self._alloc_hires()
+        return self._pixel_weights
+
+    @classmethod
+    def aliasing(cls, samples, labels, pixel_weights, weights, learning_rates=0.1):
+        """A memory that ALIASES the caller's buffers (the reference's problem objects alias memory.samples / labels /
+        pixel_weights / weights, discriminator.py:169-171,188-191: in-place edits between two run() calls reach the solver).
+        Only the low-resolution normal equations are own storage; ``refresh_normals`` rebuilds them from the aliased maps."""
+        m = cls.__new__(cls)
+        dev = samples.device
+        if dev.type != 'cuda':
+            raise RuntimeError('Memory lives on the GPU (got device %s); there is no CPU path' % dev)
+        cap = samples.shape[0]
+        m.samples, m.weights = samples, weights
+        m.grid = tuple(samples.shape[-2:])
+        m.labels_size = tuple(labels.shape[1:])
+        m.normal_B = torch.zeros(cap, 9, *m.grid, device=dev)
+        m.normal_c = torch.zeros(cap, *m.grid, device=dev)
+        m.keep_hires = True
+        m._labels, m._pixel_weights = labels, pixel_weights
+        m.pw_params = None
+        m._capacity = cap
+        m.current_size = 0
+        m.device = dev
+        m.learning_rates = learning_rates
+        m._slot = torch.zeros(4, dtype=torch.int32, device=dev)
+        m._slot[:2].fill_(-1)
+        m._have_prev = False
+        m._scratch = torch.zeros(max(cap, 8) * 32, device=dev)
+        return m
+
+    def refresh_normals(self):
+        """Active samples = weight > 0 (reference discriminator.py:38-43); they must be the leading slots (slots fill in index
+        order).  Rebuilds normal_B / normal_c of those slots from the full-resolution maps and returns their number."""
+        active = (self.weights > 0).nonzero().flatten().tolist()
+        n = len(active)
+        if active != list(range(n)):
+            raise ValueError('active samples (weight > 0) must occupy the leading memory slots, got %s' % active)
+        if n:
+            self._build_normals(self._labels[:n], self._pixel_weights[:n], n, None, 0)
+        self.current_size = n
+        return n
 
     @property
     def capacity(self):
@@ -117,8 +178,8 @@ class Memory:
         self.weights[:K] = w / w.sum()
         lab, pw = self._build_normals(init_labels, pixel_weights, K, None, 0)
         if self.keep_hires:
-            self.labels[:K] = lab.float().view(K, *self.labels_size)
-            self.pixel_weights[:K] = (pw if pw is not None else self._hires_pw(lab)).view(K, *self.labels_size)
+            self._labels[:K] = lab.float().view(K, *self.labels_size)
+            self._pixel_weights[:K] = (pw if pw is not None else self._hires_pw(lab)).view(K, *self.labels_size)
         self.current_size = K
 
     def initialize_like(self, init_features, other):
@@ -155,9 +216,9 @@ class Memory:
         lab, pw = self._build_normals(labels, pixel_weights, 1, slot_dev_ptr, 0, px_count if pixel_weights is None else None)
         if self.keep_hires:
             labf = lab.float().contiguous()          # named: H.ptr() only takes the address
-            H.call('frtm_memory_insert', H.ptr(labf), H.ptr(self.labels), labf.numel(), slot_dev_ptr)
+            H.call('frtm_memory_insert', H.ptr(labf), H.ptr(self._labels), labf.numel(), slot_dev_ptr)
             pwt = pw if pw is not None else self._hires_pw(lab)
-            H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self.pixel_weights), pwt.numel(), slot_dev_ptr)
+            H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self._pixel_weights), pwt.numel(), slot_dev_ptr)
 
     def update(self, features, labels, pixel_weights=None, count_dev=None, px_count=None):
         """Reference memory.py:59-63.  With ``count_dev`` the insert is guarded on the device; ``current_size`` is then an

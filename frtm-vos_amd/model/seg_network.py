@@ -5,7 +5,8 @@ SURVEY.md 8f row "next-1".  Two execution paths with identical results:
    kernels of libfrtm_hip.so (halo-tile 3x3 / vectorised 1x1) with bias, eval-BatchNorm, ReLU and the residual add folded
    into the conv epilogue; the glue (score injection, channel-attention combine, polyphase bicubic, bilinear) is one fused
    HIP kernel each (csrc/refiner_ops.hip).  ~80 launches per frame instead of ~370 framework launches.
- * plain PyTorch ops (the definition of the network; used on CPU, for training, and as the definition the HIP path is tested against).
+ * ``forward_torch``: plain PyTorch ops (the definition of the network; taken for CPU tensors, and called explicitly for training
+   and as the definition the HIP path is tested against -- ``forward`` never falls back to it silently on the GPU: it raises).
 Structural changes relative to the reference that leave the results unchanged:
  * all objects of a frame go through ONE batched pass (scores (n_obj,1,h,w), shared backbone taps);
    the reference loops over objects in Python (model/tracker.py:200-204);
@@ -168,7 +169,11 @@ class SegNetwork(nn.Module):
         taps of those F frames, (F,C,H,W) each (F = 1: the n objects of one frame); returns (F*n,1,H,W) logits.  The reference
         (seg_network.py:176-189) evaluates one object of one frame per call; frames between two filter re-solves do not depend
         on each other, so the tracker hands over a whole window of them."""
-        if scores.is_cuda and not self.training and not torch.is_grad_enabled() and shared is None:
+        if scores.is_cuda and shared is None:
+            if self.training or torch.is_grad_enabled():
+                raise RuntimeError('SegNetwork.forward on the GPU is the inference path (HIP kernels, no autograd): call it in eval() mode '
+                                   'under torch.no_grad(); for training / gradients call forward_torch(...) explicitly '
+                                   '(the PyTorch definition of the same network)')
             if self.use_graphs:
                 return self._forward_graphed(scores, features, image_size)
             return self._forward_hip(scores, features, image_size)

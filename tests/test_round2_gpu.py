@@ -198,3 +198,78 @@ def test_first_frame_fit_as_hipgraph_equals_eager_and_survives_recycling():
             de.update(soft)
         assert torch.equal(dg.filter.weight, de.filter.weight) and dg.num_solves == de.num_solves == 2
     assert 'init_graph' in dg._ws and 'init_graph' not in de._ws
+
+
+def test_reference_signature_of_discriminator_loss_and_aliasing(golden):
+    """DiscriminatorLoss(x, y, filter_regs, precond, sample_weights, net, pixel_weighting) -- the reference's constructor
+    (discriminator.py:13-14) -- on fixture G3's data: right-hand side and operator equal the reference's, and the problem
+    ALIASES the caller's buffers (an in-place edit of a label map between two run() calls reaches the solver, :169-171)."""
+    import numpy as np
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    T = torch.from_numpy
+    g = golden('g3_update')
+    c, h, w, H, W, cap = [int(v) for v in g['dims']]
+    x, y, pw, sw = (T(g['a_' + k]).clone().to(DEV) for k in ('samples0', 'labels0', 'pw0', 'sw0'))
+    filt = torch.nn.Conv2d(c, 1, 3, padding=1, bias=False).to(DEV)
+    filt.weight.data.copy_(T(g['a_w0']))
+    filt.weight.requires_grad_(False)
+    prob = DiscriminatorLoss(x=x, y=y, filter_regs=(1e-2,), precond=(1e-2,), sample_weights=sw, net=filt, pixel_weighting=pw)
+    opt = GaussNewtonCG(prob, TensorList([filt.weight]), fletcher_reeves=False, standard_alpha=True, direction_forget_factor=0.9 ** 750)
+    prob.initialize()
+    assert prob.N == int((sw > 0).sum()) == 7
+    opt._alloc()
+    prob.linearize(opt.x, opt._buf[0])
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max())
+    assert rel(opt.b[0], T(g['a_b'])) < 5e-5
+    for p, Ap in zip(T(g['a_p']), T(g['a_Ap'])):
+        assert rel(opt.A(TensorList([p.to(DEV)]))[0], Ap) < 5e-5
+    opt.run((10,))
+    assert rel(filt.weight, T(g['a_filters'][0])) < 1e-3
+    # residual list of the reference (discriminator.py:45-50) is available because the full-resolution maps are aliased
+    r = prob(TensorList([filt.weight]))
+    assert len(r) == 2 and r[0].shape == (7, 1, H, W)
+    # aliasing: zero one label map in place -> the next run() sees other normal equations
+    before = prob.mem.normal_c[3].clone()
+    y[3].zero_()
+    opt.run((10,))
+    assert not torch.equal(prob.mem.normal_c[3], before) and float(prob.mem.normal_c[3].abs().max()) == 0.0
+    # joint form: Sequential(project, filter)
+    proj = torch.nn.Conv2d(16, c, 1, bias=False).to(DEV)
+    xr = torch.relu(torch.randn(5, 16, h, w, device=DEV))
+    sw5 = torch.full((5,), 0.2, device=DEV)
+    pj = DiscriminatorLoss(xr, y[:5].contiguous(), (1e-4, 1e-2), (1e-4, 1e-2), sw5, torch.nn.Sequential(proj, filt), pw[:5].contiguous())
+    assert pj.joint and pj.Cin == 16
+    with pytest.raises(TypeError):
+        DiscriminatorLoss(xr, y[:5], (1e-2,), (1e-2,), sw5, torch.nn.Conv2d(16, 1, 3, padding=1).to(DEV), pw[:5])     # bias
+
+
+def test_memory_hires_maps_are_lazy_and_refiner_never_falls_back_silently():
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    m = Memory(6, (4, 6, 9), (1, 48, 70), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
+    assert m.keep_hires is False and m._labels is None
+    lab = torch.zeros(3, 1, 48, 70, device=DEV)
+    lab[:, :, 10:30, 20:50] = 1
+    m.initialize(torch.zeros(3, 4, 6, 9, device=DEV), lab)
+    assert m.labels.shape == (6, 1, 48, 70) and m.keep_hires            # first access allocates and switches recording on
+    assert float(m.labels.abs().max()) == 0.0                            # earlier samples were never kept at full resolution
+    m.update(torch.ones(1, 4, 6, 9, device=DEV), lab[:1] * 0.9)
+    assert abs(float(m.labels[3].max()) - 0.9) < 1e-6 and float(m.pixel_weights[3].min()) > 0
+    chans = {'layer5': 32, 'layer4': 16, 'layer3': 8, 'layer2': 8}
+    net = SegNetwork(1, 8, chans, True).to(DEV)
+    taps = {'layer5': torch.randn(1, 32, 3, 5, device=DEV), 'layer4': torch.randn(1, 16, 6, 9, device=DEV),
+            'layer3': torch.randn(1, 8, 12, 18, device=DEV), 'layer2': torch.randn(1, 8, 24, 35, device=DEV)}
+    s = torch.randn(2, 1, 6, 9, device=DEV)
+    with torch.enable_grad():
+        with pytest.raises(RuntimeError, match='forward_torch'):
+            net.eval()(s, taps, (48, 70))                                # grad mode: refused, not silently run through MIOpen
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match='forward_torch'):
+            net.train()(s, taps, (48, 70))
+        a = net.eval()(s, taps, (48, 70))
+        b = net.forward_torch(s, taps, (48, 70))
+    assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()) + 1e-4
