@@ -1,0 +1,382 @@
+// One Gauss-Newton iteration of the FILTER problem (reference optimizer.py:77-153 on discriminator.py:187-196: right-hand side,
+// `iters` conjugate-gradient steps, x += step * delta) as ONE persistent launch for gfx950.
+//
+// The multi-kernel form (scores -> stencil -> weight gradient -> CG step) spends 53 us per CG iteration for 25 us of kernel
+// time: four dependent launches per iteration.  Here the memory's feature maps X (N x c x h x w, 49.8 MB at N = 80, 480p) are
+// read from HBM ONCE per run and stay in VECTOR REGISTERS for all iters + 1 operator applications:
+//
+//   workgroup (n, part) owns the rows [r0, r0 + R) of sample n: 8 waves, wave = channel group (c / 8 channels), lane = x.
+//   Each lane keeps X[n, ch, r0-2 .. r0+R+1, x] for its wave's channels (12 x 14 floats at c = 96, R = 10), i.e. the rows the
+//   score halo (for the stencil) and the weight gradient need.  Per operator application, inside the workgroup:
+//     scores   s = X * v      per lane three column-partial sums (no shuffles in the channel loop), x +- 1 by two lane shifts,
+//                             channel groups combined through LDS in a fixed order
+//     stencil  t = sw (B s - c)   B, c rows of this workgroup live in LDS for the whole run
+//     wgrad    g[c,dy,dx] = sum_u t[u] X[c, u + (dy-1, dx-1)]   from the SAME registers, t taken shifted from LDS,
+//                             64-lane butterfly sums -> one 864-float slab per workgroup (write-through stores)
+//   then across workgroups: grid barrier, every workgroup sums a few elements over all slabs (fixed order), grid barrier, every
+//   workgroup reads the 864 sums and performs the CG vector step REDUNDANTLY in its own LDS copy of (b, r, r_prev, p, x): the
+//   same instructions on the same inputs give bit-identical vectors everywhere, so no third exchange is needed.
+// Two grid barriers per application (monotonic counter, agent-scope atomics; payloads travel as sc1 / write-through stores and
+// sc1 loads, so no L2 write-back fences are needed).  Every spin is bounded: on a timeout (another resident-hungry kernel holds
+// the CUs) the run aborts without touching x and leaves bar[2] raised; the host falls back to the multi-kernel form.
+// All sums have a fixed order: results are deterministic run to run.
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+namespace {
+
+constexpr int NT = 512;            // threads per workgroup (8 waves: one workgroup per CU, up to 256 VGPRs per lane)
+constexpr int NWAVE = 8;
+constexpr int CPW = 12;            // channels per wave (c <= 96)
+constexpr int RMAX = 10;           // output rows per workgroup
+constexpr int XR = RMAX + 4;       // X rows held per lane
+constexpr int SR = RMAX + 2;       // score rows (stencil halo)
+constexpr int PW = 66;             // LDS row pitch of s / t (x = -1 .. 64)
+constexpr int NMAX = CPW * NWAVE * 9;      // 864
+
+struct Params {
+  const float* X; const float* Bm; const float* cm; const float* sw;
+  float* w2; float* vec; float* state; float* slabs; float* qbuf; unsigned* bar;
+  int N, c, h, w, R, parts, iters, has_p, apply_dff, fr, std_alpha, parity;
+  float dff, lam2, invM, step;
+};
+
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Grid barrier on a monotonic counter.  Returns false (in every thread of the workgroup) if the run was aborted.
+__device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_flag, unsigned target, int* sh_flag) {
+  __syncthreads();                                   // this workgroup's stores of the phase are issued
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and have left the CU (they are write-through)
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > 400000LL) {            // 4 ms at 100 MHz: some workgroup never became resident
+        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *sh_flag = ok;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+// deterministic block sums of two values over NT threads (fixed butterfly + fixed wave order)
+__device__ __forceinline__ void bsum2(float& a, float& b, float* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[wid] = a; red[16 + wid] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWAVE; ++i) { ta += red[i]; tb += red[16 + i]; }
+  a = ta; b = tb;
+}
+
+// LDS carve-up (floats); ~80 KB, so the kernel takes its LDS dynamically (more than the 64 KB a static allocation may have)
+constexpr int L_VEC = 0;                              // 7 vectors of NMAX: b, r, r_prev, p, q (also the slab staging), x, w
+constexpr int L_B = L_VEC + 7 * NMAX;                 // [9][RMAX][64]
+constexpr int L_C = L_B + 9 * RMAX * 64;              // [RMAX][64]
+constexpr int L_S = L_C + RMAX * 64;                  // [SR][PW]
+constexpr int L_T = L_S + SR * PW;                    // [RMAX][PW]
+constexpr int L_RED = L_T + RMAX * PW;                // [NWAVE][SR][64]
+constexpr int L_SRED = L_RED + NWAVE * SR * 64;       // 32
+constexpr int L_FLAG = L_SRED + 32;                   // 1 int
+constexpr int L_TOTAL = L_FLAG + 4;
+
+__global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* vb = lds + L_VEC; float* vr = vb + NMAX; float* vrp = vr + NMAX; float* vp = vrp + NMAX; float* vq = vp + NMAX;
+  float* vx = vq + NMAX; float* vw = vx + NMAX;
+  float (*Bl)[RMAX][64] = (float (*)[RMAX][64])(lds + L_B);
+  float (*cl)[64] = (float (*)[64])(lds + L_C);
+  float (*sl)[PW] = (float (*)[PW])(lds + L_S);
+  float (*tl)[PW] = (float (*)[PW])(lds + L_T);
+  float (*red)[SR][64] = (float (*)[SR][64])(lds + L_RED);
+  float* gl = vq;                                     // slab staging: consumed (stored) before vq is written
+  float* sred = lds + L_SRED;
+  int* sh_flag_p = (int*)(lds + L_FLAG);
+#define sh_flag (*sh_flag_p)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int G = gridDim.x, g = blockIdx.x;
+  const int n_s = g / P.parts, part = g - n_s * P.parts;
+  const int r0 = part * P.R;
+  const int R = min(P.R, P.h - r0);                   // rows this workgroup owns (>= 1 by construction)
+  const int c = P.c, h = P.h, w = P.w, hw = h * w, n = c * 9;
+  unsigned* counter = P.bar;                          // bar[0] arrivals, bar[1] exits, bar[2] abort flag (left raised for the host)
+  unsigned* abort_flag = P.bar + 2;
+  unsigned epoch = 0;
+  // Every workgroup leaves through here.  The last one out zeroes the counters, so the next launch -- also the SAME captured
+  // launch replayed from a hipGraph -- starts clean; nobody polls any more at that point (a workgroup only leaves after its last barrier).
+  auto leave = [&]() {
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned k = __hip_atomic_fetch_add(P.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == (unsigned)G - 1u) {
+        __hip_atomic_store(P.bar + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+
+  // ---- resident data: X rows in registers, B / c rows and the vectors in LDS ----
+  float xr[CPW][XR];
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    const int ch = wid * CPW + k;
+    const float* Xc = P.X + ((size_t)n_s * c + min(ch, c - 1)) * hw;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int yy = r0 - 2 + i;
+      const bool ok = ch < c && lane < w && (unsigned)yy < (unsigned)h && i < P.R + 4;
+      xr[k][i] = ok ? Xc[yy * w + lane] : 0.f;
+    }
+  }
+  for (int i = tid; i < 9 * RMAX * 64; i += NT) {
+    const int d = i / (RMAX * 64), rr = (i / 64) % RMAX, x = i & 63;
+    (&Bl[0][0][0])[i] = (rr < R && x < w) ? P.Bm[((size_t)n_s * 9 + d) * hw + (r0 + rr) * w + x] : 0.f;
+  }
+  for (int i = tid; i < RMAX * 64; i += NT) {
+    const int rr = i / 64, x = i & 63;
+    (&cl[0][0])[i] = (rr < R && x < w) ? P.cm[(size_t)n_s * hw + (r0 + rr) * w + x] : 0.f;
+  }
+  for (int i = tid; i < SR * PW; i += NT) (&sl[0][0])[i] = 0.f;
+  if (tid == 0) sh_flag = 1;
+  for (int i = tid; i < RMAX * PW; i += NT) (&tl[0][0])[i] = 0.f;
+  for (int i = tid; i < NMAX; i += NT) {
+    const bool on = i < n;
+    vw[i] = on ? P.w2[i] : 0.f;
+    vp[i] = (on && P.has_p) ? P.vec[3 * n + i] : 0.f;
+    vrp[i] = (on && P.has_p) ? P.vec[2 * n + i] : 0.f;
+    vb[i] = vr[i] = vq[i] = vx[i] = 0.f;
+  }
+  const float swn = P.sw[n_s];
+  __syncthreads();
+
+  // ---- one operator application: vq <- sum_samples J^T (sw (B (X * v) - c?)) + lam2 v ----
+  auto apply = [&](const float* v, bool with_c) -> bool {
+    // scores: three column partials per score row
+    float S0[SR], S1[SR], S2[SR];
+#pragma unroll
+    for (int j = 0; j < SR; ++j) { S0[j] = 0.f; S1[j] = 0.f; S2[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const float* f = v + (wid * CPW + k) * 9;            // LDS broadcast reads (zero beyond n)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float f0 = f[dy * 3 + 0], f1 = f[dy * 3 + 1], f2 = f[dy * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < SR; ++j) {
+          const float xv = xr[k][j + dy];
+          S0[j] += f0 * xv; S1[j] += f1 * xv; S2[j] += f2 * xv;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SR; ++j) {
+      // tap dx = 0 reads the pixel to the LEFT (x - 1), dx = 2 the one to the right; lanes >= w hold zeros
+      const float l = __shfl_up(S0[j], 1, 64), r = __shfl_down(S2[j], 1, 64);
+      red[wid][j][lane] = (lane > 0 ? l : 0.f) + S1[j] + (lane < 63 ? r : 0.f);
+    }
+    __syncthreads();
+    for (int i = tid; i < SR * 64; i += NT) {
+      const int j = i >> 6, x = i & 63;
+      const int yy = r0 - 1 + j;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NWAVE; q += 4) s += (red[q][j][x] + red[q + 1][j][x]) + (red[q + 2][j][x] + red[q + 3][j][x]);
+      sl[j][x + 1] = (x < w && (unsigned)yy < (unsigned)h && j < R + 2) ? s : 0.f;
+    }
+    __syncthreads();
+    // stencil: rows wid, wid + 8
+    for (int rr = wid; rr < RMAX; rr += NWAVE) {
+      float acc = 0.f;
+      if (rr < R && lane < w) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) acc += Bl[dy * 3 + dx][rr][lane] * sl[rr + dy][lane + dx];
+        if (with_c) acc -= cl[rr][lane];
+        acc *= swn;
+      }
+      tl[rr][lane + 1] = acc;
+    }
+    __syncthreads();
+    // weight gradient from the resident rows
+    float tv[RMAX][3];
+#pragma unroll
+    for (int rr = 0; rr < RMAX; ++rr)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) tv[rr][dx] = tl[rr][lane + 2 - dx];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      float a[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) a[e] = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RMAX; ++rr)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float xv = xr[k][rr + dy + 1];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) a[dy * 3 + dx] += tv[rr][dx] * xv;
+        }
+      float mine = 0.f;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const float tot = wave_sum(a[e]);
+        mine = (lane == e) ? tot : mine;
+      }
+      if (lane < 9) gl[(wid * CPW + k) * 9 + lane] = mine;
+    }
+    __syncthreads();
+    float* slab = P.slabs + (size_t)g * NMAX;
+    for (int i = tid; i < NMAX; i += NT) st_wt(slab + i, gl[i]);
+    if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    // distributed fixed-order sum: workgroup g owns the elements [g * epw, (g + 1) * epw), one wave per element
+    const int epw = (n + G - 1) / G;
+    for (int e0 = wid; e0 < epw; e0 += NWAVE) {
+      const int e = g * epw + e0;
+      if (e < n) {
+        float s = 0.f;
+        for (int k = lane; k < G; k += 64) s += ld_l2(P.slabs + (size_t)k * NMAX + e);
+        s = wave_sum(s);
+        if (lane == 0) st_wt(P.qbuf + e, s);
+      }
+    }
+    if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    for (int i = tid; i < NMAX; i += NT) vq[i] = i < n ? ld_l2(P.qbuf + i) + P.lam2 * v[i] : 0.f;        // (gl aliases vq: its stores are long done)
+    __syncthreads();
+    return true;
+  };
+
+  // ---- right-hand side b = -(J^T f(w) + lam2 w)   (optimizer.py:80-85) ----
+  if (!apply(vw, true)) { leave(); return; }
+  // r = b; z = M^-1 r; rho' = <r,z>; rho2 = <r_prev,z>; first direction   (optimizer.py:107-130; k_cg_begin + k_cg_direction)
+  float rho_cur;
+  {
+    float d0 = 0.f, d1 = 0.f;
+    for (int i = tid; i < NMAX; i += NT) {
+      const float bv = -vq[i];
+      vb[i] = bv; vr[i] = bv;
+      const float z = bv * P.invM;
+      d0 += bv * z;
+      if (P.has_p && !P.fr) d1 += vrp[i] * z;
+    }
+    bsum2(d0, d1, sred);
+    float beta = 0.f;
+    if (P.has_p) {
+      float rho1 = P.state[0];
+      if (P.apply_dff) rho1 = rho1 / P.dff;
+      const float vv = P.fr ? d0 / rho1 : (d0 - d1) / rho1;
+      beta = (vv < 0.f) ? 0.f : vv;
+    }
+    for (int i = tid; i < NMAX; i += NT) {
+      const float z = vr[i] * P.invM;
+      vp[i] = P.has_p ? (z + vp[i] * beta) : z;
+    }
+    rho_cur = d0;
+    __syncthreads();
+  }
+  float alpha = 0.f, beta_last = 0.f, rho_prev = P.state[0];
+  for (int it = 0; it < P.iters; ++it) {
+    if (!apply(vp, false)) { leave(); return; }
+    const bool first = it == 0, last = it == P.iters - 1;
+    float pq = 0.f, pr = 0.f;
+    for (int i = tid; i < NMAX; i += NT) { pq += vp[i] * vq[i]; pr += vp[i] * vr[i]; }
+    bsum2(pq, pr, sred);
+    alpha = P.std_alpha ? rho_cur / pq : pr / pq;
+    float rn_ = 0.f, r2_ = 0.f;
+    for (int i = tid; i < NMAX; i += NT) {
+      const float rv = vr[i], pv = vp[i];
+      vrp[i] = rv;
+      vx[i] = first ? pv * alpha : vx[i] + pv * alpha;
+      float rn = rv;
+      if (!last) { rn = rv - vq[i] * alpha; vr[i] = rn; }
+      const float z = rn * P.invM;
+      rn_ += rn * z;
+      r2_ += rv * z;
+    }
+    bsum2(rn_, r2_, sred);
+    rho_prev = rho_cur;
+    if (!last) {
+      const float vv = P.fr ? rn_ / rho_cur : (rn_ - r2_) / rho_cur;
+      beta_last = (vv < 0.f) ? 0.f : vv;
+      for (int i = tid; i < NMAX; i += NT) vp[i] = vr[i] * P.invM + vp[i] * beta_last;
+      rho_cur = rn_;
+    }
+    __syncthreads();
+  }
+  // ---- write back (one workgroup): x += step * delta and the carried solver state ----
+  if (g == 0) {
+    for (int i = tid; i < n; i += NT) {
+      P.w2[i] = vw[i] + P.step * vx[i];
+      P.vec[0 * n + i] = vb[i];
+      P.vec[1 * n + i] = vr[i];
+      P.vec[2 * n + i] = vrp[i];
+      P.vec[3 * n + i] = vp[i];
+      P.vec[4 * n + i] = vq[i];
+      P.vec[5 * n + i] = vx[i];
+    }
+    if (tid == 0) {
+      // the multi-kernel form leaves: state[0] = rho of the last iteration, [4] = rho' of the next direction (if any), [1] alpha, [2] beta
+      P.state[0] = P.iters > 0 ? rho_prev : P.state[0];
+      P.state[4] = rho_cur;
+      P.state[1] = alpha;
+      P.state[2] = beta_last;
+    }
+  }
+  leave();
+#undef sh_flag
+}
+
+}  // namespace
+
+extern "C" {
+
+int frtm_cg_persistent_plan(int N, int c, int h, int w, int* parts_out, int* rows_out) {
+  if (N < 1 || c < 1 || c > CPW * NWAVE || w < 1 || w > 64 || h < 1) return 0;
+  const int min_parts = ceil_div(h, RMAX);
+  if ((long)N * min_parts > 240) return 0;
+  int parts = 240 / N;
+  if (parts > h) parts = h;
+  if (parts < min_parts) parts = min_parts;
+  int R = ceil_div(h, parts);
+  parts = ceil_div(h, R);                       // no empty workgroups
+  if (parts_out) *parts_out = parts;
+  if (rows_out) *rows_out = R;
+  return N * parts;
+}
+
+int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
+                           float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
+                           int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
+                           float lam2, float invM, float step, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && Bm && cm && sw && w2 && vec && state && slabs && qbuf && bar && iters >= 0, "frtm_cg_run_persistent: bad argument");
+  int parts = 0, R = 0;
+  const int G = frtm_cg_persistent_plan(N, c, h, w, &parts, &R);
+  FRTM_CHECK_ARG(G > 0, "frtm_cg_run_persistent: problem (N=%d, c=%d, %dx%d) does not fit the resident form", N, c, h, w);
+  Params P;
+  P.X = X; P.Bm = Bm; P.cm = cm; P.sw = sw; P.w2 = w2; P.vec = vec; P.state = state; P.slabs = slabs; P.qbuf = qbuf; P.bar = bar;
+  P.N = N; P.c = c; P.h = h; P.w = w; P.R = R; P.parts = parts; P.iters = iters; P.has_p = has_p; P.apply_dff = apply_dff;
+  P.fr = fletcher_reeves; P.std_alpha = standard_alpha; P.parity = 0; P.dff = dff; P.lam2 = lam2; P.invM = invM; P.step = step;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FRTM_HIP(hipFuncSetAttribute((const void*)k_cg_run_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4));
+    attr_set = true;
+  }
+  k_cg_run_persistent<<<G, NT, L_TOTAL * 4, (hipStream_t)stream>>>(P);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+}  // extern "C"

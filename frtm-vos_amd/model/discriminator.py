@@ -145,6 +145,14 @@ class DiscriminatorLoss(MinimizationProblem):
         H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
         return self.partial, self.N * parts, self.c * 9, self.filter_regs[0] ** 2
 
+    def persistent_args(self):
+        """Operands of the one-launch form of a GN iteration (filter problem only; None for the joint problem)."""
+        if self.joint or self.N < 1:
+            return None
+        m = self.mem
+        return dict(X=m.samples, B=m.normal_B, c_map=m.normal_c, sw=m.weights, N=self.N, c=self.c, h=self.h, w=self.w,
+                    w2=self.w2.data, lam2=self.filter_regs[0] ** 2)
+
     def _project_grad(self, lam2, pvec, sign, out):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
         H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)
@@ -274,6 +282,7 @@ class Discriminator(nn.Module):
         self.frame_num = 0
         self.num_solves = 0              # filter re-solves run by update() since init() (diagnostics: bench.py asserts the schedule)
         self.num_early_outs = 0          # host-side "fewer than 10 pixels" early-outs of update() (the device-guarded ones: memory.insert_counts)
+        self.num_persistent_aborts = 0   # persistent CG launches that timed out (GPU shared with another resident-hungry kernel)
         self.update_optimizer = None
         self.current_sample = None
         self.memory = None
@@ -289,6 +298,7 @@ class Discriminator(nn.Module):
         self.frame_num = 0
         self.num_solves = 0
         self.num_early_outs = 0
+        self.num_persistent_aborts = 0
         self.update_optimizer = None
         self.current_sample = None
         self.memory = None
@@ -365,6 +375,7 @@ class Discriminator(nn.Module):
         memory = self._memory('memory', self.memory_size, (c,) + tuple(x.shape[-2:]), y.shape[-3:], dev)
         if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing():
             opt = self._init_body(mem0, memory, None if not self.keep_hires else y)
+            opt.persistent = bool(self.persistent_cg)
             self.memory, self.update_optimizer = memory, opt
             return
         key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
@@ -381,6 +392,7 @@ class Discriminator(nn.Module):
         memory.current_size = K
         opt = ent['opt']
         opt._has_p = True
+        opt.persistent = bool(self.persistent_cg)
         self._w1T, self._w1T_key = ent['w1T'], (self.project.weight.data_ptr(), self.project.weight._version)
         self.memory, self.update_optimizer = memory, opt
 
@@ -397,8 +409,15 @@ class Discriminator(nn.Module):
             o = self._ws[tag] = GaussNewtonCG(problem, variable, fletcher_reeves=False, standard_alpha=True,
                                               direction_forget_factor=self.direction_forget_factor)
         o.x = variable
+        o.persistent = False
         o._alloc()
         return o
+
+    # True: the per-frame filter re-solves (update()) run as ONE persistent launch each when the memory's shape fits
+    # (csrc/cg_persistent.hip: w <= 64, c <= 96, N * ceil(h / 10) <= 240 -- the 480p configs; other sizes take the multi-kernel form).
+    # The fits inside init() never do: several objects are fitted on concurrent streams there, and two launches that each
+    # need all their workgroups resident at once must not share the GPU.
+    persistent_cg = True
 
     def _init_body(self, mem0, memory, y):
         """Reference :165-199 after the memory of raw samples has been filled.  Device work on this instance's buffers only."""
@@ -456,6 +475,8 @@ class Discriminator(nn.Module):
             return
         if num_positive is None:
             num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
+        if self.update_optimizer.poll_persistent_abort():      # (the host has just waited for the pixel counts anyway)
+            self.num_persistent_aborts += 1
         if num_positive < 10:
             self.num_early_outs += 1
             return

@@ -155,6 +155,7 @@ class ResnetFeatureExtractor:
         self._lanes = 1
         self._winograd = True
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
+        self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
 
     @property
     def lanes(self):
@@ -234,6 +235,19 @@ class ResnetFeatureExtractor:
             x = x.clamp(0, 255).to(torch.uint8)    # frames are uint8 everywhere in the reference (datasets.py:64-66)
         x = x.to(self.device).contiguous()
         B, _, Hh, Ww = x.shape
+        # One pass at a time on the device: callers on different streams (run_sequence's prefetch stream next to initialize() on the
+        # main stream) share the lanes' activation arenas, so a pass first waits for the previous one, whatever stream that ran on.
+        cur = torch.cuda.current_stream(self.device)
+        if self._pass_done is not None and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(self._pass_done)
+        try:
+            return self._call(x, B, Hh, Ww, output_layers)
+        finally:
+            if not torch.cuda.is_current_stream_capturing():
+                self._pass_done = torch.cuda.Event()
+                self._pass_done.record(cur)
+
+    def _call(self, x, B, Hh, Ww, output_layers):
         want = ['layer1', 'layer2', 'layer3', 'layer4', 'layer5'] if output_layers is None else list(output_layers)
         stop = max(int(L[-1]) for L in want)       # the reference always runs resnet.layer4 (:65); skipping it is exact
         size = [( (Hh + 1) // 2, (Ww + 1) // 2 )]

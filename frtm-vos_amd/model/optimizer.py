@@ -65,6 +65,8 @@ class GaussNewtonCG:
         self._n = None
         self._has_p = False
         self._buf = None
+        self._pbuf = None
+        self._persistent_launched = False
 
     # ---- device state -------------------------------------------------------------------
     def _alloc(self):
@@ -129,7 +131,54 @@ class GaussNewtonCG:
             self.run_GN_iter(n)
         return self.external_losses, self.internal_losses, self.residuals
 
+    persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
+
+    def _persistent_plan(self):
+        pr = self.problem
+        args = pr.persistent_args() if hasattr(pr, 'persistent_args') else None
+        if args is None or not self.persistent:
+            return None
+        if H.lib().frtm_cg_persistent_plan(args['N'], args['c'], args['h'], args['w'], None, None) <= 0:
+            return None
+        return args
+
+    def _run_persistent(self, num_cg_iter, a):
+        """linearize + run_CG + apply_step of run_GN_iter in ONE launch; host-side bookkeeping as in run_CG."""
+        if self._pbuf is None:
+            dev = self._buf.device
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.empty(864, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
+        slabs, qbuf, bar = self._pbuf
+        dff = float(self.direction_forget_factor)
+        if dff == 0:
+            self.reset_state()
+        n1, n2, m1, m2 = self.problem.vector_layout()
+        H.call('frtm_cg_run_persistent', H.ptr(a['X']), H.ptr(a['B']), H.ptr(a['c_map']), H.ptr(a['sw']), a['N'], a['c'], a['h'], a['w'],
+               H.ptr(a['w2']), H.ptr(self._buf), H.ptr(self._state), H.ptr(slabs), H.ptr(qbuf), H.ptr(bar),
+               int(num_cg_iter), int(self._has_p), int(self._has_p and dff != 0), int(self.fletcher_reeves), int(self.standard_alpha),
+               dff if dff != 0 else 1.0, float(a['lam2']), 1.0 / m1, float(self.step_alpha))
+        self._has_p = True
+        self._persistent_launched = True
+
+    def poll_persistent_abort(self):
+        """True if a persistent launch since the last poll gave up (its workgroups could not all become resident within the
+        spin time-out, e.g. another process holds the GPU's CUs): that run left the variable untouched.  Clears the flag and
+        switches this solver back to the multi-kernel form.  SYNCHRONISES (one 4-byte read); call it where the host waits anyway."""
+        if not self._persistent_launched or self._pbuf is None:
+            return False
+        self._persistent_launched = False
+        bar = self._pbuf[2]
+        if int(bar[2].item()) == 0:
+            return False
+        bar.zero_()
+        self.persistent = False
+        return True
+
     def run_GN_iter(self, num_cg_iter):
+        a = self._persistent_plan() if num_cg_iter > 0 else None
+        if a is not None:
+            self._run_persistent(num_cg_iter, a)
+            self.step_alpha = min(self.step_alpha * 1.2, 1.0)
+            return
         self.problem.linearize(self.x, self._buf[0])
         if num_cg_iter > 0:
             self.run_CG(num_cg_iter)

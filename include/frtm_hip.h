@@ -122,6 +122,20 @@ int frtm_cg_pq(const float* p, const float* q, const float* r, int n, float* par
 int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const float* q, int n1, int n2,
                    float invM1, float invM2, int first, int last, int standard_alpha, float* state,
                    float* partial, frtm_stream_t stream);
+/* One whole Gauss-Newton iteration of the FILTER problem (reference optimizer.py:77-153 on the problem of
+ * discriminator.py:187-196) as ONE persistent launch: right-hand side b = -(J^T f(w2) + lam2 w2), `iters` CG steps with the
+ * literal recurrences (carried p / r_prev / rho as in frtm_cg_begin / _direction / _step_small), then w2 += step * delta.
+ * The sample features X (N,c,h,w) are read once and stay in registers; Bm (N,9,h,w), cm (N,h,w), sw (N) are the memory's
+ * low-resolution normal equations and sample weights.  vec: the solver's 6*n floats {b,r,r_prev,p,q,delta}, n = 9c;
+ * state: float[8] as above; slabs: >= 256*864 floats, qbuf: >= 864 floats, bar: unsigned[4], zero-initialised once
+ * (bar[2] != 0 afterwards = the run was ABORTED by its spin time-out -- x untouched, caller falls back and clears it).
+ * frtm_cg_persistent_plan returns the number of workgroups (0 = shape not supported: w > 64, c > 96, N*ceil(h/10) > 240);
+ * all of them must be resident at once: never run two of these launches concurrently on one GPU. */
+int frtm_cg_persistent_plan(int N, int c, int h, int w, int* parts_out, int* rows_out);
+int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
+                           float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
+                           int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
+                           float lam2, float invM, float step, frtm_stream_t stream);
 /* One CG iteration's vector work for n <= 1024 in a single workgroup (the 864-element filter problem): slab reduce
  * (q = sum_k slabs[k*stride+i] + lam2 p), <p,q>, alpha, r_prev/x/r updates, and -- unless `last` -- the next direction
  * (beta, p, rho).  Same order of operations as optimizer.py:113-151; replaces frtm_vec_reduce_slabs + frtm_cg_pq +

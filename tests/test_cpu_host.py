@@ -302,6 +302,68 @@ def test_davis_measures():
     assert res['mean'] == 1.0 and 's' in res['per_sequence']
 
 
+def test_davis_measures_pinned_to_the_reference(golden):
+    """Fixture G10 (oracle/make_golden_davis.py): the reference's own lib/davis.py -- Jaccard, boundary F, seg2bmap, the
+    mean / recall / decay / std statistics and evaluate_sequence with a late-starting object -- on seeded masks."""
+    from frtm_vos_amd.lib import davis as D
+    g = golden('g10_davis')
+    for k in range(12):
+        H, W = [int(v) for v in g['shape%d' % k]]
+        a = np.unpackbits(g['a%d' % k])[:H * W].reshape(H, W).astype(bool)
+        b = np.unpackbits(g['b%d' % k])[:H * W].reshape(H, W).astype(bool)
+        assert abs(D.davis_jaccard_measure(b, a) - float(g['J'][k])) < 1e-6, k
+        assert abs(D.davis_f_measure(b, a) - float(g['F'][k])) < 1e-12, k
+        bm = np.unpackbits(g['bmap%d' % k])[:H * W].reshape(H, W).astype(bool)
+        assert np.array_equal(D.seg2bmap(a), bm), k
+    for k in range(6):
+        v = g['vec%d' % k]
+        got = [D.mean(v), D.recall(v), D.decay(v), D.std(v)]
+        assert np.allclose(got, g['stats'][k], rtol=0, atol=1e-12), (k, got, g['stats'][k])
+    from collections import OrderedDict as odict
+    ann, seg = odict(), odict()
+    for t in range(7):
+        ann['%05d' % t] = torch.from_numpy(g['seq_ann%d' % t])[None]
+        seg['%05d' % t] = torch.from_numpy(g['seq_seg%d' % t])[None]
+    for measure in 'JF':
+        r = D.evaluate_sequence(seg, ann, {1: '00000', 2: '00002'}, measure=measure)
+        raw = np.stack([r['raw'][1], r['raw'][2]])
+        ref = g['seq_%s_raw' % measure]
+        assert np.array_equal(np.isnan(raw), np.isnan(ref)) and np.allclose(np.nan_to_num(raw), np.nan_to_num(ref), atol=1e-6)
+        for st in ('mean', 'recall', 'decay', 'std'):
+            assert np.allclose(r[st], g['seq_%s_%s' % (measure, st)], atol=1e-6), (measure, st)
+
+
+def test_evaluate_dataset_reference_signature(tmp_path):
+    """evaluate_dataset(dset, results_path, measure) like the reference's driver calls it (evaluate.py:159-165): reads the
+    tracker's PNGs, writes evaluation-<measure>.txt with the per-sequence lines and the final 'J: mean, recall, decay' line."""
+    from PIL import Image
+    from frtm_vos_amd.lib.datasets import DAVISDataset
+    from frtm_vos_amd.lib.evaluation import evaluate_dataset
+    from frtm_vos_amd.lib.image import imwrite_indexed
+    root, res = tmp_path / 'DAVIS', tmp_path / 'results'
+    (root / 'ImageSets' / '2017').mkdir(parents=True)
+    (root / 'ImageSets' / '2017' / 'val.txt').write_text('cows\n')
+    (root / 'JPEGImages' / '480p' / 'cows').mkdir(parents=True)
+    (root / 'Annotations' / '480p' / 'cows').mkdir(parents=True)
+    (res / 'cows').mkdir(parents=True)
+    for t in range(6):
+        Image.fromarray(np.zeros((40, 60, 3), np.uint8)).save(root / 'JPEGImages' / '480p' / 'cows' / ('%05d.jpg' % t))
+        gt = torch.zeros(40, 60, dtype=torch.uint8)
+        gt[5 + t:20 + t, 5:25] = 1
+        gt[22:38, 30 + t:55] = 2
+        pr = gt.clone()
+        pr[5 + t:8 + t, 5:25] = 0                                  # object 1 loses 3 of 15 rows -> J = 0.8
+        imwrite_indexed(root / 'Annotations' / '480p' / 'cows' / ('%05d.png' % t), gt)
+        imwrite_indexed(res / 'cows' / ('%05d.png' % t), pr)
+    dset = DAVISDataset(root, '2017', 'val', all_annotations=True)
+    out = evaluate_dataset(dset, res, 'J')
+    assert abs(out['mean'] - 0.9) < 1e-6 and out['recall'] == 1.0 and abs(out['decay']) < 1e-9
+    text = (res / 'evaluation-J.txt').read_text()
+    assert '1/1: cows: 2 objects' in text and 'joint 1: acc 0.800' in text and text.strip().endswith('J: 0.900, recall: 1.000, decay: 0.000')
+    r = out['per_sequence']['cows']['raw']
+    assert np.isnan(r[1][0]) and np.isnan(r[1][-1]) and abs(r[1][2] - 0.8) < 1e-6 and r[2][3] == 1.0
+
+
 def test_file_datasets(tmp_path):
     """DAVIS / YouTube-VOS directory layouts -> FileSequence protocol (reference lib/datasets.py:16-158)."""
     from PIL import Image

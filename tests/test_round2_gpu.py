@@ -273,3 +273,92 @@ def test_memory_hires_maps_are_lazy_and_refiner_never_falls_back_silently():
         a = net.eval()(s, taps, (48, 70))
         b = net.forward_torch(s, taps, (48, 70))
     assert float((a - b).abs().max()) < 1e-3 * float(b.abs().max()) + 1e-4
+
+
+def _filter_problem(N, c, h, w, Hh, Ww, seed, persistent, dff=0.9 ** 750):
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    g = torch.Generator().manual_seed(seed)
+    mem = Memory(N + 3, (c, h, w), (1, Hh, Ww), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
+    X = torch.relu(torch.randn(N, c, h, w, generator=g))
+    Y = torch.zeros(N, 1, Hh, Ww)
+    for i in range(N):
+        y0, x0 = int(torch.randint(0, Hh // 2, (1,), generator=g)), int(torch.randint(0, Ww // 2, (1,), generator=g))
+        Y[i, 0, y0:y0 + Hh // 3, x0:x0 + Ww // 3] = 0.55 + 0.45 * torch.rand(Hh // 3, Ww // 3, generator=g)
+    mem.samples[:N] = X.to(DEV)
+    for k in range(0, N, 8):
+        n = min(8, N - k)
+        mem._build_normals(Y[k:k + n].to(DEV), None, n, None, k)
+    sw = torch.rand(N, generator=g) + 0.1
+    mem.weights[:N] = (sw / sw.sum()).to(DEV)
+    mem.current_size = N
+    wv = torch.nn.Parameter(((torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / (9 * c) ** 0.5).to(DEV), requires_grad=False)
+    opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=False, standard_alpha=True,
+                        direction_forget_factor=dff)
+    opt.persistent = persistent
+    return mem, opt, wv, g
+
+
+@pytest.mark.parametrize('shape', [(80, 96, 30, 54, 480, 854), (32, 96, 30, 54, 480, 854), (7, 8, 6, 9, 48, 70), (5, 96, 30, 54, 480, 854),
+                                   (24, 40, 17, 31, 272, 496), (3, 16, 23, 64, 184, 512)])
+def test_persistent_cg_run_equals_the_multi_kernel_form(shape):
+    """One persistent launch per GN iteration (features resident in registers, two grid barriers per operator application) vs
+    the launch-per-phase form: same filter after run((10,)), and after three further insert + run cycles (carried p / r_prev /
+    rho, direction forgetting), for full and partly filled memories, odd grids and channel counts; deterministic run to run."""
+    N, c, h, w, Hh, Ww = shape
+    from frtm_vos_amd import _hip as H
+    assert H.lib().frtm_cg_persistent_plan(N, c, h, w, None, None) > 0
+    res = {}
+    for persistent in (False, True, True):
+        mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 11, persistent)
+        filt = []
+        opt.run((10,))
+        filt.append(wv.detach().clone())
+        for t in range(3):
+            ft = torch.relu(torch.randn(1, c, h, w, generator=g)).to(DEV)
+            lab = torch.zeros(1, 1, Hh, Ww)
+            lab[0, 0, 5 + 3 * t:Hh // 2, 7:Ww // 2 + 5 * t] = 0.9
+            mem.update(ft, lab.to(DEV))
+            opt.run((10,) if t != 1 else (5,))
+            filt.append(wv.detach().clone())
+        assert not opt.poll_persistent_abort()
+        res.setdefault(persistent, []).append(torch.stack(filt))
+    a, b, b2 = res[False][0], res[True][0], res[True][1]
+    assert torch.equal(b, b2)                                         # fixed summation order: bit-identical run to run
+    assert bool(torch.isfinite(b).all()) and not torch.equal(b[0], b[1])
+    for k in range(4):
+        e = float((a[k] - b[k]).abs().max() / a[k].abs().max())
+        print('N=%d c=%d %dx%d  run %d: persistent vs multi-kernel %.2e' % (N, c, h, w, k, e))
+        assert e < 2e-4, (k, e)                                       # different summation orders through 10 CG steps
+
+
+def test_persistent_cg_matches_reference_fixture_g3(golden, spread_gate):
+    """Fixture G3 (reference recording: b, A p, filter after run((10,)) + 3 insert/run cycles, two forgetting rates) through the
+    persistent launch."""
+    from test_hip_parity import _hip_memory_from
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    T = torch.from_numpy
+    g = golden('g3_update')
+    c, h, w, H, W, cap = [int(v) for v in g['dims']]
+    for tag in ('a', 'b'):
+        rate = int(g[tag + '_rate'])
+        mem = _hip_memory_from(g, tag, cap, (c, h, w, H, W))
+        wv = torch.nn.Parameter(T(g[tag + '_w0']).clone().to(DEV), requires_grad=False)
+        opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=False, standard_alpha=True,
+                            direction_forget_factor=(1 - 0.1) ** rate)
+        opt.persistent = True
+        assert opt._persistent_plan() is None            # problem.initialize() has not run yet: N unknown
+        opt.run((10,))
+        assert opt._persistent_launched
+
+        def rel(a, b):
+            return float((a.cpu() - b).abs().max() / b.abs().max())
+        assert rel(wv, T(g[tag + '_filters'][0])) < spread_gate('g3_%s_filters' % tag, mult=3.0, at_most=2e-3), tag
+        for t in range(3):
+            mem.update(T(g[tag + '_ins_x'][t:t + 1]).to(DEV), T(g[tag + '_ins_y'][t:t + 1]).to(DEV), T(g[tag + '_ins_pw'][t:t + 1]).to(DEV))
+            opt.run((10,))
+            assert rel(wv, T(g[tag + '_filters'][t + 1])) < spread_gate('g3_%s_filters' % tag, mult=3.0, at_most=5e-3), (tag, t)
