@@ -60,6 +60,7 @@ def parse(argv=None):
     ap.add_argument('--first-pass-overlap', action='store_true', help='first trunk pass on a side stream next to the fits of initialize()')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
     ap.add_argument('--init-graph', action='store_true', help='first-frame fits replayed as one hipGraph per target model (default: launch by launch; no gain measured)')
+    ap.add_argument('--no-persistent-cg', action='store_true', help='filter re-solves as 4 launches per CG iteration instead of one persistent launch')
     ap.add_argument('--random-refiner', action='store_true',
                     help='default-initialised refiner (round-1 workload: no mask ever exceeds 0.5, updates early-out; counters are reported, not asserted)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -152,8 +153,10 @@ def path_counters(tracker, seq, n_frames):
     target models hold."""
     inserts = skipped = solves = early = sched_ins = sched_solve = 0
     finite = True
+    aborts = 0
     for obj_id, t in tracker.targets.items():
         d = t.discriminator
+        aborts += d.num_persistent_aborts + int(d.update_optimizer.poll_persistent_abort())
         tracked = n_frames - 1 - seq.start_frame(obj_id)
         sched_ins += tracked
         sched_solve += tracked // d.train_skipping
@@ -165,7 +168,7 @@ def path_counters(tracker, seq, n_frames):
             finite = finite and bool(torch.isfinite(x).all())
     finite = finite and bool(torch.isfinite(tracker.current_masks).all())
     return {'memory_inserts': inserts, 'memory_inserts_scheduled': sched_ins, 'cg_solves': solves, 'cg_solves_scheduled': sched_solve,
-            'early_outs_fewer_than_10_px': skipped + early, 'all_finite': finite}
+            'early_outs_fewer_than_10_px': skipped + early, 'cg_persistent_aborts': aborts, 'all_finite': finite}
 
 
 def tracking_quality(outputs, seq):
@@ -245,7 +248,7 @@ def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames):
                       (args.backbone, size[0], size[1], n_obj, 'fast' if args.fast else 'full', done - 1, inserts, threads, ncpu, T)}
 
 
-def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20):
+def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20, persistent=True):
     """HBM-bound leg: GaussNewtonCG.run((10,)) of the filter-only problem on a full memory (N = 80, 30x54 grid, c = 96).
     Algorithmic bytes: reference formulation 2*4*N*c*hw + 4*N*HW per operator application (+4*N*HW labels for
     the right-hand side); this formulation's own traffic 2*4*N*c*hw + 4*N*10*hw.  11 applications per run."""
@@ -267,6 +270,7 @@ def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20):
     wv = torch.nn.Parameter(((torch.rand(1, c, 3, 3, generator=g) * 2 - 1) / 29.4).to(dev), requires_grad=False)
     opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=False,
                         direction_forget_factor=0.9 ** 750)
+    opt.persistent = persistent
     for _ in range(3):
         opt.run((iters,))
     torch.cuda.synchronize()
@@ -291,7 +295,10 @@ def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20):
     hw, HW, apps = h * w, Hh * Ww, iters + 1
     ref_bytes = apps * (2 * 4 * n_samples * c * hw + 4 * n_samples * HW) + 4 * n_samples * HW
     own_bytes = apps * (2 * 4 * n_samples * c * hw + 4 * n_samples * 10 * hw)
-    return {'bound': 'hbm', 'kernel': 'GaussNewtonCG.run((10,)) of the filter problem, N=80: ' + getattr(opt, 'kernel_path', 'k_filter_scores + k_stencil + k_filter_wgrad + k_cg_step_small'),
+    assert not opt.poll_persistent_abort(), 'persistent CG launch timed out'
+    path = ('k_cg_run_persistent (one launch: features resident in registers)' if (persistent and opt._persistent_plan() is not None)
+            else 'k_filter_scores + k_stencil + k_filter_wgrad + k_cg_step_small (4 launches per CG iteration)')
+    return {'bound': 'hbm', 'kernel': 'GaussNewtonCG.run((10,)) of the filter problem, N=80: ' + path,
             'achieved': own_bytes / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': own_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             'ms_per_run': ms, 'ms_per_run_eager_launch': ms_eager, 'bytes_moved_this_formulation': own_bytes, 'bytes_reference_formulation': ref_bytes,
             'equivalent_rate_on_reference_bytes': ref_bytes / (ms * 1e-3) / 1e9,
@@ -401,6 +408,9 @@ def main():
     if args.init_graph:
         from frtm_vos_amd.model.discriminator import Discriminator
         Discriminator.graph_init = True
+    if args.no_persistent_cg or args.share_gpu:         # ranks sharing one GPU would starve each other's resident launches
+        from frtm_vos_amd.model.discriminator import Discriminator
+        Discriminator.persistent_cg = False
     tracker.eval()
     torch.set_grad_enabled(False)
 
@@ -482,6 +492,8 @@ def main():
     problems = []
     if not counters['all_finite']:
         problems.append('non-finite values in the target models / masks')
+    if counters['cg_persistent_aborts']:
+        problems.append('%d persistent CG launches timed out' % counters['cg_persistent_aborts'])
     if not args.random_refiner:
         if counters['memory_inserts'] + counters['early_outs_fewer_than_10_px'] < counters['memory_inserts_scheduled'] or \
                 counters['memory_inserts'] < 0.9 * counters['memory_inserts_scheduled']:
@@ -539,6 +551,8 @@ def main():
             out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev)
         if not args.no_cg_roofline:
             out['roofline_cg'] = cg_roofline(dev, size)
+            mk = cg_roofline(dev, size, persistent=False)
+            out['roofline_cg']['multi_kernel_form_ms_per_run'] = mk['ms_per_run']
         if not args.no_cpu_baseline and args.late_object is None:
             seq.preload('cpu')
             out['cpu_baseline'] = cpu_baseline(args, size, seq, aug_cpu, min(args.cpu_frames, args.steps - 1))

@@ -67,13 +67,32 @@ __device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_fla
   return *sh_flag != 0;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// 64-lane sum that lands in lane 63 only: six DPP adds on the VALU (prefix within the 16-lane rows, then row broadcasts) -- no
+// LDS crossbar traffic, unlike a __shfl_xor butterfly (ds_bpermute / ds_swizzle per step).  Fixed order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);     // bound_ctrl: lanes without a source read 0
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to63(float v) {
+  v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row holds the row total
+  v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+  return v;
+}
+
 // deterministic block sums of two values over NT threads (fixed butterfly + fixed wave order)
 __device__ __forceinline__ void bsum2(float& a, float& b, float* red) {
-  a = wave_sum(a);
-  b = wave_sum(b);
+  a = wave_sum_to63(a);
+  b = wave_sum_to63(b);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   __syncthreads();
-  if (lane == 0) { red[wid] = a; red[16 + wid] = b; }
+  if (lane == 63) { red[wid] = a; red[16 + wid] = b; }
   __syncthreads();
   float ta = 0.f, tb = 0.f;
 #pragma unroll
@@ -115,6 +134,11 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
   unsigned* counter = P.bar;                          // bar[0] arrivals, bar[1] exits, bar[2] abort flag (left raised for the host)
   unsigned* abort_flag = P.bar + 2;
   unsigned epoch = 0;
+  // optional phase stamps of workgroup 0 (bar[3] != 0): 10 ns ticks into qbuf[NMAX ..] as raw ints (tools/cg_phase_times.py)
+  const bool stamp_on = (g == 0) && (P.bar[3] != 0u);
+  int n_stamp = 0;
+  auto stamp = [&]() { if (stamp_on && tid == 0 && n_stamp < 250) { ((int*)P.qbuf)[NMAX + n_stamp] = (int)(wall_clock64() & 0x7fffffff); } ++n_stamp; };
+  stamp();
   // Every workgroup leaves through here.  The last one out zeroes the counters, so the next launch -- also the SAME captured
   // launch replayed from a hipGraph -- starts clean; nobody polls any more at that point (a workgroup only leaves after its last barrier).
   auto leave = [&]() {
@@ -161,6 +185,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
   }
   const float swn = P.sw[n_s];
   __syncthreads();
+  stamp();
 
   // ---- one operator application: vq <- sum_samples J^T (sw (B (X * v) - c?)) + lam2 v ----
   auto apply = [&](const float* v, bool with_c) -> bool {
@@ -173,11 +198,11 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       const float* f = v + (wid * CPW + k) * 9;            // LDS broadcast reads (zero beyond n)
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const float f0 = f[dy * 3 + 0], f1 = f[dy * 3 + 1], f2 = f[dy * 3 + 2];
+        const float f0 = f[dy * 3 + 0], f1 = f[dy * 3 + 1], f2_ = f[dy * 3 + 2];
 #pragma unroll
         for (int j = 0; j < SR; ++j) {
           const float xv = xr[k][j + dy];
-          S0[j] += f0 * xv; S1[j] += f1 * xv; S2[j] += f2 * xv;
+          S0[j] += f0 * xv; S1[j] += f1 * xv; S2[j] += f2_ * xv;
         }
       }
     }
@@ -197,6 +222,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       sl[j][x + 1] = (x < w && (unsigned)yy < (unsigned)h && j < R + 2) ? s : 0.f;
     }
     __syncthreads();
+    stamp();
     // stencil: rows wid, wid + 8
     for (int rr = wid; rr < RMAX; rr += NWAVE) {
       float acc = 0.f;
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       tl[rr][lane + 1] = acc;
     }
     __syncthreads();
+    stamp();
     // weight gradient from the resident rows
     float tv[RMAX][3];
 #pragma unroll
@@ -230,18 +257,19 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) a[dy * 3 + dx] += tv[rr][dx] * xv;
         }
-      float mine = 0.f;
+      float* dst = gl + (wid * CPW + k) * 9;
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
-        const float tot = wave_sum(a[e]);
-        mine = (lane == e) ? tot : mine;
+        const float tot = wave_sum_to63(a[e]);
+        if (lane == 63) dst[e] = tot;
       }
-      if (lane < 9) gl[(wid * CPW + k) * 9 + lane] = mine;
     }
     __syncthreads();
     float* slab = P.slabs + (size_t)g * NMAX;
     for (int i = tid; i < NMAX; i += NT) st_wt(slab + i, gl[i]);
+    stamp();
     if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    stamp();
     // distributed fixed-order sum: workgroup g owns the elements [g * epw, (g + 1) * epw), one wave per element
     const int epw = (n + G - 1) / G;
     for (int e0 = wid; e0 < epw; e0 += NWAVE) {
@@ -249,13 +277,16 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       if (e < n) {
         float s = 0.f;
         for (int k = lane; k < G; k += 64) s += ld_l2(P.slabs + (size_t)k * NMAX + e);
-        s = wave_sum(s);
-        if (lane == 0) st_wt(P.qbuf + e, s);
+        s = wave_sum_to63(s);
+        if (lane == 63) st_wt(P.qbuf + e, s);
       }
     }
+    stamp();
     if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    stamp();
     for (int i = tid; i < NMAX; i += NT) vq[i] = i < n ? ld_l2(P.qbuf + i) + P.lam2 * v[i] : 0.f;        // (gl aliases vq: its stores are long done)
     __syncthreads();
+    stamp();
     return true;
   };
 

@@ -654,6 +654,25 @@ __global__ __launch_bounds__(256) void k_merge_masks(float* __restrict__ masks, 
   }
 }
 
+// Any number of planes: the same arithmetic without a per-thread array (planes are re-read instead: three passes).
+__global__ __launch_bounds__(256) void k_merge_masks_any(float* __restrict__ masks, int K, int HW) {
+  masks += (size_t)blockIdx.y * K * HW;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float bg = INFINITY;
+    for (int k = 1; k < K; ++k) bg = fminf(bg, 1.f - fminf(fmaxf(masks[(size_t)k * HW + i], 1e-7f), 1.f - 1e-7f));
+    auto odds = [&](int k) {
+      const float v = k == 0 ? bg : fminf(fmaxf(masks[(size_t)k * HW + i], 1e-7f), 1.f - 1e-7f);
+      return v / (1.f - v);
+    };
+    float mx = -INFINITY; int arg = 0;
+    for (int k = 0; k < K; ++k) { const float o = odds(k); if (o > mx) { mx = o; arg = k; } }
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += expf(odds(k) - mx);
+    const float win = expf(odds(arg) - mx) / den;
+    for (int k = 0; k < K; ++k) masks[(size_t)k * HW + i] = (k == arg) ? win : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_count_above(const float* __restrict__ masks, int HW, float thr, int* __restrict__ count) {
   const int k = blockIdx.y;
   int c = 0;
@@ -880,10 +899,10 @@ int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream) {
 }
 
 int frtm_merge_masks_frames(float* masks, int frames, int n_plus_1, int HW, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(masks && frames > 0 && n_plus_1 >= 2 && n_plus_1 <= MERGE_MAX && HW > 0,
-                 "frtm_merge_masks: needs 2..%d mask planes, got %d", MERGE_MAX, n_plus_1);
+  FRTM_CHECK_ARG(masks && frames > 0 && n_plus_1 >= 2 && HW > 0, "frtm_merge_masks: needs >= 2 mask planes, got %d", n_plus_1);
   dim3 g(min(ceil_div(HW, 256), 1024), frames);
-  k_merge_masks<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
+  if (n_plus_1 <= MERGE_MAX) k_merge_masks<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
+  else k_merge_masks_any<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);      // > 15 objects (the reference has no limit)
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

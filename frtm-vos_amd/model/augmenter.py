@@ -4,7 +4,8 @@
 SURVEY.md 8f row "next-2".  The reference cuts the target out, Telea-inpaints the hole with OpenCV,
 warps target and background with NVIDIA NPP and pastes them back.  Neither OpenCV nor NPP exists
 here, so pixel-level parity is UNPINNED; what is kept is the recipe: the same parameter lists
-(evaluate.py:53-76), the same draw order from numpy's global RNG (seeded by the tracker per object),
+(evaluate.py:53-76), the same draws from numpy's global RNG in the same order (AugmentationParams2's attribute order, default
+lists included; seeded by the tracker per object; pinned by tests/test_cpu_host.py against the reference's generate_specs2),
 the same transform composition T = translate . skew . rotate . scale . translate(-target) and paste rule.
 Everything runs on the GPU: warps by the HIP kernel (csrc/image_ops.hip), the hole is filled by masked
 diffusion (a substitute for Telea inpainting), blur by a small depth-wise convolution.
@@ -46,14 +47,27 @@ class ImageAugmenter:
         np.random.shuffle(centres)
         return centres[:n]
 
-    @staticmethod
-    def _draw_specs(lists, n):
-        """Independently shuffle every parameter list and take n values of each (reference :197-228)."""
-        picked = {}
+    # defaults and ATTRIBUTE ORDER of the reference's AugmentationParams2 (augmenter.py:42-54): generate_specs2 walks vars() in this
+    # order, keys the caller adds (the background's 'tcenter') come last, and every list -- also a default one -- is shuffled,
+    # i.e. consumes draws from numpy's global RNG
+    _DEFAULT_LISTS = (('location', [(0.5, 0.5)]), ('rotation', [5, -5, 10, -10, 20, -20, 30, -30, 45, -45, 60, -60]),
+                      ('fliplr', [False, False, True]), ('scale', [0.7, 1.0, 1.5, 2.0, '0.25', '0.5', '1.0']),
+                      ('skew', [(0.0, 0.0), (0.0, 0.0), (0.1, 0.1)]), ('blur_size', [0.0, 0.0, 0.0, 2.0, 5.0]), ('blur_angle', [0, 45, 90, 135]))
+
+    @classmethod
+    def _draw_specs(cls, lists, n):
+        """Independently shuffle every parameter list and take n values of each (reference :197-228), in the reference's key order."""
+        merged = dict(cls._DEFAULT_LISTS)
+        order = [k for k, _ in cls._DEFAULT_LISTS]
         for key, vals in lists.items():
             if key == 'num_aug':
                 continue
-            vals = list(vals) * ((n + len(vals) - 1) // len(vals))
+            if key not in merged:
+                order.append(key)
+            merged[key] = vals
+        picked = {}
+        for key in order:
+            vals = list(merged[key]) * ((n + len(merged[key]) - 1) // len(merged[key]))
             np.random.shuffle(vals)
             picked[key] = vals[:n]
         return [{k: v[i] for k, v in picked.items()} for i in range(n)]
@@ -171,38 +185,45 @@ class ImageAugmenter:
         fg['location'] = self._target_locations(p.num_aug, im_sz)
         bg = deepcopy(dict(p.bg_aug_params)) if 'bg_aug_params' in p else None
         N = p.num_aug - 1
-        images, labels, retries = [], [], -1
-        while len(images) < N:
+        # Reference quirk kept (augmenter.py:524-526): the spec generator is built from fg_aug_params / bg_aug_params, which carry no
+        # num_aug, so AugmentationParams2's default (20) rules and EVERY round draws 19 candidate specs; all good candidates are
+        # collected and, being more than N, shuffled and cropped to N (:538-544).  To keep the same draws without paying for 19
+        # composites, only the candidates' LABEL warps are formed first (one nearest-neighbour plane each, their pixel counts come
+        # back in one transfer -- that is all verify_frame looks at, :454-471); images are composed for the N survivors only.
+        NS = 19
+        cand, retries = [], -1
+        bg_box = (im_sz[1] / 2, im_sz[0] / 2, im_sz[1], im_sz[0])
+        while len(cand) < N:
             retries += 1
             if retries > self.max_retries:
                 raise RuntimeError('Augmentation failed: Not enough samples after %d retries.' % self.max_retries)
-            fg_specs = self._draw_specs(fg, N)
-            bg_specs = self._draw_specs(bg, N) if bg is not None else [None] * N
-            batch = []                                        # this round's candidates; their pixel counts come back in one transfer
+            fg_specs = self._draw_specs(fg, NS)
+            bg_specs = self._draw_specs(bg, NS) if bg is not None else [None] * NS
+            batch = []
             for fs, bs in zip(fg_specs, bg_specs):
-                canvas = background
-                if bs is not None:
-                    bs = dict(bs)
-                    bs.setdefault('location', bs.pop('tcenter', (0.5, 0.5)))
-                    T, G = self._transform(bs, (im_sz[1] / 2, im_sz[0] / 2, im_sz[1], im_sz[0]), im_sz, limit_scale=False)
-                    canvas = self._blur(warp_affine(canvas, T, im_sz).clamp(0, 255), G)
                 T, G = self._transform(fs, box, im_sz)
-                wt = self._blur(warp_affine(target, T, im_sz).clamp(0, 255), G)
-                wl = warp_affine(mask, T, im_sz, 'nearest')
-                alpha = wt[3:4] / 255
-                out = (wt[:3] * alpha + canvas * (1 - alpha)).to(torch.uint8)
-                lab = wl > 0
-                batch.append((out, lab, lab.sum()))
-            counts = torch.stack([c for _, _, c in batch]).tolist()
-            for (out, lab, _), cnt in zip(batch, counts):
+                lab = warp_affine(mask, T, im_sz, 'nearest') > 0
+                batch.append((fs, bs, T, G, lab, lab.sum()))
+            counts = torch.stack([b[-1] for b in batch]).tolist()
+            for (fs, bs, T, G, lab, _), cnt in zip(batch, counts):
                 if cnt >= p.min_px_count and (cnt < lab.numel() - p.min_px_count or no_background):
-                    images.append(out)
-                    labels.append(lab.to(torch.uint8))
-        if len(images) > N:
-            order = list(range(len(images)))
+                    cand.append((fs, bs, T, G, lab))
+        if len(cand) > N:
+            order = list(range(len(cand)))
             np.random.shuffle(order)
-            images = [images[i] for i in order[:N]]
-            labels = [labels[i] for i in order[:N]]
+            cand = [cand[i] for i in order[:N]]
+        images, labels = [], []
+        for fs, bs, T, G, lab in cand:
+            canvas = background
+            if bs is not None:
+                bs = dict(bs)
+                bs.setdefault('location', bs.get('tcenter', (0.5, 0.5)))
+                Tb, Gb = self._transform(bs, bg_box, im_sz, limit_scale=False)
+                canvas = self._blur(warp_affine(canvas, Tb, im_sz).clamp(0, 255), Gb)
+            wt = self._blur(warp_affine(target, T, im_sz).clamp(0, 255), G)
+            alpha = wt[3:4] / 255
+            images.append((wt[:3] * alpha + canvas * (1 - alpha)).to(torch.uint8))
+            labels.append(lab.to(torch.uint8))
         images.insert(0, im.to(torch.uint8))
         labels.insert(0, (lb.reshape(1, *im_sz) > 0).to(torch.uint8))
         return torch.stack(images), torch.stack(labels)

@@ -146,7 +146,7 @@ class GaussNewtonCG:
         """linearize + run_CG + apply_step of run_GN_iter in ONE launch; host-side bookkeeping as in run_CG."""
         if self._pbuf is None:
             dev = self._buf.device
-            self._pbuf = (torch.empty(256 * 864, device=dev), torch.empty(864, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
         slabs, qbuf, bar = self._pbuf
         dff = float(self.direction_forget_factor)
         if dff == 0:

@@ -127,7 +127,7 @@ int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const floa
  * literal recurrences (carried p / r_prev / rho as in frtm_cg_begin / _direction / _step_small), then w2 += step * delta.
  * The sample features X (N,c,h,w) are read once and stay in registers; Bm (N,9,h,w), cm (N,h,w), sw (N) are the memory's
  * low-resolution normal equations and sample weights.  vec: the solver's 6*n floats {b,r,r_prev,p,q,delta}, n = 9c;
- * state: float[8] as above; slabs: >= 256*864 floats, qbuf: >= 864 floats, bar: unsigned[4], zero-initialised once
+ * state: float[8] as above; slabs: >= 256*864 floats, qbuf: >= 864 + 256 floats, bar: unsigned[4], zero-initialised once (bar[3] != 0: workgroup 0 also writes phase time stamps to qbuf[864..])
  * (bar[2] != 0 afterwards = the run was ABORTED by its spin time-out -- x untouched, caller falls back and clears it).
  * frtm_cg_persistent_plan returns the number of workgroups (0 = shape not supported: w > 64, c > 96, N*ceil(h/10) > 240);
  * all of them must be resident at once: never run two of these launches concurrently on one GPU. */

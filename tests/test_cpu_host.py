@@ -364,6 +364,50 @@ def test_evaluate_dataset_reference_signature(tmp_path):
     assert np.isnan(r[1][0]) and np.isnan(r[1][-1]) and abs(r[1][2] - 0.8) < 1e-6 and r[2][3] == 1.0
 
 
+def test_augmentation_parameter_draws_pinned_to_the_reference():
+    """Fixture G11 (oracle/make_golden_aug.py): for the same numpy seed the augmenter draws the SAME target locations and spec
+    combinations as the reference's generate_target_locations / generate_specs2 (attribute order of AugmentationParams2, default
+    lists included), over two retry rounds, and builds the same affine transforms and blur kernels (get_transform).  The pixel
+    operations stay unpinned (no OpenCV / NPP here)."""
+    import json
+    from copy import deepcopy
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    p = Parameters(None).aug_params
+    aug = ImageAugmenter(p)
+    cases = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g11_augspecs.json')))
+    assert len(cases) == 3
+    for case in cases:
+        np.random.seed(case['seed'])
+        im_sz, box = tuple(case['im_size']), tuple(case['box'])
+        fg = deepcopy(dict(p.fg_aug_params))
+        fg['location'] = aug._target_locations(p.num_aug, im_sz)
+        assert np.allclose(np.array(fg['location'], dtype=float), np.array(case['locations'], dtype=float), atol=0)
+        for rnd in case['rounds']:
+            fs = aug._draw_specs(fg, 19)          # the reference's generator always draws 19 (default num_aug = 20), see augment_first_frame
+            bs = aug._draw_specs(deepcopy(dict(p.bg_aug_params)), 19)
+            assert len(fs) == len(bs) == len(rnd) == 19
+            for f, b, rec in zip(fs, bs, rnd):
+                for ours, ref in ((f, rec['fg']), (b, rec['bg'])):
+                    for k, v in ours.items():
+                        rv = ref[k]
+                        assert (list(v) == list(rv)) if isinstance(v, (tuple, list)) else (v == rv), (k, v, rv)
+                b = dict(b)
+                b.setdefault('location', b.get('tcenter', (0.5, 0.5)))
+                for spec, bx, lim, Tk, Kk in ((f, box, True, 'T_fg', 'K_fg'), (b, (im_sz[1] / 2, im_sz[0] / 2, im_sz[1], im_sz[0]), False, 'T_bg', 'K_bg')):
+                    T, G = aug._transform(spec, bx, im_sz, limit_scale=lim)
+                    assert np.allclose(T, np.array(rec[Tk]), rtol=1e-12, atol=1e-9)
+                    K = np.array(rec[Kk])
+                    if G is None:
+                        assert K.shape == (1, 1) and K[0, 0] == 1.0                     # the reference's "no blur" kernel
+                    else:
+                        _, half, qa, qb, qc = G
+                        r = np.arange(-half, half + 1, dtype=np.float64)
+                        xx, yy = np.meshgrid(r, r)
+                        g = np.exp(-0.5 * (qa * xx * xx + 2 * qb * xx * yy + qc * yy * yy))
+                        assert K.shape == g.shape and np.allclose(g / g.sum(), K, atol=1e-6)
+
+
 def test_file_datasets(tmp_path):
     """DAVIS / YouTube-VOS directory layouts -> FileSequence protocol (reference lib/datasets.py:16-158)."""
     from PIL import Image

@@ -406,7 +406,7 @@ def test_short_horizon_matches_oracle_tightly(golden):
 # ------------------------------------------------------------------------------------------ merge / tracker
 def test_merge_and_count(ops):
     g = gen(11)
-    for K in (2, 3, 6):
+    for K in (2, 3, 6, 16, 17, 40):           # > 16 planes: the array-free kernel (the reference has no object limit)
         m = torch.rand(K, 48, 70, generator=g)
         m[1, :5] = 0.0
         m[1, 5:10] = 1.0

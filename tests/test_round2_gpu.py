@@ -310,28 +310,60 @@ def test_persistent_cg_run_equals_the_multi_kernel_form(shape):
     N, c, h, w, Hh, Ww = shape
     from frtm_vos_amd import _hip as H
     assert H.lib().frtm_cg_persistent_plan(N, c, h, w, None, None) > 0
-    res = {}
-    for persistent in (False, True, True):
+    def trajectory(persistent, scale=1.0):
         mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 11, persistent)
+        mem.samples.mul_(scale)
         filt = []
         opt.run((10,))
         filt.append(wv.detach().clone())
         for t in range(3):
-            ft = torch.relu(torch.randn(1, c, h, w, generator=g)).to(DEV)
+            ft = torch.relu(torch.randn(1, c, h, w, generator=g)).to(DEV) * scale
             lab = torch.zeros(1, 1, Hh, Ww)
             lab[0, 0, 5 + 3 * t:Hh // 2, 7:Ww // 2 + 5 * t] = 0.9
             mem.update(ft, lab.to(DEV))
             opt.run((10,) if t != 1 else (5,))
             filt.append(wv.detach().clone())
-        assert not opt.poll_persistent_abort()
-        res.setdefault(persistent, []).append(torch.stack(filt))
-    a, b, b2 = res[False][0], res[True][0], res[True][1]
+        assert not opt.poll_persistent_abort() and opt._persistent_launched == False
+        return torch.stack(filt)
+
+    def rel(x, y):
+        return [float((x[k] - y[k]).abs().max() / x[k].abs().max()) for k in range(4)]
+    a, b, b2 = trajectory(False), trajectory(True), trajectory(True)
     assert torch.equal(b, b2)                                         # fixed summation order: bit-identical run to run
     assert bool(torch.isfinite(b).all()) and not torch.equal(b[0], b[1])
-    for k in range(4):
-        e = float((a[k] - b[k]).abs().max() / a[k].abs().max())
-        print('N=%d c=%d %dx%d  run %d: persistent vs multi-kernel %.2e' % (N, c, h, w, k, e))
-        assert e < 2e-4, (k, e)                                       # different summation orders through 10 CG steps
+    # The truncated CG trajectory is sensitive to rounding (tools/cg_sensitivity.py: the multi-kernel form against ITSELF with the
+    # features scaled by one ulp differs by up to 3e-2 after the 5-iteration run): the gate per run is 5 x that measured
+    # sensitivity (two perturbed runs), not less than 5e-4.  The tight, chaos-free check is the single-step test below.
+    n1, n2 = rel(a, trajectory(False, 1.0 + 2.0 ** -23)), rel(a, trajectory(False, 1.0 - 2.0 ** -24))
+    noise = [max(u, v) for u, v in zip(n1, n2)]
+    errs = rel(a, b)
+    print('N=%d c=%d %dx%d: persistent vs multi-kernel after runs 0..3: %s   (one-ulp sensitivity of the multi-kernel form: %s)' %
+          (N, c, h, w, ' '.join('%.2e' % e for e in errs), ' '.join('%.2e' % e for e in noise)))
+    for e, nz in zip(errs, noise):
+        assert e < max(5e-4, 5 * nz), (errs, noise)
+
+
+@pytest.mark.parametrize('shape', [(80, 96, 30, 54, 480, 854), (13, 96, 30, 54, 480, 854), (3, 16, 23, 64, 184, 512), (24, 40, 17, 31, 272, 496)])
+def test_persistent_cg_single_step_is_tight(shape):
+    """Before rounding chaos can build up: right-hand side b, first direction p, q = A p, the step delta and the residual after
+    ONE CG iteration agree to 2e-5 between the two forms, after a second run of two steps that carries p / r_prev / rho to 2e-4."""
+    N, c, h, w, Hh, Ww = shape
+    outs = []
+    for persistent in (False, True):
+        mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 5, persistent, dff=0.9 ** 75)      # finite forgetting: beta != 0 on run 2
+        opt.run((1,))
+        first = (opt._buf.clone(), opt._state[[0, 4]].clone(), wv.detach().clone())
+        opt.run((2,))
+        outs.append(first + (opt._buf.clone(), opt._state[[0, 4]].clone(), wv.detach().clone()))
+    for k, (x, y) in enumerate(zip(*outs)):
+        gate = 2e-5 if k < 3 else 2e-4        # one CG step from identical state | two more steps on top of it
+        if x.dim() == 2:                      # rows b, r, r_prev, p, q, delta
+            for row in range(6):
+                e = float((x[row] - y[row]).abs().max() / (x[row].abs().max() + 1e-30))
+                assert e < gate, (k, row, e)
+        else:
+            e = float((x - y).abs().max() / (x.abs().max() + 1e-30))
+            assert e < gate, (k, e)
 
 
 def test_persistent_cg_matches_reference_fixture_g3(golden, spread_gate):
