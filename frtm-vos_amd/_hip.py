@@ -67,6 +67,7 @@ SIGNATURES = {
     'frtm_cab_gate': (I, [P, P, I, P, P, P, P, I, I, P, P]),
     'frtm_project_tail': (I, [P, I, I, I, I, P, P, I, I, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
+    'frtm_warp_mask_batch': (I, [P, I, I, P, I, I, P, I, P, P]),
     'frtm_blur2d': (I, [P, I, I, I, P, I, I, P, P]),
     'frtm_blur_gauss2d': (I, [P, I, I, I, I, F, F, F, P, P]),
 }

@@ -69,6 +69,48 @@ extern "C" int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* 
   return FRTM_OK;
 }
 
+// The augmenter's candidate test (reference augmenter.py:454-471 verify_frame on every candidate of a round): nearest-neighbour
+// warps of ONE mask plane under up to 32 transforms in a single launch, written as uint8 {0,1} planes, with the number of set
+// pixels per candidate counted on the way (integer atomics).
+struct AffineSet { float m[32][6]; };
+__global__ __launch_bounds__(256) void k_warp_mask_batch(const float* __restrict__ src, int Hs, int Ws, unsigned char* __restrict__ dst, int Hd, int Wd,
+                                                          AffineSet inv, int* __restrict__ count) {
+  const int j = blockIdx.y;
+  const float a0 = inv.m[j][0], a1 = inv.m[j][1], a2 = inv.m[j][2], a3 = inv.m[j][3], a4 = inv.m[j][4], a5 = inv.m[j][5];
+  const size_t total = (size_t)Hd * Wd;
+  int c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % Wd), y = (int)(i / Wd);
+    const float sx = a0 * x + a1 * y + a2, sy = a3 * x + a4 * y + a5;
+    const int on = fetch(src, Hs, Ws, (int)floorf(sy + 0.5f), (int)floorf(sx + 0.5f)) > 0.f ? 1 : 0;
+    dst[(size_t)j * total + i] = (unsigned char)on;
+    c += on;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&count[j], c);
+}
+
+extern "C" int frtm_warp_mask_batch(const float* src, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* fwd6_host, int n,
+                                    int* count_dev, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(src && dst && fwd6_host && count_dev && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && n >= 1 && n <= 32, "frtm_warp_mask_batch: bad argument (1..32 transforms)");
+  AffineSet inv;
+  for (int j = 0; j < n; ++j) {
+    const float* f = fwd6_host + 6 * j;
+    const float a = f[0], b = f[1], tx = f[2], c = f[3], d = f[4], ty = f[5];
+    const float det = a * d - b * c;
+    FRTM_CHECK_ARG(det != 0.f, "frtm_warp_mask_batch: singular transform %d", j);
+    inv.m[j][0] = d / det;  inv.m[j][1] = -b / det; inv.m[j][2] = (b * ty - d * tx) / det;
+    inv.m[j][3] = -c / det; inv.m[j][4] = a / det;  inv.m[j][5] = (c * tx - a * ty) / det;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  FRTM_HIP(hipMemsetAsync(count_dev, 0, sizeof(int) * n, st));
+  dim3 g((unsigned)min(((size_t)Hd * Wd + 255) / 256, (size_t)512), n);
+  k_warp_mask_batch<<<g, 256, 0, st>>>(src, Hs, Ws, dst, Hd, Wd, inv, count_dev);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
 // Motion / Gaussian blur of the augmenter (reference augmenter.py:330-345 uses cv2.filter2D; here the same cross-correlation
 // with zero padding that F.conv2d(x, G, padding=k//2) computes, without going through MIOpen: its per-configuration "find"
 // step takes ~100 ms whenever a blur size shows up for the first time, in the middle of a timed sequence).

@@ -131,6 +131,18 @@ class ImageAugmenter:
         return n_px, (x0 + w / 2, y0 + h / 2, w, h)
 
     @staticmethod
+    def _warp_masks(mask, transforms, im_sz):
+        """Nearest-neighbour warps of one (1,H,W) mask under all `transforms` in one launch -> ((n,1,H,W) uint8 {0,1}, [pixel counts])."""
+        import ctypes
+        n = len(transforms)
+        src = mask.reshape(mask.shape[-2], mask.shape[-1]).float().contiguous()
+        dst = torch.empty(n, 1, int(im_sz[0]), int(im_sz[1]), dtype=torch.uint8, device=src.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=src.device)
+        m = (ctypes.c_float * (6 * n))(*[float(v) for T in transforms for v in np.asarray(T, dtype=np.float32)[:2].ravel()])
+        H.call('frtm_warp_mask_batch', H.ptr(src), src.shape[0], src.shape[1], dst.data_ptr(), dst.shape[-2], dst.shape[-1], m, n, cnt.data_ptr())
+        return dst, cnt.tolist()
+
+    @staticmethod
     def _fill_hole(image, hole, iters=None):
         """Pull-push hole filling: average the known pixels down a 2x pyramid until the hole closes, then push the
         coarse values back up into the unknown pixels.  O(log size) passes (the masked 3x3 diffusion it replaces needed
@@ -199,15 +211,11 @@ class ImageAugmenter:
                 raise RuntimeError('Augmentation failed: Not enough samples after %d retries.' % self.max_retries)
             fg_specs = self._draw_specs(fg, NS)
             bg_specs = self._draw_specs(bg, NS) if bg is not None else [None] * NS
-            batch = []
-            for fs, bs in zip(fg_specs, bg_specs):
-                T, G = self._transform(fs, box, im_sz)
-                lab = warp_affine(mask, T, im_sz, 'nearest') > 0
-                batch.append((fs, bs, T, G, lab, lab.sum()))
-            counts = torch.stack([b[-1] for b in batch]).tolist()
-            for (fs, bs, T, G, lab, _), cnt in zip(batch, counts):
-                if cnt >= p.min_px_count and (cnt < lab.numel() - p.min_px_count or no_background):
-                    cand.append((fs, bs, T, G, lab))
+            tg = [self._transform(fs, box, im_sz) for fs in fg_specs]
+            labs, counts = self._warp_masks(mask, [T for T, _ in tg], im_sz)          # one launch, one transfer
+            for j, (fs, bs, (T, G), cnt) in enumerate(zip(fg_specs, bg_specs, tg, counts)):
+                if cnt >= p.min_px_count and (cnt < labs[j].numel() - p.min_px_count or no_background):
+                    cand.append((fs, bs, T, G, labs[j]))
         if len(cand) > N:
             order = list(range(len(cand)))
             np.random.shuffle(order)
@@ -223,7 +231,7 @@ class ImageAugmenter:
             wt = self._blur(warp_affine(target, T, im_sz).clamp(0, 255), G)
             alpha = wt[3:4] / 255
             images.append((wt[:3] * alpha + canvas * (1 - alpha)).to(torch.uint8))
-            labels.append(lab.to(torch.uint8))
+            labels.append(lab)
         images.insert(0, im.to(torch.uint8))
         labels.insert(0, (lb.reshape(1, *im_sz) > 0).to(torch.uint8))
         return torch.stack(images), torch.stack(labels)

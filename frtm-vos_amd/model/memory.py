@@ -41,10 +41,8 @@ class Memory:
         self.labels_size = tuple(labels_size)
         self.normal_B = torch.zeros(capacity, 9, *self.grid, device=dev)
         self.normal_c = torch.zeros(capacity, *self.grid, device=dev)
-        self.keep_hires = keep_hires
+        self.keep_hires = False
         self._labels = self._pixel_weights = None
-        if keep_hires:
-            self._alloc_hires()
         self.pw_params = pixel_weighting
         self._capacity = capacity
         self.current_size = 0
@@ -55,6 +53,8 @@ class Memory:
         self._slot[:2].fill_(-1)
         self._have_prev = False
         self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
+        if keep_hires:
+            self._alloc_hires()
 
     def _alloc_hires(self):
         self._labels = torch.zeros(self._capacity, *self.labels_size, device=self.device)

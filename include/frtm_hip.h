@@ -284,6 +284,11 @@ int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream
  * ------------------------------------------------------------------------------------------ */
 int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd,
                      const float* fwd6_host, int mode, frtm_stream_t stream);
+/* n <= 32 nearest-neighbour warps of ONE mask plane (nonzero = set) in one launch: dst (n,Hd,Wd) uint8 {0,1}, count_dev int32[n] =
+ * set pixels per warp.  fwd6_host: n forward 2x3 transforms (host memory).  The augmenter's candidate test (reference
+ * model/augmenter.py:454-471 verify_frame looks at the candidates' label pixel counts only). */
+int frtm_warp_mask_batch(const float* src, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* fwd6_host, int n,
+                         int* count_dev, frtm_stream_t stream);
 
 /* dst[p,y,x] = sum_{i,j} G[i,j] * src[p, y+i-kh/2, x+j-kw/2], zero outside (the augmenter's blur, model/augmenter.py:330-345:
  * cv2.filter2D / F.conv2d(padding=k//2) semantics).  G: DEVICE float[kh*kw], odd kh, kw. */

@@ -152,7 +152,7 @@ def test_augmenter_transform_and_draws():
     locs = aug._target_locations(5, (480, 854))
     assert len(locs) == 5 and all(0 < x < 1 and 0 < y < 1 for x, y in locs)
     specs = aug._draw_specs(dict(aug.params.fg_aug_params), 4)
-    assert len(specs) == 4 and set(specs[0]) == {'rotation', 'fliplr', 'scale', 'skew', 'blur_size', 'blur_angle'}
+    assert len(specs) == 4 and set(specs[0]) == {'location', 'rotation', 'fliplr', 'scale', 'skew', 'blur_size', 'blur_angle'}     # (default location list included, like AugmentationParams2)
     spec = dict(location=(0.5, 0.5), rotation=0.0, fliplr=False, scale=1.0, skew=(0.0, 0.0), blur_size=0.0, blur_angle=0)
     Tm, G = aug._transform(spec, (100.0, 50.0, 40, 30), (480, 854))
     assert G is None and np.allclose(Tm @ np.array([100.0, 50.0, 1.0]), [427.0, 240.0, 1.0])    # target centre -> image centre

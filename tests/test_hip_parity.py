@@ -501,6 +501,37 @@ def test_warp_affine():
     assert (out[:, 2:, 3:] - src[:, :-2, :-3]).abs().max() < 1e-5 and float(out[:, :2].abs().max()) == 0
     flip = np.array([[-1, 0, 49], [0, 1, 0], [0, 0, 1]], dtype=np.float64)
     assert (warp_affine(src, flip, (40, 50), 'nearest') - src.flip(-1)).abs().max() < 1e-6
+    # the augmenter's batched candidate test: n mask warps + pixel counts in one launch == n single nearest-neighbour warps
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    mask = torch.zeros(1, 40, 50, device=DEV)
+    mask[0, 10:25, 12:30] = 1
+    Ts = [eye, shift, flip, np.array([[0.8, 0.3, -4.0], [-0.2, 1.1, 6.5], [0, 0, 1.0]]), np.array([[2.0, 0, -40.0], [0, 2.0, -30.0], [0, 0, 1]])]
+    labs, counts = ImageAugmenter._warp_masks(mask, Ts, (40, 50))
+    assert labs.shape == (5, 1, 40, 50) and labs.dtype == torch.uint8
+    for j, Tm in enumerate(Ts):
+        one = warp_affine(mask, Tm, (40, 50), 'nearest') > 0
+        assert torch.equal(labs[j].bool(), one) and counts[j] == int(one.sum())
+
+
+def test_augment_first_frame_stack():
+    """augment_first_frame: (K,3,H,W) / (K,1,H,W) uint8 stacks, sample 0 = the frame itself, every sample shows the object, and the
+    same seed gives the same stack (numpy's global RNG, seeded by the tracker per object)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params)
+    seq = SyntheticSequence('a', 1, (240, 432), 2, seed=3)
+    im, lb, ids = seq[0]
+    im, lb = im.to(DEV), (lb == 1).to(torch.uint8).to(DEV)
+    outs = []
+    for rep in range(2):
+        np.random.seed(0)
+        ims, labs = aug.augment_first_frame(im, lb)
+        assert ims.shape == (5, 3, 240, 432) and labs.shape == (5, 1, 240, 432) and ims.dtype == labs.dtype == torch.uint8
+        assert torch.equal(ims[0], im) and torch.equal(labs[0], lb)
+        assert all(int(labs[k].sum()) >= 1 for k in range(5)) and int(labs.max()) == 1
+        outs.append((ims.clone(), labs.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 # ------------------------------------------------------------------------------------------ refiner
