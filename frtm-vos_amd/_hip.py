@@ -39,6 +39,9 @@ SIGNATURES = {
     'frtm_cg_pq': (I, [P, P, P, I, P, P]),
     'frtm_cg_update': (I, [P, P, P, P, P, I, I, F, F, I, I, I, P, P, P]),
     'frtm_cg_step_small': (I, [P, I, I, F, P, P, P, P, P, I, F, I, I, I, I, P, P]),
+    'frtm_filter_scores2': (I, [P, P, P, P, I, I, I, I, P, P]),
+    'frtm_joint_mid': (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P]),
+    'frtm_joint_q_pq': (I, [P, I, F, P, I, I, I, F, P, P, F, P, P, P, P]),
     'frtm_cg_persistent_plan': (I, [I, I, I, I, P, P]),
     'frtm_cg_run_persistent': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P]),
     'frtm_vec_axpy': (I, [P, F, P, I, P]),

@@ -1,0 +1,252 @@
+// Fused glue of the JOINT first-frame problem (reference discriminator.py:165-176; variables project.weight (c,Cin,1,1) and
+// filter.weight (1,c,3,3)).  One operator application  q = J^T J p + lam^2 p  is
+//     P = X p1 (1x1 GEMM)  ->  s = P * w2 + Z * p2  ->  t = sw (B s)  ->  g2 = wgrad(Z, t),  D = igrad(t, w2)  ->  g1 = X^T D (GEMM)
+// and the fit runs ~55 of them per object, each as a chain of DEPENDENT launches whose per-kernel floor on MI355X is ~4.5-9 us
+// however little they do (round-2 kernel trace: 134 us of kernel time per CG iteration, only 60 of them in the two GEMMs).  The
+// lever is the number of launches.  This file merges the small ones:
+//   k_scores2_rows      s = X1 * f1 + X2 * f2                           (was: two score launches)
+//   k_joint_mid         stencil + filter weight-gradient slabs + input-gradient D   (was: three launches)
+//   k_joint_q_pq        q1 = g1 + lam1 p1, q2 = sum(slabs) + lam2 p2, <p,q> partials  (was: two slab reductions + k_cg_pq)
+// 13 -> 8 launches per CG iteration (plus the split-K epilogue of the second GEMM).
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+namespace {
+
+// ---- s = X1 * f1 + X2 * f2, row form (w <= 64): lane = x, a wave owns R rows of one sample and 1/NW of the channels of BOTH sources
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void k_scores2_rows(const float* __restrict__ X1, const float* __restrict__ f1, const float* __restrict__ X2,
+                                                           const float* __restrict__ f2, int C, int h, int w, float* __restrict__ out) {
+  __shared__ float red[NW][R][64];
+  const int rbs = (h + R - 1) / R;
+  const int n = blockIdx.x / rbs, y0 = (blockIdx.x - n * rbs) * R;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool xin = lane < w, has_l = lane > 0, has_r = lane + 1 < w;
+  const int cper = (C + NW - 1) / NW;
+  const int c0 = wid * cper, c1 = min(C, c0 + cper);
+  float acc[R];
+#pragma unroll
+  for (int o = 0; o < R; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int src = 0; src < 2; ++src) {
+    const float* Xn = (src ? X2 : X1) + (size_t)n * C * h * w;
+    const float* f = src ? f2 : f1;
+    for (int c = c0; c < c1; ++c) {
+      const float* Xc = Xn + (size_t)c * h * w;
+      const float* fc = f + c * 9;
+      float m[R + 2], l[R + 2], r[R + 2];
+#pragma unroll
+      for (int i = 0; i < R + 2; ++i) {
+        const int yy = y0 - 1 + i;
+        m[i] = (xin && (unsigned)yy < (unsigned)h) ? Xc[yy * w + lane] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < R + 2; ++i) {
+        const float up = __shfl_up(m[i], 1, 64), dn = __shfl_down(m[i], 1, 64);
+        l[i] = has_l ? up : 0.f;
+        r[i] = has_r ? dn : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          acc[o] += l[o + dy] * fc[dy * 3 + 0];
+          acc[o] += m[o + dy] * fc[dy * 3 + 1];
+          acc[o] += r[o + dy] * fc[dy * 3 + 2];
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < R; ++o) red[wid][o][lane] = acc[o];
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+    const int o = i >> 6, x = i & 63, yy = y0 + o;
+    if (x < w && yy < h) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; k += 4) sum += (red[k][o][x] + red[k + 1][o][x]) + (red[k + 2][o][x] + red[k + 3][o][x]);
+      out[(size_t)n * h * w + yy * w + x] = sum;
+    }
+  }
+}
+
+// ---- stencil + weight-gradient slabs + input gradient in one launch.
+// grid (gw + gi, N, parts): blocks x < gw do the weight gradient of 16 channels over pixel part z (like k_filter_wgrad), blocks
+// x >= gw (z == 0 only) write a slice of D[n, q, c] = sum_taps w2[c,tap] t[q - off(tap)] (pixel-major: the GEMM's K-major operand).
+// Every block first rebuilds t = sw[n] (B s [- c]) of ITS sample in LDS from the 9 + 1 low-resolution maps (L2 resident).
+constexpr int MID_CH = 4;
+__global__ __launch_bounds__(256) void k_joint_mid(const float* __restrict__ s, const float* __restrict__ Bm, const float* __restrict__ cm,
+                                                    const float* __restrict__ sw, const float* __restrict__ Z, const float* __restrict__ w2,
+                                                    int C, int h, int w, int gw, int gi, int parts, float* __restrict__ partial,
+                                                    float* __restrict__ D) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hw = h * w, wp = w + 2, pe = (h + 2) * wp;
+  const bool is_w = (int)blockIdx.x < gw;
+  if (!is_w && blockIdx.z != 0) return;
+  float* tl = lds;            // (h+2) x (w+2), zero border
+  float* sl = lds + pe;
+  for (int i = threadIdx.x; i < pe; i += 256) {
+    const int yy = i / wp - 1, xx = i % wp - 1;
+    sl[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) ? s[(size_t)n * hw + yy * w + xx] : 0.f;
+  }
+  __syncthreads();
+  {
+    const float* Bn = Bm + (size_t)n * 9 * hw;
+    const float swn = sw[n];
+    for (int i = threadIdx.x; i < pe; i += 256) {
+      const int yy = i / wp - 1, xx = i % wp - 1;
+      float v = 0.f;
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+        const int q = yy * w + xx;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) v += Bn[(size_t)d * hw + q] * sl[i + (d / 3 - 1) * wp + (d % 3 - 1)];
+        if (cm) v -= cm[(size_t)n * hw + q];
+        v *= swn;
+      }
+      tl[i] = v;
+    }
+  }
+  __syncthreads();
+  if (is_w) {
+    const int cbase = blockIdx.x * (4 * MID_CH) + wid * MID_CH;
+    if (cbase >= C) return;
+    const float* Xc[MID_CH];
+#pragma unroll
+    for (int k = 0; k < MID_CH; ++k) Xc[k] = Z + ((size_t)n * C + min(cbase + k, C - 1)) * hw;
+    float acc[MID_CH][9];
+#pragma unroll
+    for (int k = 0; k < MID_CH; ++k)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[k][j] = 0.f;
+    const int part = blockIdx.z, per = (hw + parts - 1) / parts;
+    const int p_lo = part * per, p_hi = min(hw, p_lo + per);
+    constexpr int UN = 4;
+    for (int q0 = p_lo + lane; q0 < p_hi; q0 += 64 * UN) {
+      float xv[UN][MID_CH];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = q0 + u * 64;
+#pragma unroll
+        for (int k = 0; k < MID_CH; ++k) xv[u][k] = q < p_hi ? Xc[k][q] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int q = min(q0 + u * 64, hw - 1);
+        const int qy = q / w, qx = q - qy * w;
+        float tv[9];
+        const float* tc = tl + (qy + 1) * wp + (qx + 1);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) tv[dy * 3 + dx] = tc[-(dy - 1) * wp - (dx - 1)];
+#pragma unroll
+        for (int k = 0; k < MID_CH; ++k)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) acc[k][j] += xv[u][k] * tv[j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MID_CH; ++k)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) acc[k][j] = wave_sum(acc[k][j]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < MID_CH; ++k)
+        if (cbase + k < C)
+#pragma unroll
+          for (int j = 0; j < 9; ++j) partial[(((size_t)n * parts + part) * C + cbase + k) * 9 + j] = acc[k][j];
+    }
+  } else {
+    const int total = C * hw;
+    for (int i = ((int)blockIdx.x - gw) * 256 + threadIdx.x; i < total; i += gi * 256) {
+      const int q = i / C, c = i - q * C;                       // pixel-major
+      const int qy = q / w, qx = q - qy * w;
+      const float* tc = tl + (qy + 1) * wp + (qx + 1);
+      const float* fc = w2 + c * 9;
+      float a = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a += fc[dy * 3 + dx] * tc[-(dy - 1) * wp - (dx - 1)];
+      D[(size_t)n * total + i] = a;
+    }
+  }
+}
+
+// ---- q = sign * [ g1 + lam1 p1 | sum_k slabs[k] + lam2 p2 ]  and (sign > 0) the per-block partials of <p,q> (and <p,r>)
+__global__ __launch_bounds__(256) void k_joint_q_pq(const float* __restrict__ g1, int n1, float lam1, const float* __restrict__ slabs, int nslab,
+                                                     int stride, int n2, float lam2, const float* __restrict__ p1, const float* __restrict__ p2, float sign,
+                                                     float* __restrict__ q, const float* __restrict__ r, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int n = n1 + n2;
+  float d = 0.f, e = 0.f;
+  // grid-stride over the elements: the n2 slab-sum elements (40 dependent-looking loads each) spread over all blocks instead of
+  // landing in the last one; eight independent accumulators keep eight loads in flight (fixed order of the final additions)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float pv = i < n1 ? p1[i] : p2[i - n1];
+    float v;
+    if (i < n1) {
+      v = g1[i] + lam1 * pv;
+    } else {
+      const float* sp = slabs + (i - n1);
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= nslab; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += sp[(size_t)(k + j) * stride];
+      }
+      for (; k < nslab; ++k) a[0] += sp[(size_t)k * stride];
+      v = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + lam2 * pv;
+    }
+    v *= sign;
+    q[i] = v;
+    d += pv * v;
+    if (r) e += pv * r[i];
+  }
+  if (partial) {
+    d = block_sum(d, red);
+    e = block_sum(e, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = d; partial[blockIdx.x * 2 + 1] = e; }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int frtm_filter_scores2(const float* X1, const float* f1, const float* X2, const float* f2, int N, int C, int h, int w, float* out,
+                        frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X1 && f1 && X2 && f2 && out && N > 0 && C > 0 && h > 0 && w > 0, "frtm_filter_scores2: bad argument");
+  if (w <= 64) {
+    k_scores2_rows<3, 16><<<ceil_div(h, 3) * N, 1024, 0, (hipStream_t)stream>>>(X1, f1, X2, f2, C, h, w, out);
+    FRTM_LAUNCH_CHECK();
+    return FRTM_OK;
+  }
+  int rc = frtm_filter_scores(X1, f1, N, C, h, w, out, 0, stream);          // wide maps: the two single-source launches
+  if (rc) return rc;
+  return frtm_filter_scores(X2, f2, N, C, h, w, out, 1, stream);
+}
+
+int frtm_joint_mid(const float* s, const float* Bm, const float* cm, const float* sw, const float* Z, const float* w2, int N, int C,
+                   int h, int w, int parts, float* partial, float* D, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(s && Bm && sw && Z && w2 && partial && D && N > 0 && C > 0 && parts >= 1 && parts <= 64, "frtm_joint_mid: bad argument");
+  const size_t lds = 2 * (size_t)(h + 2) * (w + 2) * sizeof(float);
+  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_joint_mid: feature grid %dx%d too large for the LDS tile", h, w);
+  const int gw = ceil_div(C, 4 * MID_CH);
+  const int gi = min(ceil_div(C * h * w, 256 * 4), 64);
+  dim3 g(gw + gi, N, parts);
+  k_joint_mid<<<g, 256, lds, (hipStream_t)stream>>>(s, Bm, cm, sw, Z, w2, C, h, w, gw, gi, parts, partial, D);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_joint_q_pq(const float* g1, int n1, float lam1, const float* slabs, int nslab, int stride, int n2, float lam2, const float* p1,
+                    const float* p2, float sign, float* q, const float* r, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(g1 && slabs && p1 && p2 && q && n1 > 0 && n2 > 0 && nslab > 0, "frtm_joint_q_pq: bad argument");
+  k_joint_q_pq<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(g1, n1, lam1, slabs, nslab, stride, n2, lam2, p1, p2, sign, q, r, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+}  // extern "C"

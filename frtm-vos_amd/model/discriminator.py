@@ -172,9 +172,12 @@ class DiscriminatorLoss(MinimizationProblem):
         ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
         ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
-        self._stencil(True)
-        self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
-        self._project_grad(self.filter_regs[0] ** 2, H.ptr(self.w1T), -1.0, H.ptr(b[:n1]))
+        if not self.fused:
+            self._stencil(True)
+            self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
+            self._project_grad(self.filter_regs[0] ** 2, H.ptr(self.w1T), -1.0, H.ptr(b[:n1]))
+            return
+        self._joint_tail(True, H.ptr(self.w1T), H.ptr(self.w2.data), -1.0, b, None, None)
 
     def apply_A(self, p, q):
         """q <- J^T J p + lam^2 p   (reference optimizer.py:155-157 via double backward)."""
@@ -184,6 +187,8 @@ class DiscriminatorLoss(MinimizationProblem):
             self._stencil(False)
             self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(p), 1.0, H.ptr(q))
             return
+        if self.fused:
+            return self.apply_A_pq(p, q, None, None)
         n1 = self.Cin * c
         p1, p2 = p[:n1], p[n1:]
         ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
@@ -192,6 +197,29 @@ class DiscriminatorLoss(MinimizationProblem):
         self._stencil(False)
         self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(p2), 1.0, H.ptr(q[n1:]))
         self._project_grad(self.filter_regs[0] ** 2, H.ptr(p1), 1.0, H.ptr(q[:n1]))
+
+    fused = True        # joint problem: merged glue kernels (csrc/joint_fit.hip), 8 instead of 13 launches per CG iteration
+
+    def apply_A_pq(self, p, q, r, partial):
+        """Joint problem: q <- J^T J p + lam^2 p and, if ``partial`` is given, the partial dot products <p,q> (and <p,r>) the
+        solver's next kernel sums -- the solver then skips its own frtm_cg_pq launch.  5 launches (+ the split-K epilogue)."""
+        N, c = self.N, self.c
+        n1 = self.Cin * c
+        p1, p2 = p[:n1], p[n1:]
+        ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
+        H.call('frtm_filter_scores2', H.ptr(self.P), H.ptr(self.w2.data), H.ptr(self.Z), H.ptr(p2), N, c, self.h, self.w, H.ptr(self.s))
+        self._joint_tail(False, H.ptr(p1), H.ptr(p2), 1.0, q, r, partial)
+
+    def _joint_tail(self, with_c, p1, p2, sign, q, r, partial):
+        """stencil + weight-gradient slabs + input gradient (one launch), the K = N*h*w GEMM, then q / <p,q> (one launch)."""
+        m, N, c = self.mem, self.N, self.c
+        n1 = self.Cin * c
+        parts = H.lib().frtm_filter_wgrad_parts(N, c)
+        H.call('frtm_joint_mid', H.ptr(self.s), H.ptr(m.normal_B), H.ptr(m.normal_c) if with_c else None, H.ptr(m.weights), H.ptr(self.Z),
+               H.ptr(self.w2.data), N, c, self.h, self.w, parts, H.ptr(self.partial), H.ptr(self.D))
+        ops.conv2d(self.Xt, self.D, c, out=self.g1, out_transposed=True, shape=(1, N * self.hw, 1, self.Cin), w_pitch=c, ws=self.ws)
+        H.call('frtm_joint_q_pq', H.ptr(self.g1), n1, self.filter_regs[0] ** 2, H.ptr(self.partial), N * parts, c * 9, c * 9,
+               self.filter_regs[1] ** 2, p1, p2, sign, H.ptr(q), None if r is None else H.ptr(r), None if partial is None else H.ptr(partial))
 
     def apply_step(self, x, step, delta):
         """x += step * delta  (reference optimizer.py:89-90), un-transposing the projection part."""

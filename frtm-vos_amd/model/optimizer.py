@@ -213,8 +213,12 @@ class GaussNewtonCG:
             H.call('frtm_cg_direction', r, p, n1, n2, im1, im2, int(self._has_p), apply_dff if ii == 0 else 0, fr,
                    dff if dff != 0 else 1.0, st, part)
             self._has_p = True
-            pr.apply_A(self._buf[3], self._buf[4])
-            H.call('frtm_cg_pq', p, q, None if self.standard_alpha else r, n1 + n2, part)
+            if getattr(pr, 'joint', False) and getattr(pr, 'fused', False):
+                # the problem's last kernel also leaves the partials of <p,q> (and <p,r>): no separate frtm_cg_pq launch
+                pr.apply_A_pq(self._buf[3], self._buf[4], None if self.standard_alpha else self._buf[1], self._partial)
+            else:
+                pr.apply_A(self._buf[3], self._buf[4])
+                H.call('frtm_cg_pq', p, q, None if self.standard_alpha else r, n1 + n2, part)
             H.call('frtm_cg_update', dx, r, r_prev, p, q, n1, n2, im1, im2, int(ii == 0), int(ii == num_iter - 1),
                    int(self.standard_alpha), st, part)
         return pr.views(self._buf[5]), []

@@ -122,6 +122,21 @@ int frtm_cg_pq(const float* p, const float* q, const float* r, int n, float* par
 int frtm_cg_update(float* x, float* r, float* r_prev, const float* p, const float* q, int n1, int n2,
                    float invM1, float invM2, int first, int last, int standard_alpha, float* state,
                    float* partial, frtm_stream_t stream);
+/* Fused glue of the JOINT first-frame problem (reference discriminator.py:165-176): fewer dependent launches per operator
+ * application (csrc/joint_fit.hip).
+ *   frtm_filter_scores2   out (N,1,h,w) = X1 * f1 + X2 * f2   (two 3x3 score passes in one launch; X (N,C,h,w), f (1,C,3,3))
+ *   frtm_joint_mid        t = sw (B s [- cm]) formed per block in LDS, then BOTH the filter weight-gradient slabs of Z
+ *                         (partial: (N*parts, C*9), like frtm_filter_wgrad) and the input gradient D (N,h*w,C) pixel-major
+ *                         (like frtm_filter_igrad(..., pix_major=1)); cm may be NULL
+ *   frtm_joint_q_pq       q[:n1] = sign (g1 + lam1 p1), q[n1:] = sign (sum_k slabs[k*stride + i] + lam2 p2); if partial != NULL
+ *                         also the FRTM_CG_BLOCKS partials of <p,q> (and <p,r> when r != NULL) in frtm_cg_pq's layout */
+int frtm_filter_scores2(const float* X1, const float* f1, const float* X2, const float* f2, int N, int C, int h, int w, float* out,
+                        frtm_stream_t stream);
+int frtm_joint_mid(const float* s, const float* Bm, const float* cm, const float* sw, const float* Z, const float* w2, int N, int C,
+                   int h, int w, int parts, float* partial, float* D, frtm_stream_t stream);
+int frtm_joint_q_pq(const float* g1, int n1, float lam1, const float* slabs, int nslab, int stride, int n2, float lam2, const float* p1,
+                    const float* p2, float sign, float* q, const float* r, float* partial, frtm_stream_t stream);
+
 /* One whole Gauss-Newton iteration of the FILTER problem (reference optimizer.py:77-153 on the problem of
  * discriminator.py:187-196) as ONE persistent launch: right-hand side b = -(J^T f(w2) + lam2 w2), `iters` CG steps with the
  * literal recurrences (carried p / r_prev / rho as in frtm_cg_begin / _direction / _step_small), then w2 += step * delta.

@@ -13,7 +13,7 @@ import sys
 tag, prof, fetch, write, bench = sys.argv[1:6]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, 'profiles')
-cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8 --trunk-batch 16 --trunk-lanes 2)'
+cmd = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --no-init-sweep --no-cg-roofline   (defaults: --gpus 1 --steps 64 --warmup 8 --trunk-batch 16 --trunk-lanes 2)'
 
 rows = list(csv.DictReader(open(os.path.join(prof, 'prof_kernel_stats.csv'))))
 with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w') as f:
