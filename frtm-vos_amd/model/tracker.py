@@ -160,9 +160,15 @@ class Tracker(nn.Module):
         self.release_targets()
         torch.cuda.synchronize()
 
-    def run_sequence(self, sequence, speedrun=False):
-        """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included."""
+    def run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
+        """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included.
+
+        ``ytvos_merge``: label decoding of the reference's YouTube-VOS validation fork instead (ytvos_validation/tracker.py:84-116):
+        the per-object masks BEFORE the per-frame merge are kept for the whole sequence, the ground truth is re-inserted on every
+        object's first frame, and ONE merge over the sequence (background = min(1 - p), soft-max of p / (1 - p), arg-max) gives the
+        labels.  Tracking itself (scores, refinement, per-frame merge for the memory updates) is unchanged."""
         self.eval()
+        self._raw_log = [] if ytvos_merge else None
         self.object_ids = sequence.obj_ids
         self.current_frame = 0
         self.release_targets()
@@ -218,9 +224,28 @@ class Tracker(nn.Module):
                 self.current_frame += 1
             N += 1
         flush()
+        if ytvos_merge:
+            outputs = self._ytvos_labels(sequence, outputs, object_ids)
         torch.cuda.synchronize()
         T = time() - t0
+        self._raw_log = None
         return outputs, N / T
+
+    def _ytvos_labels(self, sequence, outputs, object_ids):
+        """Sequence-level decoding (ytvos_validation/tracker.py:103-116).  self._raw_log holds, per tracked frame, the masks before
+        the merge: plane t.index = sigmoid(refiner) of an active object (already multiplied by (1 - start mask) of objects starting
+        on that frame, :148-151), or the start mask itself on an object's first frame (= the re-inserted ground truth, :107-110)."""
+        n = len(sequence.obj_ids)
+        T_, (Hh, Ww) = len(outputs), outputs[0].shape[-2:]
+        planes = torch.zeros(T_, n + 1, Hh, Ww, device=self.device)
+        index = {t.object_id: t.index for t in self.targets.values()}
+        for t_idx, raw in self._raw_log:
+            planes[t_idx, :raw.shape[0]] = raw                          # planes of objects that do not exist yet stay 0
+        for oid, t in self.targets.items():                             # objects whose first frame was not tracked (frame 0)
+            planes[t.start_frame, index[oid]] = t.start_mask.reshape(Hh, Ww).float()
+        ops.merge_masks_(planes)                                        # one launch over all frames: planes[:, 0] = background
+        labels = object_ids[planes.argmax(dim=1, keepdim=True)]
+        return [labels[t] for t in range(T_)]
 
     @staticmethod
     def _extends(prev, nxt):
@@ -401,6 +426,9 @@ class Tracker(nn.Module):
             for t2 in self.targets.values():
                 if t2 is not t1 and t2.start_frame == self.current_frame:
                     masks[0, t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+        if getattr(self, '_raw_log', None) is not None:
+            for f in range(W):
+                self._raw_log.append((self.current_frame + f, masks[f].clone()))
         ops.merge_masks_(masks)                                                              # :214-221, all frames of the window
         if active and self.disc_params.update_filters:
             K = masks.shape[1]

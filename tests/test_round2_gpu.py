@@ -439,3 +439,94 @@ def test_fused_joint_operator_equals_the_unfused_chain(golden):
             # b and A p: same arithmetic, other summation order in the slab sums.  After the whole 45-iteration fit the two trajectories
             # have drifted like any two fp32 evaluations of this solver do (tools/cg_sensitivity.py)
             assert e < (1e-5 if k < 2 else 5e-2), (cin, name, e)
+
+
+def test_ytvos_sequence_level_merge_with_ground_truth_reinsertion():
+    """run_sequence(..., ytvos_merge=True): decoding of the reference's YouTube-VOS fork (ytvos_validation/tracker.py:84-116) --
+    raw per-object masks over the whole sequence, ground truth re-inserted on each object's first frame, one merge over the
+    sequence -- against a plain torch restatement of merge_segmentations on the same raw masks."""
+    import torch.nn.functional as F
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    size = (192, 256)
+    seq = SyntheticSequence('yt', 14, size, 3, seed=12, late_object_at=6)
+    seq.preload(DEV)
+    trk = _tracker(memory_size=8, init_iters=(5, 10, 10), update_iters=(5,))
+    captured = {}
+    orig = trk._ytvos_labels
+
+    def spy(sequence, outputs, object_ids):
+        captured['raw'] = [(t, m.clone()) for t, m in trk._raw_log]
+        captured['targets'] = {oid: (t.index, t.start_frame, t.start_mask.clone()) for oid, t in trk.targets.items()}
+        return orig(sequence, outputs, object_ids)
+    trk._ytvos_labels = spy
+    torch.manual_seed(3)
+    labels, fps = trk.run_sequence(seq, ytvos_merge=True)
+    assert len(labels) == 14 and labels[0].shape == (1, *size) and labels[0].dtype == torch.uint8
+    lab = torch.stack([l.reshape(size) for l in labels]).cpu()
+    # restatement: fg (n, T, H, W) -> bg = min(1 - fg), softmax(p / (1 - p)) over {bg, objects}, arg-max -> ids
+    fg = torch.zeros(3, 14, *size)
+    for t, m in captured['raw']:
+        fg[:m.shape[0] - 1, t] = m[1:].cpu()
+    for oid, (idx, f0, sm) in captured['targets'].items():
+        fg[idx - 1, f0] = sm.reshape(size).float().cpu()
+    fgc = fg.clamp(1e-7, 1 - 1e-7)
+    p = torch.cat(((1 - fgc).min(dim=0, keepdim=True)[0], fgc))
+    expect = torch.tensor([0, 1, 2, 3], dtype=torch.uint8)[F.softmax(p / (1 - p), dim=0).argmax(dim=0)]
+    assert float((lab == expect).float().mean()) > 0.9999
+    # ground truth re-inserted where known: on an object's first frame its label covers its start mask
+    for oid, (idx, f0, sm) in captured['targets'].items():
+        sm = sm.reshape(size).cpu() > 0
+        assert float((lab[f0][sm] == oid).float().mean()) > 0.99, (oid, f0)
+    assert captured['targets'][3][1] == 6 and int((lab[:6] == 3).sum()) == 0         # the late object does not appear before frame 6
+    # and the per-frame decoding of the main tracker is a different rule: same tracker state, other labels on some pixels
+    torch.manual_seed(3)
+    plain, _ = _tracker(memory_size=8, init_iters=(5, 10, 10), update_iters=(5,)).run_sequence(seq)
+    agree = float((torch.stack([l.reshape(size) for l in plain]).cpu() == lab).float().mean())
+    assert 0.9 < agree <= 1.0
+
+
+def test_training_model_target_model_cache(tmp_path):
+    """TrainerModel (reference model/training_model.py): target models fitted on the HIP path and cached as
+    <cache>/<sequence>/<frame0>.<object>.<layer>.pth; a second pass over the same samples loads them (cache hits) and scores
+    identically; the refiner trains through its PyTorch definition (finite BCE loss, gradients on the refiner only)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    from frtm_vos_amd.model.training_model import SampleSpec, TargetModelCache, TrainerModel
+    P = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18')
+    P.disc_params.update(memory_size=20, init_iters=(3, 5), update_iters=(3,), c_channels=32)
+    ext = ResnetFeatureExtractor('resnet18').to(DEV)
+    chans = {L: n for L, n in ext.get_out_channels().items() if L in P.refnet_params.layers}
+    torch.manual_seed(1)
+    refiner = SegNetwork(1, 64, chans, True).to(DEV)
+
+    def model():
+        return TrainerModel(ImageAugmenter(P.aug_params), ext, P.disc_params, refiner, batch_size=2,
+                            tmodel_cache=dict(path=tmp_path / 'resnet18-c32', enable=True, read_only=False), device=DEV)
+    seqs = [SyntheticSequence('s%d' % k, 3, (128, 160), 1, seed=30 + k) for k in range(2)]
+    images = [torch.stack([s.images[t] for s in seqs]) for t in range(3)]
+    labels = [torch.stack([(s.gt[t] == 1).to(torch.uint8) for s in seqs]) for t in range(3)]
+    meta = [SampleSpec('s%d' % k, 1, ['00000', '00001', '00002'], 0).encoded() for k in range(2)]
+    np_seed = __import__('numpy').random.seed
+    m1 = model()
+    np_seed(0)
+    st1 = m1(images, labels, meta)
+    assert st1['stats/fcache_hits'] == 0 and st1['stats/loss'] > 0 and st1['stats/loss'] == st1['stats/loss']
+    f = m1.tmodel_filename(SampleSpec('s1', 1, None, 0), 'layer4')
+    assert f == tmp_path / 'resnet18-c32' / 's1' / '00000.1.layer4.pth' and f.exists()
+    sd = torch.load(f)
+    assert set(sd) == {'project.weight', 'filter.weight'} and sd['project.weight'].shape == (32, 256, 1, 1)
+    grads = [p.grad for p in refiner.parameters() if p.grad is not None]
+    assert grads and all(bool(torch.isfinite(g).all()) for g in grads)
+    m2 = model()
+    st2 = m2(images, labels, meta)
+    assert st2['stats/fcache_hits'] == 2
+    for a, b in zip(m1.tmodels, m2.tmodels):
+        assert torch.equal(a.get_state_dict()['filter.weight'], b.get_state_dict()['filter.weight'])
+    assert abs(st1['stats/loss'] - st2['stats/loss']) < 1e-5 * max(1.0, st1['stats/loss'])
+    assert set(m1.state_dict()) == {'refiner.' + k for k in refiner.state_dict()}
+    ro = TargetModelCache(tmp_path / 'elsewhere', enable=True, read_only=True)
+    assert ro.load(SampleSpec('s0', 1, None, 0), 'layer4') is None
