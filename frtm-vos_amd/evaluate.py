@@ -93,8 +93,7 @@ def main(argv=None):
     from pathlib import Path
 
     from .lib.datasets import DAVISDataset, YouTubeVOSDataset
-    from .lib.evaluation import evaluate_sequence
-    from .lib.davis import db_statistics
+    from .lib.evaluation import evaluate_dataset
     from .shard import aggregate_throughput, shard_indices, write_rank_report
 
     ap = argparse.ArgumentParser(description='Evaluate FRTM on a validation dataset (MI355X-native hot path)')
@@ -106,15 +105,22 @@ def main(argv=None):
     ap.add_argument('--yt2018', default=os.environ.get('YTVOS_ROOT', '/path/to/ytvos2018'))
     ap.add_argument('--jjval-list', default=None, help="id list of the reference's jjval split (lib/ytvos_jjvalid.txt upstream)")
     ap.add_argument('--output', default='results')
+    ap.add_argument('--no-eval', action='store_true', help='skip the J / F evaluation after the run (reference evaluate.py:159-165 always evaluates)')
+    ap.add_argument('--ytvos-merge', action='store_true', help="decode like the reference's YouTube-VOS fork (sequence-level merge, ground truth re-inserted)")
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL); gloo for tests')
+    ap.add_argument('--share-gpu', action='store_true', help='tests only: every rank uses cuda:0')
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
         import torch.distributed as dist
-        local = int(os.environ.get('LOCAL_RANK', 0))
+        local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', 0))
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(args.dist_backend)
         args.dev = 'cuda:%d' % local
     weights = torch.load(args.model, map_location='cpu')['model']
     if args.dset.startswith('dv'):
@@ -142,13 +148,31 @@ def main(argv=None):
                 seq.release()
     import time
     t0 = time.time()
+    if args.ytvos_merge:
+        run_sequence = tracker.run_sequence
+        tracker.run_sequence = lambda seq, speedrun=False: run_sequence(seq, speedrun, ytvos_merge=True)
+    if args.share_gpu:
+        from .model.discriminator import Discriminator
+        Discriminator.persistent_cg = False           # ranks on one GPU would starve each other's resident launches
     tracker.run_dataset(_Shard(), out_path, speedrun=args.dset == 'dv2016val')
     wall = time.time() - t0
     write_rank_report(out_path, rank, world, dict(frames=_Shard.frames, seconds=wall, fps=_Shard.frames / max(wall, 1e-9),
                                                   dataset=dset.name, device=args.dev))
-    fps, total, wall = aggregate_throughput(_Shard.frames, wall, device=args.dev if world > 1 else 'cpu')
+    red_dev = args.dev if (world > 1 and args.dist_backend == 'nccl') else 'cpu'
+    fps, total, wall = aggregate_throughput(_Shard.frames, wall, device=red_dev)       # (a collective: also the closing barrier)
     if rank == 0:
         print('%d frames on %d GPU(s): %.1f frames/s incl. decoding and PNG writing' % (total, world, fps))
+        if not args.no_eval and args.dset.startswith('dv'):
+            # every rank's PNGs are on disk: J and F like the reference's driver (evaluate.py:159-165)
+            dset.all_annotations = True
+            for measure in ('J', 'F'):
+                print()
+                print('Computing %s-scores' % measure)
+                evaluate_dataset(dset, out_path, measure=measure)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
