@@ -38,6 +38,9 @@ class MinimizationProblem:
     def ip_input(self, a, b):
         return sum(a.view(-1) @ b.view(-1))
 
+    def initialize(self):
+        pass
+
     def M1(self, x):
         return x
 
@@ -46,10 +49,12 @@ class GaussNewtonCG:
 
     def __init__(self, problem: MinimizationProblem, variable: TensorList, cg_eps=0.0, fletcher_reeves=True,
                  standard_alpha=True, direction_forget_factor=0, step_alpha=1.0):
-        for need in ('vector_layout', 'linearize', 'apply_A', 'apply_step'):
-            if not hasattr(problem, need):
-                raise TypeError('GaussNewtonCG needs a problem with explicit HIP operators (missing %s); '
-                                'see MinimizationProblem' % need)
+        # Problems with explicit operators (the target model's: DiscriminatorLoss) run on the fused HIP kernels.  Any other
+        # MinimizationProblem -- user code written against the reference's protocol (__call__ / ip_input / M1, optimizer.py:5-15)
+        # -- takes the generic form below: J p and J^T r through torch.autograd, exactly as the reference does it.  That form is
+        # framework arithmetic on whatever device the problem's tensors live on; it is not the product's hot path.
+        self._generic = not all(hasattr(problem, need) for need in ('vector_layout', 'linearize', 'apply_A', 'apply_step'))
+        self._g = dict(p=None, rho=torch.ones(1), r_prev=None)
         self.fletcher_reeves = fletcher_reeves
         self.standard_alpha = standard_alpha
         self.direction_forget_factor = direction_forget_factor
@@ -84,18 +89,26 @@ class GaussNewtonCG:
 
     @property
     def b(self):
+        if self._generic:
+            return self._g.get('b')
         return None if self._buf is None else self.problem.views(self._buf[0])
 
     @property
     def p(self):
+        if self._generic:
+            return self._g['p']
         return self.problem.views(self._buf[3]) if self._has_p else None
 
     @property
     def r_prev(self):
+        if self._generic:
+            return self._g['r_prev']
         return self.problem.views(self._buf[2]) if self._has_p else None
 
     @property
     def rho(self):
+        if self._generic:
+            return self._g['rho']
         return torch.ones(1) if self._buf is None else self._state[0:1]
 
     def clear_temp(self):
@@ -113,6 +126,7 @@ class GaussNewtonCG:
         return self
 
     def reset_state(self):
+        self._g.update(p=None, rho=torch.ones(1), r_prev=None)
         self._has_p = False
         if self._buf is not None:
             self._state[:1].fill_(1.0)
@@ -126,6 +140,10 @@ class GaussNewtonCG:
             num_cg_iter = [num_cg_iter] * num_gn_iter
         if len(num_cg_iter) == 0:
             return None
+        if self._generic:
+            for n in num_cg_iter:
+                self._generic_GN_iter(n)
+            return self.external_losses, self.internal_losses, self.residuals
         self._alloc()
         for n in num_cg_iter:
             self.run_GN_iter(n)
@@ -223,8 +241,67 @@ class GaussNewtonCG:
                    int(self.standard_alpha), st, part)
         return pr.views(self._buf[5]), []
 
+    # ---- generic form: any MinimizationProblem, operators through autograd (reference optimizer.py:77-157) -------------------
+    def _generic_GN_iter(self, num_cg_iter):
+        x = self.x
+        for v in x:
+            v.requires_grad_(True)
+        with torch.enable_grad():
+            f0 = self.problem(x)                                                  # residual list
+            g = TensorList([f.detach().clone().requires_grad_(True) for f in f0])
+            jt_g = TensorList(torch.autograd.grad(list(f0), list(x), list(g), create_graph=True))     # J^T g, differentiable in g
+        self._lin = (f0, g, jt_g)
+        self._g['b'] = b = TensorList([-t.detach() for t in jt_g])
+        if num_cg_iter > 0:
+            delta = self._generic_CG(num_cg_iter, b)
+            for v in x:
+                v.detach_()
+            for v, d in zip(x, delta):
+                v.add_(d, alpha=float(self.step_alpha))
+        else:
+            for v in x:
+                v.detach_()
+        self.step_alpha = min(self.step_alpha * 1.2, 1.0)
+        self._lin = None
+
+    def _generic_A(self, p):
+        f0, g, jt_g = self._lin
+        with torch.enable_grad():
+            jp = torch.autograd.grad(list(jt_g), list(g), list(p), retain_graph=True)         # J p   (double backward, :156)
+            return TensorList(torch.autograd.grad(list(f0), list(self.x), jp, retain_graph=True))   # J^T J p (incl. lam^2 p)
+
+    def _generic_CG(self, num_iter, b):
+        st, pr = self._g, self.problem
+        dff = self.direction_forget_factor
+        if dff == 0:
+            self.reset_state()
+        elif st['p'] is not None:
+            st['rho'] = st['rho'] / dff                                           # may overflow to inf: beta = 0 (literal)
+        r = TensorList([t.clone() for t in b])
+        x = None
+        for ii in range(num_iter):
+            z = pr.M1(r)
+            rho1, st['rho'] = st['rho'], pr.ip_input(r, z)
+            if st['p'] is None:
+                st['p'] = TensorList([t.clone() for t in z])
+            else:
+                beta = st['rho'] / rho1 if self.fletcher_reeves else (st['rho'] - pr.ip_input(st['r_prev'], z)) / rho1
+                beta = beta.clamp(0)
+                st['p'] = z + st['p'] * beta
+            q = self._generic_A(st['p'])
+            pq = pr.ip_input(st['p'], q)
+            alpha = st['rho'] / pq if self.standard_alpha else pr.ip_input(st['p'], r) / pq
+            if not self.fletcher_reeves:
+                st['r_prev'] = TensorList([t.clone() for t in r])
+            x = st['p'] * alpha if x is None else x + st['p'] * alpha
+            if ii < num_iter - 1:
+                r = r - q * alpha
+        return x
+
     def A(self, x):
         """q = J^T J x + lam^2 x for a TensorList / flat vector in the problem's layout."""
+        if self._generic:
+            return self._generic_A(x)
         self._alloc()
         q = torch.empty(self._n, device=self._buf.device)
         flat = x if torch.is_tensor(x) else torch.cat([t.reshape(-1) for t in x])

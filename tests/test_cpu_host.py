@@ -177,9 +177,6 @@ def test_synthetic_sequence_protocol():
 
 def test_solver_argument_errors():
     from frtm_vos_amd.model.optimizer import GaussNewtonCG, MinimizationProblem
-    with pytest.raises(TypeError):
-        GaussNewtonCG(MinimizationProblem(), [torch.zeros(1)])
-
     class P(MinimizationProblem):
         def initialize(self): pass
         def vector_layout(self): return 1, 0, 1.0, 1.0
@@ -191,6 +188,60 @@ def test_solver_argument_errors():
     with pytest.raises(ValueError):
         opt.run(3)                       # reference optimizer.py:59-62
     assert opt.run([]) is None           # zero GN iterations -> None (optimizer.py:65-66)
+
+
+def test_generic_problems_run_through_autograd_like_the_reference(golden):
+    """A MinimizationProblem WITHOUT explicit operators (user code against the reference's protocol: __call__ / ip_input / M1)
+    is solved like the reference does it -- J p and J^T r through autograd double-backward, literal CG recurrences, carried state.
+    Here: the filter problem of fixture G3 written as a plain torch problem on CPU tensors; the result must equal the
+    reference's recorded filters (b, A p, run((10,)), three insert + run cycles with direction forgetting)."""
+    import torch.nn.functional as F
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG, MinimizationProblem
+    from oracle import cpu_ref as O
+    T = torch.from_numpy
+    g = golden('g3_update')
+    c, h, w, H, W, cap = [int(v) for v in g['dims']]
+
+    class Plain(MinimizationProblem):
+        """reference discriminator.py:11-64 in ten lines of torch"""
+        def __init__(self, mem):
+            self.mem = mem
+        def initialize(self):
+            a = self.mem.weights > 0
+            self.x, self.y = self.mem.samples[a], self.mem.labels[a]
+            self.wgt = self.mem.pixel_weights[a] * self.mem.weights[a].sqrt().view(-1, 1, 1, 1)
+        def __call__(self, params):
+            s = F.interpolate(F.conv2d(self.x, params[0], padding=1), (H, W), mode='bilinear', align_corners=False)
+            return TensorList([self.wgt * (s - self.y), 1e-2 * params[0]])
+        def ip_input(self, a, b):
+            return sum(u.reshape(-1) @ v.reshape(-1) for u, v in zip(a, b))
+        def M1(self, x):
+            return TensorList([t / 1e-2 for t in x])
+    for tag in ('a', 'b'):
+        mem = O.MemoryRef(cap, (c, h, w), (1, H, W), 0.1)
+        mem.samples[:], mem.labels[:], mem.pixel_weights[:], mem.weights[:] = (T(g[tag + '_samples0']), T(g[tag + '_labels0']),
+                                                                              T(g[tag + '_pw0']), T(g[tag + '_sw0']))
+        mem.current_size = int((mem.weights > 0).sum())
+        mem.prev_ind = 6
+        wv = T(g[tag + '_w0']).clone()
+        opt = GaussNewtonCG(Plain(mem), TensorList([wv]), fletcher_reeves=False, standard_alpha=True,
+                            direction_forget_factor=0.9 ** int(g[tag + '_rate']))
+        assert opt._generic and opt.p is None and float(opt.rho) == 1.0
+        opt.run((10,))
+        assert float((opt.b[0] - T(g[tag + '_b'])).abs().max() / T(g[tag + '_b']).abs().max()) < 1e-6    # same autograd graph as the reference
+        assert float((wv - T(g[tag + '_filters'][0])).abs().max() / T(g[tag + '_filters'][0]).abs().max()) < 1e-4
+        for t in range(3):
+            mem.update(T(g[tag + '_ins_x'][t]), T(g[tag + '_ins_y'][t]), T(g[tag + '_ins_pw'][t]))
+            opt.run((10,))
+            ref = T(g[tag + '_filters'][t + 1])
+            assert float((wv - ref).abs().max() / ref.abs().max()) < 5e-4, (tag, t)
+        assert opt.p is not None and opt.r_prev is not None and not wv.requires_grad
+    # ValueError / None conventions hold in the generic form too
+    opt2 = GaussNewtonCG(Plain(mem), TensorList([wv]))
+    with pytest.raises(ValueError):
+        opt2.run(3)
+    assert opt2.run([]) is None
 
 
 _WORKER = r'''
