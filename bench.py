@@ -187,7 +187,7 @@ def tracking_quality(outputs, seq):
 # CPU baseline: the oracle on the host cores, SAME sequence / objects / schedule / refiner weights
 # ------------------------------------------------------------------------------------------------------------------
 
-def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames):
+def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames, gpu_labels=None):
     """oracle/cpu_ref.py ('port') on the host cores: the first 1 + n_frames frames of the SAME synthetic sequence the GPU leg
     timed (same objects, iteration schedule, trunk and refiner weights).  Augmentation: the oracle has no augmenter (OpenCV /
     NPP are absent); the augmented first-frame stacks the GPU leg produced are replayed, their generation is NOT in the CPU time."""
@@ -211,20 +211,25 @@ def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames):
                 best = (dt, th)
     threads = best[1]
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(0)
     n_obj = len(seq_cpu.obj_ids)
+    start_w = []
+    for k in range(n_obj):                                  # the draws of the GPU leg, repeated (same seeds, same order: project, filter)
+        torch.manual_seed(4242 if k == 0 else 0)
+        pj = torch.nn.Conv2d(cin, 96, 1, bias=False, device='cuda:0')
+        fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False, device='cuda:0')
+        start_w.append((pj.weight.detach().cpu(), fl.weight.detach().cpu()))
     t0 = time.time()
     with torch.no_grad():
         discs = []
         for k in range(n_obj):
-            w1 = (torch.rand(96, cin, 1, 1, generator=g) * 2 - 1) / cin ** 0.5
-            w2 = (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / (9 * 96) ** 0.5
+            w1, w2 = start_w[k]
             d = O.DiscriminatorRef(w1, w2, init_iters=iters[0], update_iters=iters[1], CG_forgetting_rate=750, memory_size=args.memory,
                                    pixel_weighting=dict(method='hinge', tf=0.1))
             im, msk = aug_stacks[k]
             d.init(O.resnet_forward(args.backbone, P, im, ['layer4'])['layer4'], msk)
             discs.append(d)
         done, inserts = 1, 0
+        cpu_labels = [seq_cpu.gt[0].reshape(size).clone()]
         for t in range(1, n_frames + 1):
             if time.time() - t0 > 30.0:       # bounded sample: stop after ~30 s of CPU work
                 break
@@ -236,12 +241,25 @@ def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames):
             masks = torch.zeros(n_obj + 1, *im.shape[-2:])
             masks[1:] = y[:, 0]
             masks = O.merge_masks(masks)
+            cpu_labels.append(O.merge_masks(masks).argmax(0).to(torch.uint8))        # label decoding of tracker.py:146-150
             for k, d in enumerate(discs):
                 if int((masks[k + 1] > 0.5).sum()) >= 10:
                     inserts += 1
                 d.update(masks[k + 1][None, None])
     T = time.time() - t0
-    return {'value': done / T, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+    parity = None
+    if gpu_labels is not None and done > 3:
+        # J&F (DAVIS measures, lib/davis.py pinned to the reference by fixture G10) of BOTH paths against the synthetic ground truth
+        # on the frames the CPU leg covered: the north star asks for the two within +-0.1 points
+        from frtm_vos_amd.lib.evaluation import j_and_f
+        ids = list(seq_cpu.obj_ids)
+        gt = [seq_cpu.gt[t].reshape(size).numpy() for t in range(done)]
+        jf_g = j_and_f([gpu_labels[t].reshape(size).cpu().numpy() for t in range(done)], gt, ids)
+        jf_c = j_and_f([cpu_labels[t].numpy() for t in range(done)], gt, ids)
+        agree = float(sum(float((gpu_labels[t].reshape(size).cpu() == cpu_labels[t]).float().mean()) for t in range(1, done)) / (done - 1))
+        parity = {'frames': done, 'J&F_hip_path': round(jf_g[0], 3), 'J&F_cpu_oracle': round(jf_c[0], 3), 'abs_diff_points': round(abs(jf_g[0] - jf_c[0]), 3),
+                  'label_agreement': round(agree, 5)}
+    return {'value': done / T, 'unit': 'frames/s', 'cores': threads, 'kind': 'port', 'jf_parity_vs_hip_path': parity,
             'sample': 'oracle/cpu_ref.py on the same synthetic sequence as the GPU leg: %s %dx%d, %d objects, %s iterations, same trunk / '
                       'refiner weights, initialize() (augmented stacks replayed from the GPU leg, their generation not timed) + %d tracked '
                       'frames (%d memory inserts), %d torch threads (fastest of 16/64/all on a trunk probe) of %d host cores, %.1f s' %
@@ -451,6 +469,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # target-model start weights are drawn on the device from torch's generator (the first object from this seed, every later one
+    # after initialize()'s manual_seed(0), reference tracker.py:174-180): seeded so that the CPU leg can start from the same weights
+    torch.manual_seed(4242 + rank)
     dev_allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     if args.debug_allocs:
         torch.cuda.memory._record_memory_history(enabled='all', context='alloc', stacks='python')
@@ -555,7 +576,7 @@ def main():
             out['roofline_cg']['multi_kernel_form_ms_per_run'] = mk['ms_per_run']
         if not args.no_cpu_baseline and args.late_object is None:
             seq.preload('cpu')
-            out['cpu_baseline'] = cpu_baseline(args, size, seq, aug_cpu, min(args.cpu_frames, args.steps - 1))
+            out['cpu_baseline'] = cpu_baseline(args, size, seq, aug_cpu, min(args.cpu_frames, args.steps - 1), gpu_labels=outputs)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

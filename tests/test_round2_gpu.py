@@ -587,3 +587,22 @@ def test_evaluate_driver_end_to_end_single_and_two_ranks(tmp_path):
     assert '30 frames on 2 GPU(s)' in out2.stdout
     j2 = float((res2 / 'evaluation-J.txt').read_text().strip().splitlines()[-1].split()[1].rstrip(','))
     assert abs(j1 - j2) < 0.1, (j1, j2)          # target-model weights are drawn per process: close, not identical
+
+
+def test_recycled_target_model_draws_like_a_new_one():
+    """bench.py's CPU leg repeats the GPU leg's start weights from the seed: a recycled Discriminator (pool) draws the same
+    numbers from torch's device generator as a newly constructed one."""
+    from frtm_vos_amd.model.discriminator import Discriminator
+    kw = dict(in_channels=256, c_channels=96, device=DEV, layer='layer4')
+    torch.manual_seed(77)
+    a = Discriminator(**kw)
+    torch.manual_seed(77)
+    pj = torch.nn.Conv2d(256, 96, 1, bias=False, device=DEV)
+    fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False, device=DEV)
+    assert torch.equal(a.project.weight, pj.weight) and torch.equal(a.filter.weight, fl.weight)
+    torch.manual_seed(0)
+    a.recycle()
+    torch.manual_seed(0)
+    pj = torch.nn.Conv2d(256, 96, 1, bias=False, device=DEV)
+    fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False, device=DEV)
+    assert torch.equal(a.project.weight, pj.weight) and torch.equal(a.filter.weight, fl.weight)
