@@ -15,6 +15,10 @@ Pinning status
   (model/discriminator.py, model/optimizer.py, model/memory.py, model/tracker.py)
   in the build container and stores their outputs in ``tests/golden/*.npz``;
   ``tests/test_oracle_golden.py`` replays them against this file.
+  Round 2 adds ``oracle/make_golden_r2.py`` (joint problem at BASELINE size, G9; full memory, G8 at N = 80; and the reference's
+  own run-to-run spread of every trajectory-level output, ``g_spread.npz``, from which the test gates are derived),
+  ``make_golden_davis.py`` (the reference's lib/davis.py measures, G10) and ``make_golden_aug.py`` (parameter draws and transforms of
+  the reference's augmenter, G11).
 * backbone (torchvision ResNet topology): PARITY UNPINNED.  torchvision is a
   third-party, un-vendored, un-pinned dependency of the reference
   (model/feature_extractor.py:3,12-14; README.md:28) and is absent here, as are

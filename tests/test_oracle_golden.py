@@ -288,3 +288,41 @@ def test_g8_full_memory_n80(golden, spread_gate):
     assert rel(prob.A([p])[0], T(g['Ap'])) < 2e-5
     opt.run((10,))
     assert rel(wv, T(g['filt'])) < spread_gate('g8n80_filt')
+
+
+def test_config1_cpu_plumbing_oracle_tracks_a_synthetic_sequence():
+    """BASELINE config 1 (plumbing, CPU only, reduced to 240x432 / 12 frames so that the CPU suite stays short): ResNet-18 trunk,
+    "fast" iteration schedule, one object, the oracle assembled in the control flow of model/tracker.py with the synthetic trunk
+    weights and the score-following refiner of bench.py.  The feedback loop must close on the CPU path too: the object is tracked
+    (IoU vs the synthetic ground truth), every tracked frame inserts a sample, the filter is re-solved on frame 8."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence, make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    from test_fullsize_gpu import _CpuTracker
+    torch.set_num_threads(8)
+    size = (240, 432)
+    seq = SyntheticSequence('cfg1', 12, size, 1, seed=5)
+    P = O.resnet_random_params('resnet18', seed=0)
+    torch.manual_seed(1)
+    net = make_score_following_refiner(SegNetwork(1, 64, {'layer5': 512, 'layer4': 256, 'layer3': 128, 'layer2': 64}, True).eval())
+    g = torch.Generator().manual_seed(0)
+    w1w2 = {1: ((torch.rand(96, 256, 1, 1, generator=g) * 2 - 1) / 16, (torch.rand(1, 96, 3, 3, generator=g) * 2 - 1) / 29.4)}
+    trk = _CpuTracker('resnet18', P, net, w1w2, ((5, 10, 10, 10), (5,)))
+    ious, sizes, filt = [], [], []
+    with torch.no_grad():
+        for i, (im, lb, new) in enumerate(seq):
+            old = set(trk.targets)
+            if new:
+                trk.initialize(im, lb, new)
+            if old:
+                trk.track(im)
+                m = trk.masks[1] > 0.5
+                gt = seq.gt[i][0] == 1
+                ious.append(float((m & gt).sum()) / float((m | gt).sum()))
+                d = trk.targets[1]['d']
+                sizes.append(d.memory.current_size)
+                filt.append(d.w2.clone())
+            trk.frame += 1
+    assert len(ious) == 11 and min(ious) > 0.6 and sum(ious) / 11 > 0.8, ious
+    assert sizes == [min(3 + k, 8) for k in range(1, 12)], sizes            # K = 3 initial samples (stub augmentation), capacity 8
+    changed = [not torch.equal(filt[k], filt[k - 1]) for k in range(1, 11)]
+    assert changed == [k + 1 == 8 for k in range(1, 11)], changed            # the only re-solve: tracked frame 8
