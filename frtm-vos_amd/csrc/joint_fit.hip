@@ -232,7 +232,12 @@ int frtm_joint_mid(const float* s, const float* Bm, const float* cm, const float
                    int h, int w, int parts, float* partial, float* D, frtm_stream_t stream) {
   FRTM_CHECK_ARG(s && Bm && sw && Z && w2 && partial && D && N > 0 && C > 0 && parts >= 1 && parts <= 64, "frtm_joint_mid: bad argument");
   const size_t lds = 2 * (size_t)(h + 2) * (w + 2) * sizeof(float);
-  FRTM_CHECK_ARG(lds <= 64 * 1024, "frtm_joint_mid: feature grid %dx%d too large for the LDS tile", h, w);
+  FRTM_CHECK_ARG(lds <= 144 * 1024, "frtm_joint_mid: feature grid %dx%d too large for the LDS tile", h, w);
+  static bool big_lds = false;                  // 1080p (68x120): two padded maps are 68 KB -- more than the 64 KB default limit
+  if (lds > 64 * 1024 && !big_lds) {
+    FRTM_HIP(hipFuncSetAttribute((const void*)k_joint_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    big_lds = true;
+  }
   const int gw = ceil_div(C, 4 * MID_CH);
   const int gi = min(ceil_div(C * h * w, 256 * 4), 64);
   dim3 g(gw + gi, N, parts);

@@ -172,7 +172,7 @@ class DiscriminatorLoss(MinimizationProblem):
         ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
         ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
-        if not self.fused:
+        if not self._use_fused():
             self._stencil(True)
             self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
             self._project_grad(self.filter_regs[0] ** 2, H.ptr(self.w1T), -1.0, H.ptr(b[:n1]))
@@ -187,7 +187,7 @@ class DiscriminatorLoss(MinimizationProblem):
             self._stencil(False)
             self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(p), 1.0, H.ptr(q))
             return
-        if self.fused:
+        if self._use_fused():
             return self.apply_A_pq(p, q, None, None)
         n1 = self.Cin * c
         p1, p2 = p[:n1], p[n1:]
@@ -199,6 +199,10 @@ class DiscriminatorLoss(MinimizationProblem):
         self._project_grad(self.filter_regs[0] ** 2, H.ptr(p1), 1.0, H.ptr(q[:n1]))
 
     fused = True        # joint problem: merged glue kernels (csrc/joint_fit.hip), 8 instead of 13 launches per CG iteration
+
+    def _use_fused(self):
+        # k_joint_mid keeps two zero-padded score maps in LDS: grids beyond ~135x135 take the launch-per-step chain
+        return self.fused and 8 * (self.h + 2) * (self.w + 2) <= 144 * 1024
 
     def apply_A_pq(self, p, q, r, partial):
         """Joint problem: q <- J^T J p + lam^2 p and, if ``partial`` is given, the partial dot products <p,q> (and <p,r>) the
