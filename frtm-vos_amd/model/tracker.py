@@ -75,6 +75,7 @@ class Tracker(nn.Module):
         self._first_stream = None
         self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
+        self.share_first_sample = True   # the un-augmented frame (sample 0 of every object's stack) passes the trunk once per frame
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
@@ -374,7 +375,13 @@ class Tracker(nn.Module):
             # one trunk call for the augmented stacks of ALL objects that start on this frame (the reference runs one per
             # object, :186); same per-image results, larger launches and one lane per object
             layers = sorted({t.disc_layer for t, _, _ in fresh})
-            ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers)
+            # Sample 0 of every object's augmented stack is the frame itself (augment_first_frame's contract, reference
+            # augmenter.py:546-547): it goes through the trunk ONCE for all objects that start here, not once per object.
+            share = self.share_first_sample and len(fresh) > 1
+            if share:
+                ft_all = self.feature_extractor(torch.cat([fresh[0][1][:1]] + [im[1:] for _, im, _ in fresh]), layers)
+            else:
+                ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers)
             if self._after_init_trunk is not None:
                 hook, self._after_init_trunk = self._after_init_trunk, None
                 hook()
@@ -384,15 +391,19 @@ class Tracker(nn.Module):
             lanes = self._init_streams(min(len(fresh), self.init_lanes)) if len(fresh) > 1 and self.init_lanes > 1 else []
             for st in lanes:
                 st.wait_stream(cur)
-            b0 = 0
+            b0 = 1 if share else 0
             for i, (target, im, msk) in enumerate(fresh):
-                k = im.shape[0]
-                feats = {L: ft[L][b0:b0 + k] for L in layers}
+                k = im.shape[0] - 1 if share else im.shape[0]
+                def fit(target=target, msk=msk, b0=b0, k=k):
+                    # (the gather of the shared sample runs on the stream of the fit that reads it)
+                    feats = ({L: torch.cat((ft_all[L][:1], ft_all[L][b0:b0 + k])) for L in layers} if share
+                             else {L: ft[L][b0:b0 + k] for L in layers})
+                    target.initialize(feats, msk)
                 if lanes:
                     with torch.cuda.stream(lanes[i % len(lanes)]):
-                        target.initialize(feats, msk)
+                        fit()
                 else:
-                    target.initialize(feats, msk)
+                    fit()
                 b0 += k
             for st in lanes:
                 cur.wait_stream(st)
