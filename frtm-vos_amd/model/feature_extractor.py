@@ -156,6 +156,7 @@ class ResnetFeatureExtractor:
         self._winograd = True
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
         self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
+        self.pass_events = None        # a list: every pass appends (start event, end event, FLOPs, conv launches)  (bench.py's roofline leg)
 
     @property
     def lanes(self):
@@ -238,12 +239,20 @@ class ResnetFeatureExtractor:
         # One pass at a time on the device: callers on different streams (run_sequence's prefetch stream next to initialize() on the
         # main stream) share the lanes' activation arenas, so a pass first waits for the previous one, whatever stream that ran on.
         cur = torch.cuda.current_stream(self.device)
-        if self._pass_done is not None and not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._pass_done is not None and not capturing:
             cur.wait_event(self._pass_done)
+        timed = self.pass_events is not None and not capturing
+        if timed:                                             # (after the wait: the pair brackets this pass's own kernels)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         try:
             return self._call(x, B, Hh, Ww, output_layers)
         finally:
-            if not torch.cuda.is_current_stream_capturing():
+            if timed:
+                e1.record(cur)
+                self.pass_events.append((e0, e1, self.last_flops, self.last_conv_launches))
+            if not capturing:
                 self._pass_done = torch.cuda.Event()
                 self._pass_done.record(cur)
 

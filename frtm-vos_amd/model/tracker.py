@@ -76,6 +76,7 @@ class Tracker(nn.Module):
         self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self.share_first_sample = True   # the un-augmented frame (sample 0 of every object's stack) passes the trunk once per frame
+        self.early_first_pass = True     # first tracking pass enqueued before initialize(): it runs under the host-bound augmentation
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
@@ -324,7 +325,14 @@ class Tracker(nn.Module):
         # Single stream: a pass is enqueued when its first frame is asked for -- by then run_sequence has flushed every window of the
         # previous batch (windows end with the last frame of a trunk batch), so the one persistent tap set can be overwritten.
         # Side stream: one pass AHEAD, into the other tap set.
-        if side is not None:
+        if (side is None and persistent and self.early_first_pass and not self.overlap_first_pass and torch.cuda.is_available()
+                and len(frames) > 1 and len(frames[0][2]) > 0):
+            # The first tracking pass does not depend on initialize(): enqueue it right away on a side stream.  It then runs
+            # while the host is busy with the first-frame augmentation (host-bound: a dozen tiny kernels and two device->host
+            # reads per object), which only synchronises the main stream.  initialize()'s own trunk call follows it (passes are
+            # serialised by the extractor).  One pass only: later passes reuse the single tap set.
+            launch(0, on=self._first_pass_stream())
+        elif side is not None:
             if len(frames) > 0 and len(frames[0][2]) > 0:
                 # frame 0 initialises objects: its own trunk call (the augmented stacks) goes first, the pass for frames 1.. follows
                 # on the side stream, next to the target-model fits (initialize() fires the hook right after its trunk call)
