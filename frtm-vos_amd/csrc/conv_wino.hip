@@ -23,26 +23,35 @@ constexpr int WCI = 8;                 // input channels per chunk
 constexpr int WBM = 32;                // output channels per workgroup
 constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight block: [xi][lane][(kk,i)]
 
-// LDS carries only the raw input patch (double buffered) and, at the end, the accumulator planes for the output transform.  A
-// first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
+// LDS carries only the raw input patch (three stages) and, at the end, the accumulator planes for the output transform (the same
+// 32 KB).  A first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
 // LDS-bandwidth bound (59 KB of LDS traffic per 64 MFMAs; the skeleton without MFMAs took 73 % of the time).  Now
 //  * the weights are packed in MFMA A-fragment order ([chunk][m_tile][xi][lane][4]) and go from L2 straight into registers:
-//    one dwordx4 per lane per component per chunk, a fully coalesced 1 KB per wave instruction;
+//    one dwordx4 per lane per component per chunk, a fully coalesced 1 KB per wave instruction, in a ring of three chunks;
 //  * wave `wid` owns the components xi = 4*wid .. 4*wid+3, i.e. ROW wid of the transformed 4x4 patch: each lane forms its own
 //    B fragments V[wid][0..3] for (channel = kk*4 + lane/16, tile = lane%16) from the two raw rows that row needs -- 8 LDS
 //    values in, 4 MFMA operands out, no transformed image in LDS and no transform stage;
-//  * one barrier per chunk (raw patch double buffer).
-// FN = 1: 8x8 output block (16 tiles).  FN = 2: 32 tiles per workgroup, as 8 rows x 16 columns (TALL = 0) or 16 rows x 8
-// columns (TALL = 1): every weight fragment feeds two MFMAs, which halves the L2 -> register weight traffic per FLOP (the
-// heaviest stream of this kernel: 16 KB per chunk per workgroup).
-template <int FN, int TALL>
-__global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
-  constexpr int BH = (FN == 2 && TALL) ? 16 : 8, BW = (FN == 2 && !TALL) ? 16 : 8;      // output block
-  constexpr int PR = BH + 2, PC = BW + 2, PE = PR * PC;                                 // raw patch of one channel
-  constexpr int WRAW = (PE + 3) / 4 * 4 + 4;                                            // its pitch
-  constexpr int NR = (WCI * PE + 255) / 256;                                            // raw elements per thread
-  __shared__ __attribute__((aligned(16))) float Raw[2][WCI][WRAW];
-  __shared__ __attribute__((aligned(16))) float Ms[16 * WBM * 16];          // epilogue: M[xi][cout][tile] of one fragment column
+//  * the raw patch goes from global memory STRAIGHT into LDS (buffer_load ... lds: the hardware bounds checks still give the
+//    zero border; no register ring and no ds_write pass for it).  The LDS image is lane-linear: element e = tid + i*256 of the
+//    8 x PR x PC patch sits at word e of its stage (channel pitch = PR*PC);
+//  * per chunk: issue the loads of chunk k+2, compute chunk k, wait until this wave's part of patch k+1 has landed
+//    (s_waitcnt vmcnt(NR + 8): the loads issued after it may stay in flight), one barrier.
+// FN = 1: 8x8 output block (16 tiles), 128 registers -> four workgroups per CU.  FN = 2: 32 tiles per workgroup, as 8 rows x 16
+// columns (TALL = 0) or 16 rows x 8 columns (TALL = 1), 167 registers -> three per CU: every weight fragment feeds two MFMAs,
+// which halves the L2 -> register weight traffic per FLOP.
+// Round-2 measurements of this form against its predecessor (register ring for the patch, 4-chunk weight ring: 160 registers /
+// 3 workgroups per CU for FN = 1, 228 / 2 for FN = 2): trunk 118.1 -> 118.6 TF (two lanes), 105.8 -> 107.7 (one lane); the
+// refiner, whose single-M-tile convs take the FN = 2 forms, 31.6 -> 29.7 ms per 63 frames.  Occupancy is not what bounds the
+// trunk's convs: three structurally different variants (3 or 4 workgroups per CU, 8x8 or 8x16 blocks) run at the same rate.
+template <int FN, int TALL, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_conv3x3_wino(const ConvParams p) {
+  constexpr int BH = (FN == 2 && TALL) ? 16 : 8, BW = (FN == 2 && !TALL) ? 16 : 8;
+  constexpr int PR = BH + 2, PC = BW + 2, PE = PR * PC;
+  constexpr int NR = (WCI * PE + 255) / 256;                                 // 4 (8x8 block) or 6 (32-tile blocks)
+  constexpr int STAGE = NR * 256;                                            // floats per patch stage, lane-linear
+  static_assert(3 * STAGE <= 16 * WBM * 16, "patch stages must fit the epilogue buffer");
+  __shared__ __attribute__((aligned(16))) float smem[16 * WBM * 16];       // main loop: 3 patch stages; epilogue: M[xi][cout][tile]
+  float* Ms = smem;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, li = lane & 15;
   const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
@@ -55,9 +64,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
-
-  // raw patch staging: 8 channels x PR x PC, element e = tid + i*256
-  unsigned r_goff[NR]; int r_loff[NR], r_ci[NR];
+  unsigned r_goff[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int e = tid + i * 256;
@@ -65,51 +72,36 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
     const int yy = y0 - 1 + r, xx = x0 - 1 + c;
     const bool ok = e < WCI * PE && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
     r_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
-    r_loff[i] = e < WCI * PE ? ci * WRAW + q : -1;
-    r_ci[i] = ci;
   }
-  // this lane's weight fragments: component q of wave wid, chunk kc  ->  float4 {(kk0,i0), (kk0,i1), (kk1,i0), (kk1,i1)}
-  const unsigned a_lane = (unsigned)(((m_tile * 16 + wid * 4) * 64 + lane) * 16);       // bytes inside a chunk's block row
-  const unsigned a_chunk = (unsigned)mt * WFRAG * 4u;                                  // bytes per chunk
-  // row `wid` of B^T d:  r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3   ->  u = d[ra] + sb * d[rb]
+  const unsigned a_lane = (unsigned)(((m_tile * 16 + wid * 4) * 64 + lane) * 16);
+  const unsigned a_chunk = (unsigned)mt * WFRAG * 4u;
   const int ra_ = (wid == 0) ? 0 : (wid == 2 ? 2 : 1), rb_ = (wid == 3) ? 3 : (wid == 2 ? 1 : 2);
   const float sb_ = (wid == 1) ? 1.f : -1.f;
-  // tile of fragment column j: (row, col) among the block's tiles; its 4x4 patch starts at (2*row, 2*col) of the raw patch
-  int t_r[FN], t_c[FN], offA[FN], offB[FN];
+  int offA[FN], offB[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    t_r[j] = (li >> 2) + ((FN == 2 && TALL) ? 4 * j : 0);
-    t_c[j] = (li & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
-    const int po = (2 * t_r[j]) * PC + 2 * t_c[j];
-    offA[j] = lk * WRAW + po + ra_ * PC;
-    offB[j] = lk * WRAW + po + rb_ * PC;
+    const int t_r = (li >> 2) + ((FN == 2 && TALL) ? 4 * j : 0), t_c = (li & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
+    const int po = (2 * t_r) * PC + 2 * t_c;
+    offA[j] = lk * PE + po + ra_ * PC;
+    offB[j] = lk * PE + po + rb_ * PC;
   }
 
-  // Register ring of 4 chunks: the loads of chunk k+3 are issued while chunk k is computed.  A chunk is only 16 (32) MFMAs per
-  // wave, far less than the L2 / HBM latency; with a one-chunk look-ahead every chunk waited for its own loads (the kernel ran
-  // at the same speed with the MFMAs removed).
-  f32x4 fa[4][4];
-  float rr[4][NR];
+  f32x4 fa[3][4];
   auto gloadA = [&](int kc, f32x4* dst) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = buf_ld4(rw, (unsigned)kc * a_chunk + a_lane + (unsigned)(q * 64 * 16));
   };
-  auto gloadR = [&](int kc, float* dst) {
-    // OOB + cstep stays beyond the buffer (cstep < in_bytes < 2^31), so padding elements need no select
+  auto gloadR = [&](int kc, int stage) {                   // NR x buffer_load_dword ... lds per lane: this wave's NR x 64 words
     const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);
-    const bool tail = (kc + 1) * WCI > p.Cin;                         // only the last chunk of a Cin that is not a multiple of 8
+    const bool tail = (kc + 1) * WCI > p.Cin;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       unsigned o = r_goff[i] + cstep;
-      if (tail && kc * WCI + r_ci[i] >= p.Cin) o = OOB;
-      dst[i] = buf_ld1(rin, o);
+      if (tail && kc * WCI + (tid + i * 256) / PE >= p.Cin) o = OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + i * 256 + wid * 64),
+                                               4, (int)o, 0, 0, 0);
     }
   };
-  auto lstoreR = [&](int buf, const float* src) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) if (r_loff[i] >= 0) (&Raw[buf][0][0])[r_loff[i]] = src[i];
-  };
-
   f32x4 acc[4][2][FN];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -119,25 +111,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
       for (int j = 0; j < FN; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nch = p.nchunks;
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    if (k < nch) { gloadA(k, fa[k]); gloadR(k, rr[k]); }
-  lstoreR(0, rr[0]);
+  gloadR(0, 0); gloadA(0, fa[0]);
+  if (1 < nch) { gloadR(1, 1); gloadA(1, fa[1]); }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) (expcnt / lgkmcnt untouched): patch 0 of this wave is in LDS
   __syncthreads();
-  // one chunk; S = k & 3 is a compile-time constant so that the ring stays in registers
   auto chunk = [&](int k, auto S_) {
-    constexpr int S = decltype(S_)::value;
-    if (k + 3 < nch) { gloadA(k + 3, fa[(S + 3) & 3]); gloadR(k + 3, rr[(S + 3) & 3]); }
-    const float* R = &Raw[k & 1][0][0];
+    constexpr int S = decltype(S_)::value;                  // k % 3
+    if (k + 2 < nch) { gloadR(k + 2, (S + 2) % 3); gloadA(k + 2, fa[(S + 2) % 3]); }
+    const float* R = smem + S * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       float bq[FN][4];
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const float* da = R + kk * 4 * WRAW + offA[j];
-        const float* db = R + kk * 4 * WRAW + offB[j];
+        const float* da = R + kk * 4 * PE + offA[j];
+        const float* db = R + kk * 4 * PE + offB[j];
         const float u0 = da[0] + sb_ * db[0], u1 = da[1] + sb_ * db[1], u2 = da[2] + sb_ * db[2], u3 = da[3] + sb_ * db[3];
-        bq[j][0] = u0 - u2; bq[j][1] = u1 + u2; bq[j][2] = u2 - u1; bq[j][3] = u1 - u3;      // (B^T d) B, columns 0..3
+        bq[j][0] = u0 - u2; bq[j][1] = u1 + u2; bq[j][2] = u2 - u1; bq[j][3] = u1 - u3;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -147,22 +137,22 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
           acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][q][kk * 2 + 1], bq[j][q], acc[q][1][j], 0, 0, 0);
         }
     }
-    if (k + 1 < nch) lstoreR((k + 1) & 1, rr[(S + 1) & 3]);      // loaded two chunks ago
+    // patch k+1 (issued one chunk ago) must have landed before anyone reads it; newer than it in the in-order queue are the
+    // weight loads of k+1 (4) and, if issued, the NR + 4 loads of k+2
+    if (k + 2 < nch) __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F7C : 0x0F7E);   // vmcnt(NR + 8): 12 / 14 newer loads may stay in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
     __syncthreads();
   };
-  for (int kc = 0; kc < nch; kc += 4) {
+  for (int kc = 0; kc < nch; kc += 3) {
     chunk(kc, std::integral_constant<int, 0>{});
     if (kc + 1 < nch) chunk(kc + 1, std::integral_constant<int, 1>{});
     if (kc + 2 < nch) chunk(kc + 2, std::integral_constant<int, 2>{});
-    if (kc + 3 < nch) chunk(kc + 3, std::integral_constant<int, 3>{});
   }
 
   const bool pair_ok = (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
-  // ---- output transform: the 16 component planes of a (cout, tile) pair sit in 4 different waves -> through LDS, one fragment
-  // column (16 tiles) at a time ----
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    if (j > 0) __syncthreads();                               // Ms of the previous column has been consumed
+    if (j > 0) __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -172,7 +162,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int pidx = tid + h * 256;                         // (cout, tile) pair
+      const int pidx = tid + h * 256;
       const int co = pidx >> 4, t = pidx & 15;
       const int mm = m0 + co;
       float m[16];
@@ -196,7 +186,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wino(const ConvParams p) {
         float v0 = (s[a][0] + s[a][1] + s[a][2]) * sc + sh, v1 = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
         const size_t o = plane + (size_t)yy * p.Wo + xx;
         const bool two = xx + 1 < p.Wo;
-        if (two && (o & 1) == 0 && pair_ok) {                 // both pixels of the row as one 8-byte access
+        if (two && (o & 1) == 0 && pair_ok) {
           if (p.residual) { const float2 rv = *(const float2*)&p.residual[o]; v0 += rv.x; v1 += rv.y; }
           if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
           *(float2*)&p.out[o] = make_float2(v0, v1);
@@ -265,11 +255,11 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
     if (mt > 1 || a * 100 > a1 * 115 || blocks2 < 512) variant = 1;     // measured: the 32-tile forms only pay for a single M tile
   }
   if (variant == 2) {
-    k_conv3x3_wino<2, 0><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);
+    k_conv3x3_wino<2, 0, 3><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);
   } else if (variant == 3) {
-    k_conv3x3_wino<2, 1><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
+    k_conv3x3_wino<2, 1, 3><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
   } else {
-    k_conv3x3_wino<1, 0><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
+    k_conv3x3_wino<1, 0, 4><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
   }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
