@@ -68,6 +68,10 @@ def parse(argv=None):
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
+    ap.add_argument('--no-trunk-graph', action='store_true', help='trunk passes launched kernel by kernel instead of replayed as hipGraphs')
+    ap.add_argument('--balance', action='store_true', help='trunk batches of similar size instead of full ones and a short tail pass (measured slower at 20 frames)')
+    ap.add_argument('--pipeline', action='store_true', help='two tap sets, trunk passes one ahead on a side stream, one beside the first-frame fits (measured: +4 %% frames/s at 20 frames, trunk passes 5 %% slower)')
+    ap.add_argument('--first-batch', type=int, default=0, help='frames of the pipelined first trunk pass (default: trunk batch / 2)')
     ap.add_argument('--overlap', action='store_true', help='run the next trunk batch on a side stream, overlapped with tracking')
     ap.add_argument('--memory', type=int, default=80, help='target-model memory slots (80 = evaluate.py:80)')
     ap.add_argument('--late-object', type=int, default=None, help='frame at which the last object first appears')
@@ -417,6 +421,10 @@ def main():
     params.refiner_factory = lambda chans: synthetic_refiner(args, chans)
     tracker = params.get_model()
     tracker.prefetch_stream = args.overlap
+    tracker.pipeline_passes = args.pipeline
+    tracker.balance_batches = args.balance
+    tracker.first_batch = args.first_batch or None
+    tracker.graph_trunk = not args.no_trunk_graph
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
     tracker.overlap_first_pass = args.first_pass_overlap
@@ -436,6 +444,7 @@ def main():
 
     timer = StageTimer()
     ext = tracker.feature_extractor
+    ext.pass_frames = []
     ext.pass_events = []                     # HIP events around every trunk pass, recorded on the stream the pass runs on
     aug_log = []
     raw_augment = tracker.augment
@@ -467,6 +476,7 @@ def main():
     timer.reset()
     del aug_log[:]
     del ext.pass_events[:]
+    del ext.pass_frames[:]
 
     if dist is not None:
         dist.barrier()
@@ -566,7 +576,11 @@ def main():
                      # profiles/*_trunk_only.json holds the union-of-intervals cross-check from rocprofv3.
                      'per_launch': {'flops': flops_total / max(n_launch, 1), 'avg_ms': bb_ms / max(n_launch, 1), 'launches': n_launch,
                                     'concurrent_lanes': args.trunk_lanes},
-                     'trunk_ms_per_pass': bb_ms / max(bb_calls, 1)},
+                     'trunk_ms_per_pass': bb_ms / max(bb_calls, 1),
+                     # every pass of the timed region in order: [frames, ms, TFLOP/s] (the augmented first-frame stack, then the
+                     # tracking passes; the first tracking pass is enqueued before initialize() and shares the GPU with it)
+                     'passes': [[nf, round(a.elapsed_time(b), 3), round(f / a.elapsed_time(b) / 1e9, 1)]
+                                for (a, b, f, _), nf in zip(ext.pass_events, ext.pass_frames)]},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'path_counters': counters,
         'mean_iou_vs_synthetic_gt': round(quality, 4),

@@ -44,6 +44,7 @@ SIGNATURES = {
     'frtm_joint_q_pq': (I, [P, I, F, P, I, I, I, F, P, P, F, P, P, P, P]),
     'frtm_cg_persistent_plan': (I, [I, I, I, I, P, P]),
     'frtm_cg_run_persistent': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P]),
+    'frtm_cg_run_persistent_guarded': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P, I, P, P]),
     'frtm_vec_axpy': (I, [P, F, P, I, P]),
     'frtm_transpose2d': (I, [P, I, I, P, P]),
     'frtm_conv_pack_weights': (I, [P, I, I, I, I, P, P, P]),

@@ -39,6 +39,7 @@ struct Params {
   float* w2; float* vec; float* state; float* slabs; float* qbuf; unsigned* bar;
   int N, c, h, w, R, parts, iters, has_p, apply_dff, fr, std_alpha, parity;
   float dff, lam2, invM, step;
+  const int* guard; int guard_min; unsigned* stats;     // optional device-side early-out and its counters (see the guarded entry)
 };
 
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -127,6 +128,13 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int G = gridDim.x, g = blockIdx.x;
+  // Device-side form of the reference's early-out (discriminator.py:214: fewer than 10 mask pixels above 0.5 -> no update): the count
+  // was left in device memory by an earlier kernel of this stream, every workgroup reads the same value and the whole launch
+  // returns before its first barrier.  The host never has to wait for the count.
+  if (P.guard != nullptr && *P.guard < P.guard_min) {
+    if (g == 0 && tid == 0 && P.stats) atomicAdd(P.stats + 1, 1u);
+    return;
+  }
   const int n_s = g / P.parts, part = g - n_s * P.parts;
   const int r0 = part * P.R;
   const int R = min(P.R, P.h - r0);                   // rows this workgroup owns (>= 1 by construction)
@@ -364,6 +372,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       P.state[4] = rho_cur;
       P.state[1] = alpha;
       P.state[2] = beta_last;
+      if (P.stats) atomicAdd(P.stats, 1u);
     }
   }
   leave();
@@ -388,10 +397,11 @@ int frtm_cg_persistent_plan(int N, int c, int h, int w, int* parts_out, int* row
   return N * parts;
 }
 
-int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
-                           float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
-                           int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
-                           float lam2, float invM, float step, frtm_stream_t stream) {
+int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
+                                   float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
+                                   int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
+                                   float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
+                                   frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && Bm && cm && sw && w2 && vec && state && slabs && qbuf && bar && iters >= 0, "frtm_cg_run_persistent: bad argument");
   int parts = 0, R = 0;
   const int G = frtm_cg_persistent_plan(N, c, h, w, &parts, &R);
@@ -400,6 +410,7 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
   P.X = X; P.Bm = Bm; P.cm = cm; P.sw = sw; P.w2 = w2; P.vec = vec; P.state = state; P.slabs = slabs; P.qbuf = qbuf; P.bar = bar;
   P.N = N; P.c = c; P.h = h; P.w = w; P.R = R; P.parts = parts; P.iters = iters; P.has_p = has_p; P.apply_dff = apply_dff;
   P.fr = fletcher_reeves; P.std_alpha = standard_alpha; P.parity = 0; P.dff = dff; P.lam2 = lam2; P.invM = invM; P.step = step;
+  P.guard = guard_count; P.guard_min = guard_min; P.stats = stats;
   static bool attr_set = false;
   if (!attr_set) {
     FRTM_HIP(hipFuncSetAttribute((const void*)k_cg_run_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4));
@@ -408,6 +419,14 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
   k_cg_run_persistent<<<G, NT, L_TOTAL * 4, (hipStream_t)stream>>>(P);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
+}
+
+int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
+                           float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
+                           int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
+                           float lam2, float invM, float step, frtm_stream_t stream) {
+  return frtm_cg_run_persistent_guarded(X, Bm, cm, sw, N, c, h, w, w2, vec, state, slabs, qbuf, bar, iters, has_p, apply_dff, fletcher_reeves,
+                                        standard_alpha, dff, lam2, invM, step, nullptr, 0, nullptr, stream);
 }
 
 }  // extern "C"

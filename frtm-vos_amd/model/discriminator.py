@@ -312,8 +312,9 @@ class Discriminator(nn.Module):
         if not dev_ok:
             self.to(device)
         self.frame_num = 0
-        self.num_solves = 0              # filter re-solves run by update() since init() (diagnostics: bench.py asserts the schedule)
-        self.num_early_outs = 0          # host-side "fewer than 10 pixels" early-outs of update() (the device-guarded ones: memory.insert_counts)
+        self._solves_host = 0            # filter re-solves / "fewer than 10 pixels" early-outs decided on the host since init(); the ones
+        self._early_outs_host = 0        # decided on the device are counted there (num_solves / num_early_outs add the two)
+        self._guarded_runs = 0
         self.num_persistent_aborts = 0   # persistent CG launches that timed out (GPU shared with another resident-hungry kernel)
         self.update_optimizer = None
         self.current_sample = None
@@ -322,14 +323,51 @@ class Discriminator(nn.Module):
         self._w1T_key = None
         self._ws = {}                    # recycled state: memories and problems of the previous object this instance served
 
+    # True: on filter re-solve frames the "fewer than 10 pixels" early-out (reference :214) is taken ON THE DEVICE when the caller
+    # hands update() a device-resident pixel count and the re-solve runs as persistent launches: the tracking loop then has no
+    # device->host read at all and the host enqueues whole sequences ahead of the GPU.
+    device_early_out = True
+
+    def guards_on_device(self):
+        """Will update() decide the early-out of a re-solve frame on the device (no host-side pixel count needed)?"""
+        o = self.update_optimizer
+        return bool(self.device_early_out and self.update_filters and o is not None and o.persistent)
+
+    def _device_counts(self):
+        """(re-solves, early-outs) of the device-guarded runs since init().  SYNCHRONISES (diagnostics only)."""
+        if self._guarded_runs == 0 or self.update_optimizer is None:
+            return 0, 0
+        k = max(1, len([n for n in self.update_iters if n > 0]))               # persistent launches per run
+        done, skipped = self.update_optimizer.persistent_counts()
+        return done // k, skipped // k
+
+    @property
+    def num_solves(self):
+        """Filter re-solves run by update() since init() (diagnostics: bench.py checks them against the schedule)."""
+        return self._solves_host + self._device_counts()[0]
+
+    @num_solves.setter
+    def num_solves(self, v):
+        self._solves_host = v - self._device_counts()[0]
+
+    @property
+    def num_early_outs(self):
+        """Re-solve-frame "fewer than 10 pixels" early-outs of update() (the guarded inserts of the other frames: memory.insert_counts)."""
+        return self._early_outs_host + self._device_counts()[1]
+
+    @num_early_outs.setter
+    def num_early_outs(self, v):
+        self._early_outs_host = v - self._device_counts()[1]
+
     def recycle(self):
         """Prepares this instance for a NEW object: fresh weights drawn like a newly constructed Discriminator, counters reset; the memories / problem buffers (~150 MB at 480p)
         stay allocated and are reused by the next init().  Nothing is freed or allocated on the device."""
         self.project.reset_parameters()        # in place, on the device
         self.filter.reset_parameters()
         self.frame_num = 0
-        self.num_solves = 0
-        self.num_early_outs = 0
+        self._solves_host = 0
+        self._early_outs_host = 0
+        self._guarded_runs = 0
         self.num_persistent_aborts = 0
         self.update_optimizer = None
         self.current_sample = None
@@ -408,6 +446,7 @@ class Discriminator(nn.Module):
         if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing():
             opt = self._init_body(mem0, memory, None if not self.keep_hires else y)
             opt.persistent = bool(self.persistent_cg)
+            opt.reset_persistent_counts()
             self.memory, self.update_optimizer = memory, opt
             return
         key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
@@ -425,6 +464,7 @@ class Discriminator(nn.Module):
         opt = ent['opt']
         opt._has_p = True
         opt.persistent = bool(self.persistent_cg)
+        opt.reset_persistent_counts()
         self._w1T, self._w1T_key = ent['w1T'], (self.project.weight.data_ptr(), self.project.weight._version)
         self.memory, self.update_optimizer = memory, opt
 
@@ -505,15 +545,33 @@ class Discriminator(nn.Module):
         if num_positive is None and count_dev is not None and not solve:
             self.memory.update(self.current_sample, train_y, count_dev=count_dev)
             return
+        opt = self.update_optimizer
+        if num_positive is None and count_dev is not None and self.device_early_out and opt.persistent:
+            # re-solve frame, the early-out decided on the device as well: guarded insert + guarded persistent launches
+            if opt.peek_persistent_abort() and opt.poll_persistent_abort():
+                self.num_persistent_aborts += 1
+            else:
+                self.memory.update(self.current_sample, train_y, count_dev=count_dev)
+                if opt.can_guard():
+                    opt.run(self.update_iters, guard=count_dev, guard_min=10)
+                    self._guarded_runs += 1
+                    return
+                num_positive = int(count_dev.item())                    # (shape does not fit the resident form: decide here)
+                if num_positive < 10:
+                    self._early_outs_host += 1
+                    return
+                opt.run(self.update_iters)
+                self._solves_host += 1
+                return
         if num_positive is None:
             num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
-        if self.update_optimizer.poll_persistent_abort():      # (the host has just waited for the pixel counts anyway)
+        if opt.poll_persistent_abort():                             # (the host has just waited for the pixel counts anyway)
             self.num_persistent_aborts += 1
         if num_positive < 10:
-            self.num_early_outs += 1
+            self._early_outs_host += 1
             return
         self.memory.update(self.current_sample, train_y, px_count=count_dev)     # soft mask as label, weights from (y > 0.5)  (:217-219)
         if not solve:
             return
-        self.update_optimizer.run(self.update_iters)
-        self.num_solves += 1
+        opt.run(self.update_iters)
+        self._solves_host += 1

@@ -156,6 +156,7 @@ class ResnetFeatureExtractor:
         self._winograd = True
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
         self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
+        self.pass_frames = []
         self.pass_events = None        # a list: every pass appends (start event, end event, FLOPs, conv launches)  (bench.py's roofline leg)
 
     @property
@@ -252,6 +253,7 @@ class ResnetFeatureExtractor:
             if timed:
                 e1.record(cur)
                 self.pass_events.append((e0, e1, self.last_flops, self.last_conv_launches))
+                self.pass_frames.append(B)
             if not capturing:
                 self._pass_done = torch.cuda.Event()
                 self._pass_done.record(cur)

@@ -132,8 +132,23 @@ class GaussNewtonCG:
             self._state[:1].fill_(1.0)
 
     # ---- solver ---------------------------------------------------------------------------
-    def run(self, num_cg_iter, num_gn_iter=None):
+    def can_guard(self):
+        """True if the next run() can take a device-side early-out (``guard``): the problem runs as persistent launches."""
+        if self._generic or not self.persistent:
+            return False
+        self.problem.initialize()                                   # (the plan depends on the number of active samples)
+        return self._persistent_plan() is not None
+
+    def run(self, num_cg_iter, num_gn_iter=None, guard=None, guard_min=10):
+        """``guard`` (device int32, one element): the whole run becomes a no-op ON THE DEVICE when its value is below ``guard_min`` --
+        the reference's "fewer than 10 pixels" early-out (discriminator.py:214) without a device->host read.  Only for problems
+        whose GN iterations run as persistent launches (``can_guard()``)."""
         self.problem.initialize()
+        self._guard = None
+        if guard is not None:
+            if not self.can_guard():
+                raise RuntimeError('GaussNewtonCG.run(guard=...): only for persistent launches (can_guard())')
+            self._guard = (guard, int(guard_min))
         if isinstance(num_cg_iter, int):
             if num_gn_iter is None:
                 raise ValueError('Must specify number of GN iter if CG iter is constant')
@@ -145,8 +160,11 @@ class GaussNewtonCG:
                 self._generic_GN_iter(n)
             return self.external_losses, self.internal_losses, self.residuals
         self._alloc()
-        for n in num_cg_iter:
-            self.run_GN_iter(n)
+        try:
+            for n in num_cg_iter:
+                self.run_GN_iter(n)
+        finally:
+            self._guard = None
         return self.external_losses, self.internal_losses, self.residuals
 
     persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
@@ -164,18 +182,41 @@ class GaussNewtonCG:
         """linearize + run_CG + apply_step of run_GN_iter in ONE launch; host-side bookkeeping as in run_CG."""
         if self._pbuf is None:
             dev = self._buf.device
-            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
-        slabs, qbuf, bar = self._pbuf
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
+                          torch.zeros(2, dtype=torch.int32, device=dev))
+            # the abort flag (bar[2]) mirrored into pinned host memory after every launch: read without waiting (poll_persistent_abort)
+            self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        slabs, qbuf, bar, stats = self._pbuf
+        guard, guard_min = self._guard if getattr(self, '_guard', None) is not None else (None, 0)
         dff = float(self.direction_forget_factor)
         if dff == 0:
             self.reset_state()
         n1, n2, m1, m2 = self.problem.vector_layout()
-        H.call('frtm_cg_run_persistent', H.ptr(a['X']), H.ptr(a['B']), H.ptr(a['c_map']), H.ptr(a['sw']), a['N'], a['c'], a['h'], a['w'],
+        H.call('frtm_cg_run_persistent_guarded', H.ptr(a['X']), H.ptr(a['B']), H.ptr(a['c_map']), H.ptr(a['sw']), a['N'], a['c'], a['h'], a['w'],
                H.ptr(a['w2']), H.ptr(self._buf), H.ptr(self._state), H.ptr(slabs), H.ptr(qbuf), H.ptr(bar),
                int(num_cg_iter), int(self._has_p), int(self._has_p and dff != 0), int(self.fletcher_reeves), int(self.standard_alpha),
-               dff if dff != 0 else 1.0, float(a['lam2']), 1.0 / m1, float(self.step_alpha))
+               dff if dff != 0 else 1.0, float(a['lam2']), 1.0 / m1, float(self.step_alpha),
+               None if guard is None else guard.data_ptr(), guard_min, H.ptr(stats))
         self._has_p = True
         self._persistent_launched = True
+        if guard is not None:
+            self._abort_host.copy_(bar[2:3], non_blocking=True)
+
+    def reset_persistent_counts(self):
+        if self._pbuf is not None:
+            self._pbuf[3].zero_()
+
+    def persistent_counts(self):
+        """(completed persistent launches, launches that took the device-side early-out) so far.  SYNCHRONISES."""
+        if self._pbuf is None:
+            return 0, 0
+        a, b = self._pbuf[3].tolist()
+        return int(a), int(b)
+
+    def peek_persistent_abort(self):
+        """Non-blocking look at the abort flag as of the last guarded launch whose mirror copy has landed (may lag by one launch).
+        True -> the caller should call poll_persistent_abort() (which waits, clears the flag and switches to the multi-kernel form)."""
+        return self._pbuf is not None and int(self._abort_host[0]) != 0
 
     def poll_persistent_abort(self):
         """True if a persistent launch since the last poll gave up (its workgroups could not all become resident within the
@@ -188,6 +229,7 @@ class GaussNewtonCG:
         if int(bar[2].item()) == 0:
             return False
         bar.zero_()
+        self._abort_host.zero_()
         self.persistent = False
         return True
 

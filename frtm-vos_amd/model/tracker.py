@@ -22,6 +22,7 @@ per-object memory/filter update -- with the device work re-laid out for one MI35
 from time import time
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -81,6 +82,12 @@ class Tracker(nn.Module):
         self._disc_pool = []
         self.graph_refiner = True
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
+        self.pipeline_passes = False     # two tap sets, passes one ahead on a side stream, a short pass before and a pass beside
+                                         # initialize()'s fits (supersedes early_first_pass / overlap_first_pass / prefetch_stream)
+        self.first_batch = None          # frames of the pipelined first pass (default: feature_batch // 2)
+        self.balance_batches = False     # True: trunk batches of similar size instead of full ones and a short tail (batch_sizes).  Measured
+                                         # at 20 frames: the 8 + 11 split saves 2 ms of trunk time but the long first pass no longer covers
+                                         # initialize()'s host-bound phases: 58 instead of 54 ms per sequence
         self.augmenter = augmenter
         self.augment = augmenter.augment_first_frame
         self.disc_params = disc_params
@@ -229,6 +236,10 @@ class Tracker(nn.Module):
         if ytvos_merge:
             outputs = self._ytvos_labels(sequence, outputs, object_ids)
         torch.cuda.synchronize()
+        for t in self.targets.values():                      # (a 4-byte read per object, after the synchronise above)
+            d = t.discriminator
+            if d is not None and d.update_optimizer is not None and d.update_optimizer.poll_persistent_abort():
+                d.num_persistent_aborts += 1
         T = time() - t0
         self._raw_log = None
         return outputs, N / T
@@ -296,16 +307,57 @@ class Tracker(nn.Module):
                 if saved[2] is not None:
                     self.refiner.use_graphs = saved[2]
 
+    def batch_sizes(self, n, fb):
+        """Trunk batches for n tracked frames, at most fb frames each: as few passes as possible, and those of similar size -- a
+        3-frame tail pass after a 16-frame one runs at 76 TFLOP/s, two passes of 8 and 11 frames at 100-110 -- with the cuts on
+        filter re-solve frames (multiples of ``train_skipping``) where that fits, so that no tracking window is split by a cut."""
+        if n <= 0:
+            return []
+        k = -(-n // fb)
+        if k == 1 or not self.balance_batches:
+            return [min(fb, n - i) for i in range(0, n, fb)]
+        q = max(1, int(getattr(self.disc_params, 'train_skipping', 8)))
+        cuts, prev = [], 0
+        for j in range(1, k):
+            ideal = n * j / k
+            c = int(round(ideal / q)) * q
+            lo, hi = max(prev + 1, n - (k - j) * fb), min(prev + fb, n - (k - j))     # what keeps every batch within 1..fb
+            if not lo <= c <= hi:
+                c = min(max(int(round(ideal)), lo), hi)
+            cuts.append(c)
+            prev = c
+        edges = [0] + cuts + [n]
+        return [b - a for a, b in zip(edges[:-1], edges[1:])]
+
     def _frames_with_features(self, frames, fb, ext, persistent):
-        side = torch.cuda.Stream(device=self.device) if (persistent and self.prefetch_stream and torch.cuda.is_available()) else None
-        starts = list(range(1, len(frames), fb))
-        pending = {}                                        # batch start -> (taps, ready event, set index)
+        pipelined = bool(persistent and self.pipeline_passes and torch.cuda.is_available())
+        side = None
+        if pipelined:
+            side = self._first_pass_stream()
+        elif persistent and self.prefetch_stream and torch.cuda.is_available():
+            side = torch.cuda.Stream(device=self.device)
+        # trunk batches [first, last) over the tracked frames 1..; pipelined: a short first batch (it has to be through the trunk
+        # before initialize()'s own pass can start)
+        n_tracked = len(frames) - 1
+        if pipelined:
+            fb0 = max(1, min(fb, int(self.first_batch) if self.first_batch else max(1, fb // 2)))
+            sizes, left = [], n_tracked
+            while left > 0:
+                sizes.append(min(left, fb0 if not sizes else fb))
+                left -= sizes[-1]
+        else:
+            sizes = self.batch_sizes(n_tracked, fb)
+        bounds, i0 = [], 1
+        for size in sizes:
+            bounds.append((i0, i0 + size))
+            i0 += size
+        pending = {}                                        # batch start -> (taps, ready event, frame indices)
 
         def launch(bi, on=None):
-            if bi >= len(starts) or starts[bi] in pending:
+            if bi >= len(bounds) or bounds[bi][0] in pending:
                 return
-            i0 = starts[bi]
-            idx = list(range(i0, min(i0 + fb, len(frames))))
+            i0 = bounds[bi][0]
+            idx = list(range(*bounds[bi]))
             batch = torch.stack([frames[j][0].to(self.device) for j in idx])
             st = on if on is not None else side
             if st is not None:
@@ -325,12 +377,22 @@ class Tracker(nn.Module):
         # Single stream: a pass is enqueued when its first frame is asked for -- by then run_sequence has flushed every window of the
         # previous batch (windows end with the last frame of a trunk batch), so the one persistent tap set can be overwritten.
         # Side stream: one pass AHEAD, into the other tap set.
-        if (side is None and persistent and self.early_first_pass and not self.overlap_first_pass and torch.cuda.is_available()
-                and len(frames) > 1 and len(frames[0][2]) > 0):
+        starts_with_init = len(frames) > 1 and len(frames[0][2]) > 0
+        if pipelined:
+            # Two tap sets, every pass on the side stream, one pass ahead of the frames being tracked.  Around initialize():
+            #   pass 0 (short) is enqueued BEFORE it and runs under its host-bound augmentation (a dozen tiny kernels and two
+            #     device->host reads per object, which only synchronise the main stream);
+            #   initialize()'s own pass (the augmented stacks) follows it (passes are serialised by the extractor);
+            #   pass 1 is enqueued by the hook right after that and runs NEXT TO the target-model fits -- dependent chains of small
+            #     kernels that leave most of the GPU idle on their own.
+            launch(0)
+            if starts_with_init:
+                self._after_init_trunk = lambda: launch(1)
+        elif (side is None and persistent and self.early_first_pass and not self.overlap_first_pass and torch.cuda.is_available()
+                and starts_with_init):
             # The first tracking pass does not depend on initialize(): enqueue it right away on a side stream.  It then runs
-            # while the host is busy with the first-frame augmentation (host-bound: a dozen tiny kernels and two device->host
-            # reads per object), which only synchronises the main stream.  initialize()'s own trunk call follows it (passes are
-            # serialised by the extractor).  One pass only: later passes reuse the single tap set.
+            # while the host is busy with the first-frame augmentation, initialize()'s own trunk call follows it.  One pass only:
+            # later passes reuse the single tap set.
             launch(0, on=self._first_pass_stream())
         elif side is not None:
             if len(frames) > 0 and len(frames[0][2]) > 0:
@@ -340,9 +402,8 @@ class Tracker(nn.Module):
             else:
                 launch(0)
         elif persistent and self.overlap_first_pass and torch.cuda.is_available():
-            # The first pass does not depend on initialize().  initialize() calls this hook right after it has enqueued its own
-            # trunk call: the pass then runs on a side stream next to the target-model fits (chains of small kernels that
-            # leave most of the GPU idle) instead of after them.  One pass only: later passes overwrite the tap set in use.
+            # initialize() calls this hook right after it has enqueued its own trunk call: the pass then runs on a side stream
+            # next to the target-model fits instead of after them.  One pass only: later passes overwrite the tap set in use.
             first = self._first_pass_stream()
             self._after_init_trunk = lambda: launch(0, on=first)
         cache, bi = {}, 0
@@ -452,11 +513,12 @@ class Tracker(nn.Module):
         if active and self.disc_params.update_filters:
             K = masks.shape[1]
             counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)                 # device int32, no sync
+            on_device = all(t.discriminator.guards_on_device() for t in active)
             for f in range(W):
                 for t in active:
                     t.discriminator.advance(cfts[active.index(t)][f:f + 1])
                 solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
-                host = counts[f].tolist() if solve else None                                 # one D2H only on re-solve frames
+                host = counts[f].tolist() if solve and not on_device else None               # (no D2H at all when the early-out runs on the device)
                 for t in active:
                     y1 = masks[f, t.index].unsqueeze(0).unsqueeze(0)
                     if host is not None:
@@ -490,7 +552,7 @@ class Tracker(nn.Module):
         if active and self.disc_params.update_filters:
             counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync
             solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
-            host = counts.tolist() if solve else None                                        # one D2H only on re-solve frames
+            host = counts.tolist() if solve and not all(t.discriminator.guards_on_device() for t in active) else None
             for k, t in enumerate(active):
                 y = self.current_masks[t.index].unsqueeze(0).unsqueeze(0)
                 if host is not None:

@@ -151,6 +151,15 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
                            float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
                            int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                            float lam2, float invM, float step, frtm_stream_t stream);
+/* The same launch with the reference's early-out (discriminator.py:214, "fewer than 10 mask pixels above 0.5: no update") decided on
+ * the DEVICE: guard_count (device int32, e.g. one element of frtm_count_above's output) < guard_min -> the launch returns without
+ * touching anything.  stats (device unsigned[2], optional): [0] += 1 per completed solve, [1] += 1 per guarded early-out.  The host
+ * never waits for the pixel count, so a tracking loop enqueues whole sequences without a device->host read. */
+int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
+                                   float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
+                                   int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
+                                   float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
+                                   frtm_stream_t stream);
 /* One CG iteration's vector work for n <= 1024 in a single workgroup (the 864-element filter problem): slab reduce
  * (q = sum_k slabs[k*stride+i] + lam2 p), <p,q>, alpha, r_prev/x/r updates, and -- unless `last` -- the next direction
  * (beta, p, rho).  Same order of operations as optimizer.py:113-151; replaces frtm_vec_reduce_slabs + frtm_cg_pq +

@@ -509,3 +509,22 @@ def test_file_datasets(tmp_path):
     assert new == [2] and set(lb.unique().tolist()) == {0, 2} and v1[2][2] == []
     with pytest.raises(ValueError):
         YouTubeVOSDataset(yt, '2018', 'jjval_all_frames')
+
+
+def test_trunk_batch_schedule():
+    """Tracker.batch_sizes: every tracked frame in exactly one pass, no pass above the limit; the balanced form needs no more
+    passes than the greedy one, has no tiny tail and cuts on filter re-solve frames where that fits."""
+    from types import SimpleNamespace
+    from frtm_vos_amd.model.tracker import Tracker
+    greedy = SimpleNamespace(balance_batches=False, disc_params=SimpleNamespace(train_skipping=8))
+    even = SimpleNamespace(balance_batches=True, disc_params=SimpleNamespace(train_skipping=8))
+    for fb in (1, 4, 8, 16):
+        for n in range(0, 70):
+            a, b = Tracker.batch_sizes(greedy, n, fb), Tracker.batch_sizes(even, n, fb)
+            for sz in (a, b):
+                assert sum(sz) == n and all(1 <= s <= fb for s in sz), (n, fb, sz)
+            assert len(a) == len(b) == -(-n // fb)
+            if b:
+                assert min(b) >= min(a), (n, fb, a, b)
+    assert Tracker.batch_sizes(greedy, 19, 16) == [16, 3] and Tracker.batch_sizes(even, 19, 16) == [8, 11]
+    assert Tracker.batch_sizes(even, 63, 16) == [16, 16, 16, 15]

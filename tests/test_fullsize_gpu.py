@@ -239,15 +239,16 @@ def test_feature_batching_and_graphs_do_not_change_results():
         assert agree > 0.995, agree        # identical up to fp32 summation order inside the convs (split-K vs none)
 
 
-@pytest.mark.parametrize('prefetch', [False, True])
-def test_yielded_taps_belong_to_their_frames(prefetch):
+@pytest.mark.parametrize('mode', ['single', 'prefetch', 'pipelined'])
+def test_yielded_taps_belong_to_their_frames(mode):
     """frames_with_features hands every frame the taps of THAT frame (the persistent tap buffers are overwritten by later trunk
     passes: a pass must not be enqueued before the frames of the previous one have been consumed)."""
     from frtm_vos_amd.evaluate import Parameters
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
     trk = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=4).get_model().eval()
-    trk.prefetch_stream = prefetch
+    trk.prefetch_stream = mode == 'prefetch'
+    trk.pipeline_passes = mode == 'pipelined'
     seq = SyntheticSequence('s', 14, (128, 160), 1, seed=3)
     seq.preload(DEV)
     ref_ext = ResnetFeatureExtractor('resnet18').to(DEV)

@@ -606,3 +606,64 @@ def test_recycled_target_model_draws_like_a_new_one():
     pj = torch.nn.Conv2d(256, 96, 1, bias=False, device=DEV)
     fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False, device=DEV)
     assert torch.equal(a.project.weight, pj.weight) and torch.equal(a.filter.weight, fl.weight)
+
+
+# ---- device-side early-out of the filter re-solve (no device->host read in the tracking loop) -------------------------------------------
+def test_guarded_persistent_run_skips_or_solves_on_the_device():
+    """GaussNewtonCG.run(guard=count): count < 10 -> the launch leaves filter, solver vectors and state untouched and counts one
+    early-out; count >= 10 -> bit-identical to the unguarded run and counts one solve.  Nothing is read back in between."""
+    N, c, h, w, Hh, Ww = 13, 96, 30, 54, 480, 854
+    mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 3, True)
+    mem2, opt2, wv2, _ = _filter_problem(N, c, h, w, Hh, Ww, 3, True)
+    assert opt.can_guard()
+    few, many = torch.tensor([9], dtype=torch.int32, device=DEV), torch.tensor([10], dtype=torch.int32, device=DEV)
+    w0 = wv.detach().clone()
+    opt.run((10,), guard=few)
+    assert torch.equal(wv, w0) and opt.persistent_counts() == (0, 1)
+    opt.run((10,), guard=many)
+    opt2.run((10,))
+    assert not torch.equal(wv, w0) and torch.equal(wv, wv2) and opt.persistent_counts() == (1, 1)
+    assert torch.equal(opt._buf, opt2._buf) and torch.equal(opt._state, opt2._state)
+    assert not opt.peek_persistent_abort() and not opt.poll_persistent_abort()
+    opt.persistent = False
+    assert not opt.can_guard()
+    with pytest.raises(RuntimeError):
+        opt.run((10,), guard=many)
+
+
+def test_update_decides_the_early_out_on_the_device_like_the_host_path():
+    """Discriminator.update() with a device-resident pixel count: same memory, filter and counters as with the host-side count
+    (the reference's `if num_positive < 10: return`, discriminator.py:214), for a frame sequence that contains early-out frames
+    on insert-only AND on re-solve frames."""
+    from frtm_vos_amd import ops
+    from frtm_vos_amd.model.discriminator import Discriminator
+    g = torch.Generator().manual_seed(5)
+    cin, c, h, w, Hh, Ww = 64, 16, 24, 40, 96, 160
+    x0 = torch.relu(torch.randn(3, cin, h, w, generator=g)).to(DEV)
+    y0 = torch.zeros(3, 1, Hh, Ww)
+    y0[:, 0, 20:60, 30:90] = 1
+    frames = [torch.relu(torch.randn(1, cin, h, w, generator=g)).to(DEV) for _ in range(8)]
+    masks = []
+    for t in range(8):
+        m = torch.zeros(1, 1, Hh, Ww)
+        if t not in (2, 5):                               # frames 3 and 6 (1-based): empty masks; frame 6 is a re-solve frame
+            m[0, 0, 22 + t:58, 28:88 - t] = 0.9
+        masks.append(m.to(DEV))
+    outs = []
+    for on_device in (False, True):
+        torch.manual_seed(3)
+        d = Discriminator(in_channels=cin, c_channels=c, init_iters=(2, 3), update_iters=(4,), memory_size=6, train_skipping=2,
+                          pixel_weighting=dict(method='hinge', tf=0.1), device=DEV, layer='layer4')
+        d.device_early_out = on_device
+        d.init(x0, y0.to(DEV))
+        assert d.guards_on_device() == on_device
+        for ft, m in zip(frames, masks):
+            d.apply(ft)
+            d.update(m, count_dev=ops.count_above(m.view(1, Hh, Ww)))
+        outs.append((d.filter.weight.detach().clone(), d.memory.weights.clone(), d.memory.samples.clone(), d.num_solves, d.num_early_outs,
+                     d.memory.insert_counts, d._guarded_runs))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3] == 3 and a[4] == b[4] == 1, (a[3:], b[3:])          # re-solve frames 2, 4, 8; early-out on 6
+    assert a[6] == 0 and b[6] == 4
+    assert a[5] == (6, 1) and b[5] == (6, 2), (a[5], b[5])       # (inserts done, guarded inserts skipped): the host path never reaches frame 6's insert
