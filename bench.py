@@ -585,6 +585,8 @@ def main():
         'path_counters': counters,
         'mean_iou_vs_synthetic_gt': round(quality, 4),
         'device_mallocs_in_timed_region': mallocs,
+        # wall-clock until the host had enqueued the whole sequence (run_sequence, before its final synchronise)
+        'host_enqueue_ms_total': round(1e3 * getattr(tracker, 'last_enqueue_seconds', 0.0), 2),
         'valid': bool(ok.item() > 0),
     }
     if rank == 0 and world == 1:

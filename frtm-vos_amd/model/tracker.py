@@ -235,6 +235,7 @@ class Tracker(nn.Module):
         flush()
         if ytvos_merge:
             outputs = self._ytvos_labels(sequence, outputs, object_ids)
+        self.last_enqueue_seconds = time() - t0              # host done; the GPU may still be working (no host wait while tracking)
         torch.cuda.synchronize()
         for t in self.targets.values():                      # (a 4-byte read per object, after the synchronise above)
             d = t.discriminator

@@ -2,6 +2,7 @@
 
     python tools/make_profiles.py r01 gpurun_out/prof_final gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 gpurun_out/bench_r1_final.json
 """
+import bisect
 import collections
 import csv
 import json
@@ -26,7 +27,17 @@ with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w') as f:
 tr = list(csv.DictReader(open(os.path.join(prof, 'prof_kernel_trace.csv'))))
 b = json.loads(open(bench).read().strip().splitlines()[-1])
 t1 = max(int(r['End_Timestamp']) for r in tr)
-win = 0.8 * b['ms_per_step'] * b['steps'] * 1e6           # the last 80 % of the timed sequence: tracked frames only
+# The process ends with host-side validation (path counters, IoU against the synthetic ground truth): a few small framework kernels
+# after a multi-millisecond host gap.  The timed sequence ends where the last kernel before that gap ends.
+_ends = sorted(int(r['End_Timestamp']) for r in tr)
+_starts = sorted(int(r['Start_Timestamp']) for r in tr)
+for _e in reversed(_ends):
+    _i = bisect.bisect_right(_starts, _e)
+    if _i < len(_starts) and _starts[_i] - _e > 4e6 and t1 - _e < 80e6:
+        t1 = _e
+        break
+tr = [r for r in tr if int(r['Start_Timestamp']) < t1]
+win = 0.7 * b['ms_per_step'] * b['steps'] * 1e6           # the last 70 % of the timed sequence: tracked frames only
 tot, cnt = collections.Counter(), collections.Counter()
 for r in tr:
     if int(r['Start_Timestamp']) >= t1 - win:
@@ -56,7 +67,7 @@ inwin = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) 
 occupied = union_ns([(a, e) for a, e, _ in inwin])
 with open(os.path.join(out, tag + '_steady_state.csv'), 'w') as f:
     w = csv.writer(f)
-    w.writerow(['# same run; last %.0f ms of the trace = tracked frames of the timed sequence; at least one kernel running %.1f %% of the '
+    w.writerow(['# same run; last %.0f ms of the timed sequence = tracked frames only; at least one kernel running %.1f %% of the '
                 'window; summed kernel durations = %.2f x the occupied time (concurrent trunk lanes / refiner branches overlap)'
                 % (win / 1e6, 100 * occupied / win, busy / max(occupied, 1))])
     w.writerow(['Name', 'Calls', 'TotalMs', 'AvgUs', 'PercentOfBusy'])
