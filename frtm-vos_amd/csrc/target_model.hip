@@ -106,28 +106,44 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
   const unsigned char* lb8 = (const unsigned char*)labels + (size_t)n * H * W;
   const float* lbf = (const float*)labels + (size_t)n * H * W;
-  for (int Y = Y0 + (lane >> 5); Y < Y1; Y += 2) {
-    int yi0, yi1; float yl0, yl1;
-    taps(Y, sy, h, yi0, yi1, yl0, yl1);
-    const float wyc = tap_w(ci, yi0, yi1, yl0, yl1);
-    if (wyc == 0.f) continue;
-    const float wy0 = tap_w(ci - 1, yi0, yi1, yl0, yl1), wy2 = tap_w(ci + 1, yi0, yi1, yl0, yl1);
-    for (int X = X0 + (lane & 31); X < X1; X += 32) {
-      int xi0, xi1; float xl0, xl1;
-      taps(X, sx, w, xi0, xi1, xl0, xl1);
-      const float wxc = tap_w(cj, xi0, xi1, xl0, xl1);
-      if (wxc == 0.f) continue;
-      const float wx0 = tap_w(cj - 1, xi0, xi1, xl0, xl1), wx2 = tap_w(cj + 1, xi0, xi1, xl0, xl1);
-      const float lab = U8 ? (float)lb8[(size_t)Y * W + X] : lbf[(size_t)Y * W + X];
-      const float ys = lab > 0.5f ? 1.f : 0.f;
-      float w2 = wf * ys + wb * (1.f - ys);              // pw^2
-      if (pwn) { const float pv = pwn[(size_t)Y * W + X]; w2 = pv * pv; }
-      const float m = w2 * wyc * wxc;
-      const float my0 = m * wy0, myc = m * wyc, my2 = m * wy2;
-      acc[0] += my0 * wx0; acc[1] += my0 * wxc; acc[2] += my0 * wx2;
-      acc[3] += myc * wx0; acc[4] += myc * wxc; acc[5] += myc * wx2;
-      acc[6] += my2 * wx0; acc[7] += my2 * wxc; acc[8] += my2 * wx2;
-      acc[9] += m * lab;
+  // A cell's window is ~36 x 36 pixels (the feature stride is 16): lane = column, and the rows go in blocks of NB whose loads are
+  // all issued before the first one is used -- the kernel is one memory latency per block instead of one per row.
+  constexpr int NB = 20;
+  for (int Xb = X0; Xb < X1; Xb += 64) {
+    const int X = Xb + lane;
+    const bool xin = X < X1;
+    int xi0, xi1; float xl0, xl1;
+    taps(xin ? X : X0, sx, w, xi0, xi1, xl0, xl1);
+    const float wxc = xin ? tap_w(cj, xi0, xi1, xl0, xl1) : 0.f;
+    const float wx0 = tap_w(cj - 1, xi0, xi1, xl0, xl1), wx2 = tap_w(cj + 1, xi0, xi1, xl0, xl1);
+    for (int Yb = Y0; Yb < Y1; Yb += NB) {
+      float lab_[NB], pv_[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const int Y = Yb + r;
+        const bool ok = xin && Y < Y1;
+        const size_t o = (size_t)(ok ? Y : Y0) * W + (ok ? X : X0);
+        lab_[r] = U8 ? (float)lb8[o] : lbf[o];
+        pv_[r] = pwn ? pwn[o] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const int Y = Yb + r;
+        int yi0, yi1; float yl0, yl1;
+        taps(min(Y, Y1 - 1), sy, h, yi0, yi1, yl0, yl1);
+        const float wyc = Y < Y1 ? tap_w(ci, yi0, yi1, yl0, yl1) : 0.f;
+        const float wy0 = tap_w(ci - 1, yi0, yi1, yl0, yl1), wy2 = tap_w(ci + 1, yi0, yi1, yl0, yl1);
+        const float lab = lab_[r];
+        const float ys = lab > 0.5f ? 1.f : 0.f;
+        float w2 = wf * ys + wb * (1.f - ys);              // pw^2
+        if (pwn) w2 = pv_[r] * pv_[r];
+        const float m = w2 * wyc * wxc;                    // 0 outside the cell's support (and for the padding lanes / rows)
+        const float my0 = m * wy0, myc = m * wyc, my2 = m * wy2;
+        acc[0] += my0 * wx0; acc[1] += my0 * wxc; acc[2] += my0 * wx2;
+        acc[3] += myc * wx0; acc[4] += myc * wxc; acc[5] += myc * wx2;
+        acc[6] += my2 * wx0; acc[7] += my2 * wxc; acc[8] += my2 * wx2;
+        acc[9] += m * lab;
+      }
     }
   }
 #pragma unroll

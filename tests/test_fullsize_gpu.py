@@ -87,7 +87,8 @@ def test_operator_properties_fullsize():
         opp = (1 - di) * 3 + (1 - dj)
         lhs = B[:, a, max(0, -di):h - max(0, di), max(0, -dj):w - max(0, dj)]
         rhs = B[:, opp, max(0, di):h - max(0, -di), max(0, dj):w - max(0, -dj)]
-        assert (lhs - rhs).abs().max() < 1e-4
+        # (two sums of ~1300 products each in another order: a few 1e-6 of the entries, which are ~30 here)
+        assert (lhs - rhs).abs().max() < 1e-5 * float(B.abs().max())
     # monotone decrease of phi(x) = 1/2 x^T A x - b^T x over the CG iterations of one run
     prob.linearize(opt.x, opt._buf[0])
     b = opt._buf[0].clone()

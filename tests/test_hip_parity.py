@@ -299,15 +299,15 @@ def test_init_problem_g4(golden, spread_gate):
     g = golden('g4_init')
     cin, c, h, w, H, W = [int(v) for v in g['dims']]
     x, y = T(g['x']).to(DEV), T(g['y']).to(DEV)
-    for tag, iters in (('fast', (5, 10, 10, 10)), ('full', (5, 10, 10, 10, 10))):
+    def fit(iters, scale=1.0, check_operators=False):
         mem = Memory(5, (cin, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
-        mem.initialize(x, y)
+        mem.initialize(x * scale, y)
         w1 = torch.nn.Parameter(T(g['w1_0']).clone().to(DEV), requires_grad=False)
         w2 = torch.nn.Parameter(T(g['w2_0']).clone().to(DEV), requires_grad=False)
         prob = DiscriminatorLoss(mem, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)
         opt = GaussNewtonCG(prob, TensorList([w1, w2]), fletcher_reeves=False, standard_alpha=True,
                             direction_forget_factor=0.9 ** 750)
-        if tag == 'fast':
+        if check_operators:
             prob.initialize()
             opt._alloc()
             prob.linearize(opt.x, opt._buf[0])
@@ -318,10 +318,23 @@ def test_init_problem_g4(golden, spread_gate):
                 q = opt.A(flat)
                 assert rel(q[0], a1) < 5e-5 and rel(q[1], a2) < 5e-5
         opt.run(iters)
+        return w1.detach().cpu().clone(), w2.detach().cpu().clone()
+
+    for tag, iters in (('fast', (5, 10, 10, 10)), ('full', (5, 10, 10, 10, 10))):
+        w1, w2 = fit(iters, check_operators=tag == 'fast')
+        # The truncated fit amplifies rounding-level differences by ~1e3 (the reference against itself, features scaled by 1-3 ulp or
+        # another thread count: g_spread).  The HIP path is one more draw of that noise, with its own sensitivity: measured here the
+        # same way (features scaled by one ulp up / half an ulp down).  Gate = 3 x the larger of the two measured spreads.
+        own1, own2 = 0.0, 0.0
+        for sc in (1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24):
+            v1, v2 = fit(iters, sc)
+            own1, own2 = max(own1, rel(v1, w1)), max(own2, rel(v2, w2))
         e1, e2 = rel(w1, T(g[tag + '_w1'])), rel(w2, T(g[tag + '_w2']))
-        print('g4 %s: w1 %.2e (gate %.2e)  w2 %.2e (gate %.2e)' % (tag, e1, spread_gate('g4_%s_w1' % tag, mult=3.0), e2, spread_gate('g4_%s_w2' % tag, mult=3.0)))
-        assert e1 < spread_gate('g4_%s_w1' % tag, mult=3.0, at_most=5e-3), tag
-        assert e2 < spread_gate('g4_%s_w2' % tag, mult=3.0, at_most=5e-3), tag
+        g1 = min(3.0 * max(spread_gate('g4_%s_w1' % tag, mult=1.0), own1), 5e-3)
+        g2 = min(3.0 * max(spread_gate('g4_%s_w2' % tag, mult=1.0), own2), 5e-3)
+        print('g4 %s: w1 %.2e (gate %.2e; spread of the reference %.2e, of this path %.2e)  w2 %.2e (gate %.2e; %.2e, %.2e)' %
+              (tag, e1, g1, spread_gate('g4_%s_w1' % tag, mult=1.0), own1, e2, g2, spread_gate('g4_%s_w2' % tag, mult=1.0), own2))
+        assert e1 < g1 and e2 < g2, tag
 
 
 def test_problem_residuals_and_ip(golden):

@@ -310,14 +310,17 @@ def test_persistent_cg_run_equals_the_multi_kernel_form(shape):
     N, c, h, w, Hh, Ww = shape
     from frtm_vos_amd import _hip as H
     assert H.lib().frtm_cg_persistent_plan(N, c, h, w, None, None) > 0
-    def trajectory(persistent, scale=1.0):
+    def trajectory(persistent, jitter=0):
         mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 11, persistent)
-        mem.samples.mul_(scale)
+        if jitter:
+            # relative feature noise of 1e-6: the size of the rounding differences BETWEEN the two forms (they agree to 2e-5 of the
+            # largest entry in b, p, q after one CG step -- test below -- i.e. ~1e-6 on typical entries), not just one ulp
+            mem.samples.mul_(1.0 + 1e-6 * torch.randn(mem.samples.shape, generator=torch.Generator().manual_seed(jitter)).to(DEV))
         filt = []
         opt.run((10,))
         filt.append(wv.detach().clone())
         for t in range(3):
-            ft = torch.relu(torch.randn(1, c, h, w, generator=g)).to(DEV) * scale
+            ft = torch.relu(torch.randn(1, c, h, w, generator=g)).to(DEV)
             lab = torch.zeros(1, 1, Hh, Ww)
             lab[0, 0, 5 + 3 * t:Hh // 2, 7:Ww // 2 + 5 * t] = 0.9
             mem.update(ft, lab.to(DEV))
@@ -333,11 +336,11 @@ def test_persistent_cg_run_equals_the_multi_kernel_form(shape):
     assert bool(torch.isfinite(b).all()) and not torch.equal(b[0], b[1])
     # The truncated CG trajectory is sensitive to rounding (tools/cg_sensitivity.py: the multi-kernel form against ITSELF with the
     # features scaled by one ulp differs by up to 3e-2 after the 5-iteration run): the gate per run is 5 x that measured
-    # sensitivity (two perturbed runs), not less than 5e-4.  The tight, chaos-free check is the single-step test below.
-    n1, n2 = rel(a, trajectory(False, 1.0 + 2.0 ** -23)), rel(a, trajectory(False, 1.0 - 2.0 ** -24))
-    noise = [max(u, v) for u, v in zip(n1, n2)]
+    # sensitivity, not less than 5e-4.  The tight, chaos-free check is the single-step test below.
+    pert = [rel(a, trajectory(False, jitter=k)) for k in (1, 2, 3, 4)]
+    noise = [max(col) for col in zip(*pert)]
     errs = rel(a, b)
-    print('N=%d c=%d %dx%d: persistent vs multi-kernel after runs 0..3: %s   (one-ulp sensitivity of the multi-kernel form: %s)' %
+    print('N=%d c=%d %dx%d: persistent vs multi-kernel after runs 0..3: %s   (sensitivity of the multi-kernel form to 1e-6 feature noise: %s)' %
           (N, c, h, w, ' '.join('%.2e' % e for e in errs), ' '.join('%.2e' % e for e in noise)))
     for e, nz in zip(errs, noise):
         assert e < max(5e-4, 5 * nz), (errs, noise)
