@@ -13,7 +13,8 @@ from frtm_vos_amd.lib.synthetic import SyntheticSequence  # noqa: E402
 
 torch.set_grad_enabled(False)
 trk = Parameters(None, device='cuda:0').get_model().eval()
-seq = SyntheticSequence('p', 3, (480, 854), 2, seed=1)
+NOBJ = int(os.environ.get('NOBJ', '2'))
+seq = SyntheticSequence('p', 3, (480, 854), NOBJ, seed=1)
 seq.preload('cuda:0')
 image, labels, new_objects = seq[0]
 image, labels = image.cuda(), labels.cuda()
