@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
     ap.add_argument('--no-trunk-graph', action='store_true', help='trunk passes launched kernel by kernel instead of replayed as hipGraphs')
+    ap.add_argument('--no-fold-tail', action='store_true', help='a last trunk batch of 1-3 frames stays a pass of its own instead of joining the one before it')
     ap.add_argument('--balance', action='store_true', help='trunk batches of similar size instead of full ones and a short tail pass (measured slower at 20 frames)')
     ap.add_argument('--pipeline', action='store_true', help='two tap sets, trunk passes one ahead on a side stream, one beside the first-frame fits (measured: +4 %% frames/s at 20 frames, trunk passes 5 %% slower)')
     ap.add_argument('--first-batch', type=int, default=0, help='frames of the pipelined first trunk pass (default: trunk batch / 2)')
@@ -423,6 +424,8 @@ def main():
     tracker.prefetch_stream = args.overlap
     tracker.pipeline_passes = args.pipeline
     tracker.balance_batches = args.balance
+    if args.no_fold_tail:
+        tracker.fold_tail = 0
     tracker.first_batch = args.first_batch or None
     tracker.graph_trunk = not args.no_trunk_graph
     tracker.refiner.parallel_levels = not args.refiner_serial

@@ -189,3 +189,36 @@ def require_gpu(t, what):
         raise RuntimeError('%s: tensor is on %s; the FRTM hot path runs on the GPU only (no CPU fallback)' % (what, t.device))
     if t.dtype != torch.float32 and t.dtype != torch.uint8:
         raise TypeError('%s: expected float32/uint8, got %s' % (what, t.dtype))
+
+
+class capture:
+    """``with capture(graph, pool=None):`` -- torch.cuda.graph with the garbage collector under control.
+
+    hipGraph stream capture runs in GLOBAL mode: a hipFree / hipStreamDestroy / hipGraphExecDestroy issued by ANY code of the
+    process while a capture is open is illegal.  Destructors issue exactly those (a dead tracker's native trunk, its graphs,
+    its memory pool), and Python's cyclic collector runs them whenever an allocation count crosses its threshold -- also in the
+    middle of a capture.  So: collect BEFORE the capture opens, keep the collector off while it is open."""
+
+    def __init__(self, graph, pool=None):
+        self._ctx = torch.cuda.graph(graph, pool=pool) if pool is not None else torch.cuda.graph(graph)
+        self._was_enabled = False
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._was_enabled:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._was_enabled:
+                gc.enable()

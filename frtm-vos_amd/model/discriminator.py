@@ -455,7 +455,7 @@ class Discriminator(nn.Module):
         if ent is None or ent['key'] != key or ent['mem0'] is not mem0 or ent['memory'] is not memory:
             self._init_problems(mem0, memory)                    # buffers of problems / solvers exist before the capture
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with H.capture(g):
                 opt = self._init_body(mem0, memory, None)
             ent = self._ws['init_graph'] = dict(key=key, graph=g, mem0=mem0, memory=memory, opt=opt, w1T=self._w1T)
         ent['graph'].replay()

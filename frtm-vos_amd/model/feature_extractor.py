@@ -309,7 +309,7 @@ class ResnetFeatureExtractor:
         ent['in'] = x.clone()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with H.capture(g):
             self._forward(ent['in'], ent['out'], args, stop)
         ent['stats'] = (self.last_flops, self.last_conv_launches)
         ent['graph'], ent['gen'] = g, H.lib().frtm_backbone_generation(self._handle)

@@ -224,7 +224,7 @@ class SegNetwork(nn.Module):
             g = torch.cuda.CUDAGraph()
             # all refiner graphs (one per window shape / object count / tap set) share one memory pool: they never run
             # concurrently and each output is consumed before the next replay, so the pool is as large as the largest graph
-            with torch.cuda.graph(g, pool=self._pool):
+            with H.capture(g, pool=self._pool):
                 out = self._forward_hip(static_scores, features, image_size, self._side if self.parallel_levels else None)
             entry = (g, static_scores, out, [features[L] for L in self.ft_channels])
         self._graphs[key] = entry                                            # (re-)insert as most recently used

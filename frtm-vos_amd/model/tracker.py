@@ -74,6 +74,8 @@ class Tracker(nn.Module):
                                          # with 2 objects -- the fits just run slower next to the trunk kernels --, +3 % with 5)
         self._after_init_trunk = None
         self._first_stream = None
+        self._main_stream = None
+        self.own_stream = True           # run_sequence moves off the framework's default (null) stream
         self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self.share_first_sample = True   # the un-augmented frame (sample 0 of every object's stack) passes the trunk once per frame
@@ -85,6 +87,7 @@ class Tracker(nn.Module):
         self.pipeline_passes = False     # two tap sets, passes one ahead on a side stream, a short pass before and a pass beside
                                          # initialize()'s fits (supersedes early_first_pass / overlap_first_pass / prefetch_stream)
         self.first_batch = None          # frames of the pipelined first pass (default: feature_batch // 2)
+        self.fold_tail = max(0, int(feature_batch) // 4 - 1)   # a last trunk batch of at most this many frames is folded into the one before it
         self.balance_batches = False     # True: trunk batches of similar size instead of full ones and a short tail (batch_sizes).  Measured
                                          # at 20 frames: the 8 + 11 split saves 2 ms of trunk time but the long first pass no longer covers
                                          # initialize()'s host-bound phases: 58 instead of 54 ms per sequence
@@ -170,7 +173,23 @@ class Tracker(nn.Module):
         torch.cuda.synchronize()
 
     def run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
-        """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included.
+        """Reference tracker.py:103-163: frames / wall-clock of the loop below, initialize() included.  Called on the framework's
+        DEFAULT stream, the sequence runs on a stream of this tracker instead: the default stream is the legacy null stream, which
+        synchronises implicitly with every blocking stream of the process -- measured: the first host-side read of initialize()
+        waited 18 ms for a trunk-graph replay in flight on the side stream.  The caller's stream waits for the results."""
+        cur = torch.cuda.current_stream(self.device) if torch.cuda.is_available() and torch.device(self.device).type == 'cuda' else None
+        if cur is None or cur != torch.cuda.default_stream(self.device) or not self.own_stream:
+            return self._run_sequence(sequence, speedrun, ytvos_merge)
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(device=self.device)
+        self._main_stream.wait_stream(cur)
+        with torch.cuda.stream(self._main_stream):
+            out = self._run_sequence(sequence, speedrun, ytvos_merge)
+        cur.wait_stream(self._main_stream)
+        return out
+
+    def _run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
+        """The loop of run_sequence on the current stream.
 
         ``ytvos_merge``: label decoding of the reference's YouTube-VOS validation fork instead (ytvos_validation/tracker.py:84-116):
         the per-object masks BEFORE the per-frame merge are kept for the whole sequence, the ground truth is re-inserted on every
@@ -309,14 +328,19 @@ class Tracker(nn.Module):
                     self.refiner.use_graphs = saved[2]
 
     def batch_sizes(self, n, fb):
-        """Trunk batches for n tracked frames, at most fb frames each: as few passes as possible, and those of similar size -- a
+        """Trunk batches for n tracked frames, fb frames each (the last one up to fb + fold_tail).  With ``balance_batches``: at most
+        fb frames each, as few passes as possible, and those of similar size -- a
         3-frame tail pass after a 16-frame one runs at 76 TFLOP/s, two passes of 8 and 11 frames at 100-110 -- with the cuts on
         filter re-solve frames (multiples of ``train_skipping``) where that fits, so that no tracking window is split by a cut."""
         if n <= 0:
             return []
         k = -(-n // fb)
         if k == 1 or not self.balance_batches:
-            return [min(fb, n - i) for i in range(0, n, fb)]
+            sizes = [min(fb, n - i) for i in range(0, n, fb)]
+            # a tail of a few frames does not fill the GPU (3 frames: 77 TFLOP/s against 113 for 16): it joins the pass before it
+            if len(sizes) > 1 and sizes[-1] <= int(getattr(self, 'fold_tail', 0)):
+                sizes[-2:] = [sizes[-2] + sizes[-1]]
+            return sizes
         q = max(1, int(getattr(self.disc_params, 'train_skipping', 8)))
         cuts, prev = [], 0
         for j in range(1, k):

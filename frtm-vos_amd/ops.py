@@ -11,7 +11,15 @@ _workspaces = {}
 
 def workspace(device, elems):
     """Grow-only fp32 scratch (split-K partials) per device AND stream: convs enqueued on different streams may run
-    concurrently and must not share partial sums."""
+    concurrently and must not share partial sums.
+
+    Inside a hipGraph capture the scratch is NOT taken from this process-wide cache: a tensor allocated while a capture is open comes
+    from the capturing graph's private memory pool, and a cache entry allocated there outlives its pool -- the next tracker's graphs
+    then baked in an address inside a pool that had been released with the previous tracker's refiner (the process aborted in a
+    later replay, tools/graph_lifetime_check.py).  A capture gets a fresh allocation from its own pool instead, like every other
+    intermediate of the captured sequence: the pool keeps it for the graph's lifetime."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(int(elems), device=device, dtype=torch.float32)
     key = (device, H.stream())
     w = _workspaces.get(key)
     if w is None or w.numel() < elems:

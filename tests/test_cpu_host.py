@@ -516,7 +516,8 @@ def test_trunk_batch_schedule():
     passes than the greedy one, has no tiny tail and cuts on filter re-solve frames where that fits."""
     from types import SimpleNamespace
     from frtm_vos_amd.model.tracker import Tracker
-    greedy = SimpleNamespace(balance_batches=False, disc_params=SimpleNamespace(train_skipping=8))
+    greedy = SimpleNamespace(balance_batches=False, fold_tail=0, disc_params=SimpleNamespace(train_skipping=8))
+    folded = SimpleNamespace(balance_batches=False, fold_tail=3, disc_params=SimpleNamespace(train_skipping=8))
     even = SimpleNamespace(balance_batches=True, disc_params=SimpleNamespace(train_skipping=8))
     for fb in (1, 4, 8, 16):
         for n in range(0, 70):
@@ -527,4 +528,9 @@ def test_trunk_batch_schedule():
             if b:
                 assert min(b) >= min(a), (n, fb, a, b)
     assert Tracker.batch_sizes(greedy, 19, 16) == [16, 3] and Tracker.batch_sizes(even, 19, 16) == [8, 11]
+    assert Tracker.batch_sizes(folded, 19, 16) == [19] and Tracker.batch_sizes(folded, 35, 16) == [16, 19]
+    assert Tracker.batch_sizes(folded, 20, 16) == [16, 4] and Tracker.batch_sizes(folded, 3, 16) == [3]
+    for n in range(0, 70):
+        sz = Tracker.batch_sizes(folded, n, 16)
+        assert sum(sz) == n and all(1 <= v <= 19 for v in sz) and (len(sz) < 2 or sz[-1] > 3)
     assert Tracker.batch_sizes(even, 63, 16) == [16, 16, 16, 15]

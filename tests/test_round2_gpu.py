@@ -670,3 +670,16 @@ def test_update_decides_the_early_out_on_the_device_like_the_host_path():
     assert a[3] == b[3] == 3 and a[4] == b[4] == 1, (a[3:], b[3:])          # re-solve frames 2, 4, 8; early-out on 6
     assert a[6] == 0 and b[6] == 4
     assert a[5] == (6, 1) and b[5] == (6, 2), (a[5], b[5])       # (inserts done, guarded inserts skipped): the host path never reaches frame 6's insert
+
+
+def test_trackers_created_and_destroyed_one_after_the_other():
+    """A tracker's hipGraphs must not depend on anything that dies with an EARLIER tracker (its refiner's graph memory pool in
+    particular): one process serves many configurations / datasets.  Regression: a process-wide split-K scratch allocated inside the
+    first tracker's refiner capture was baked into the second tracker's graphs and vanished with the first tracker's pool; the
+    process aborted in a replay.  Runs in a subprocess so that a crash fails this test instead of the session."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KEEP='del', FIRST='[(8, 2, True), (4, 1, True)]')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'graph_lifetime_check.py')], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DONE' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
