@@ -355,6 +355,19 @@ def init_sweep(tracker, size, dev, counts=(1, 2, 5), reps=3):
     objects starting on frame 0, HIP events, best of `reps` after one untimed call."""
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     out = {}
+    # (on a stream of its own, like Tracker.run_sequence: the default stream is the legacy null stream)
+    own = torch.cuda.Stream(device=dev)
+    own.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(own):
+        _init_sweep(tracker, size, dev, counts, reps, out)
+    torch.cuda.current_stream().wait_stream(own)
+    tracker.release_targets()
+    tracker.clear()
+    return out
+
+
+def _init_sweep(tracker, size, dev, counts, reps, out):
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
     for n in counts:
         seq = SyntheticSequence('init%d' % n, 1, size, n, seed=40 + n)
         seq.preload(dev)
@@ -373,9 +386,6 @@ def init_sweep(tracker, size, dev, counts=(1, 2, 5), reps=3):
             if r > 0:
                 best = ms if best is None else min(best, ms)
         out[str(n)] = round(best, 3)
-    tracker.release_targets()
-    tracker.clear()
-    return out
 
 
 def launch_check(args, rank, world):
