@@ -683,3 +683,13 @@ def test_trackers_created_and_destroyed_one_after_the_other():
     env = dict(os.environ, KEEP='del', FIRST='[(8, 2, True), (4, 1, True)]')
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'graph_lifetime_check.py')], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'DONE' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_edge_case_sequences():
+    """tools/edge_cases.py: sequences of 1 and 2 frames, objects appearing on frame 1 / on the last frame, 17 objects, odd and minimal
+    frame sizes, a scene that goes blank -- one label image per frame, only known ids, the tracker usable afterwards."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'edge_cases.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'EDGE OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
