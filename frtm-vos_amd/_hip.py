@@ -45,6 +45,12 @@ SIGNATURES = {
     'frtm_cg_persistent_plan': (I, [I, I, I, I, P, P]),
     'frtm_cg_run_persistent': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P]),
     'frtm_cg_run_persistent_guarded': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P, I, P, P]),
+    'frtm_filter_scores_split': (I, [P, P, I, I, I, I, I, P, P]),
+    'frtm_stencil_sum': (I, [P, P, P, P, I, I, I, I, P, P]),
+    'frtm_joint_scores_composed': (I, [P, P, I, P, P, I, I, I, I, I, P, P]),
+    'frtm_joint_q_pq_composed': (I, [P, I, I, I, P, F, P, I, I, I, F, P, P, F, P, P, P, P]),
+    'frtm_joint_compose': (I, [P, P, I, I, P, P]),
+    'frtm_joint_expand': (I, [P, I, P, I, I, F, P, F, P, P]),
     'frtm_vec_axpy': (I, [P, F, P, I, P]),
     'frtm_transpose2d': (I, [P, I, I, P, P]),
     'frtm_conv_pack_weights': (I, [P, I, I, I, I, P, P, P]),

@@ -211,6 +211,182 @@ __global__ __launch_bounds__(256) void k_joint_q_pq(const float* __restrict__ g1
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Composed form of the joint problem's projection part (round 2).  The score is ONE channel, so "project 1x1 (Cin -> c), then
+// filter 3x3 (c -> 1)" is a single 3x3 filter over the raw features with the composed kernel K = p1 . w2:
+//     K[ci][tap] = sum_c p1[ci][c] * w2[c][tap]          (k_joint_compose)
+// and the gradient with respect to the projection needs only the raw features' 3x3 weight gradient G[ci][tap] against the
+// one-channel map t:
+//     g1[ci][c] = sum_tap G[ci][tap] * w2[c][tap]         (k_joint_expand, which also sums the per-sample slabs of G)
+// Both directions then read the raw features once (33 MB at 480p, HBM-bound) instead of running a 1.6-GFLOP GEMM each
+// (Cin x c x pixels: the c = 96 intermediate channels are never formed).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_joint_compose(const float* __restrict__ p1, const float* __restrict__ w2, int Cin, int c,
+                                                       float* __restrict__ K) {
+  __shared__ float wl[9 * 128];                      // w2 transposed: [tap][c], c <= 128
+  for (int i = threadIdx.x; i < 9 * c; i += 256) { const int cc = i / 9, tap = i - cc * 9; wl[tap * 128 + cc] = w2[i]; }
+  __syncthreads();
+  // one wave per input channel: lanes stride over c, nine running sums, wave reduction
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 4 + wid;
+  if (ci >= Cin) return;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int cc = lane; cc < c; cc += 64) {
+    const float pv = p1[(size_t)ci * c + cc];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += pv * wl[t * 128 + cc];
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = wave_sum(acc[t]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) K[(size_t)ci * 9 + t] = acc[t];
+  }
+}
+
+// q1[ci][c] = sign * ( sum_tap (sum_slab G[slab][ci][tap]) * w2[c][tap]  +  lam2 * p1[ci][c] )
+__global__ __launch_bounds__(256) void k_joint_expand(const float* __restrict__ G, int nslab, const float* __restrict__ w2, int Cin, int c,
+                                                      float lam2, const float* __restrict__ p1, float sign, float* __restrict__ q1) {
+  __shared__ float gl[4][9];
+  const int ci0 = blockIdx.x * 4;
+  if (threadIdx.x < 36) {
+    const int k = threadIdx.x / 9, tap = threadIdx.x - k * 9, ci = ci0 + k;
+    float v = 0.f;
+    if (ci < Cin)
+      for (int sl = 0; sl < nslab; ++sl) v += G[((size_t)sl * Cin + ci) * 9 + tap];          // fixed order: deterministic
+    gl[k][tap] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * c; i += 256) {
+    const int k = i / c, cc = i - k * c, ci = ci0 + k;
+    if (ci >= Cin) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v += gl[k][t] * w2[cc * 9 + t];
+    const size_t o = (size_t)ci * c + cc;
+    q1[o] = sign * (v + lam2 * p1[o]);
+  }
+}
+
+
+// ---- composed form, forward: partial score maps of the raw features under the composed kernel (channel groups 0 .. CS-1) and the
+// filter-direction term Z * p2 as map CS, in ONE launch.  Row form like k_scores2_rows; block (row block of a sample, map index).
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void k_scores_composed(const float* __restrict__ X, const float* __restrict__ K, int Cx,
+                                                              const float* __restrict__ Z, const float* __restrict__ p2, int Cz, int h, int w,
+                                                              float* __restrict__ out) {
+  __shared__ float red[NW][R][64];
+  const int rbs = (h + R - 1) / R, N = gridDim.x / rbs, CS = gridDim.y - 1;
+  const int n = blockIdx.x / rbs, y0 = (blockIdx.x - n * rbs) * R;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool xin = lane < w, has_l = lane > 0, has_r = lane + 1 < w;
+  const bool zsrc = (int)blockIdx.y == CS;
+  const int C = zsrc ? Cz : Cx;
+  const int Cs = zsrc ? Cz : (Cx + CS - 1) / CS, cb = zsrc ? 0 : blockIdx.y * Cs, ce = min(C, cb + Cs);
+  const int cper = (Cs + NW - 1) / NW;
+  const int c0 = cb + wid * cper, c1 = min(ce, c0 + cper);
+  const float* Xn = (zsrc ? Z : X) + (size_t)n * C * h * w;
+  const float* f = zsrc ? p2 : K;
+  float acc[R];
+#pragma unroll
+  for (int o = 0; o < R; ++o) acc[o] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    const float* Xc = Xn + (size_t)c * h * w;
+    const float* fc = f + c * 9;
+    float m[R + 2], l[R + 2], r[R + 2];
+#pragma unroll
+    for (int i = 0; i < R + 2; ++i) {
+      const int yy = y0 - 1 + i;
+      m[i] = (xin && (unsigned)yy < (unsigned)h) ? Xc[yy * w + lane] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < R + 2; ++i) {
+      const float up = __shfl_up(m[i], 1, 64), dn = __shfl_down(m[i], 1, 64);
+      l[i] = has_l ? up : 0.f;
+      r[i] = has_r ? dn : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        acc[o] += l[o + dy] * fc[dy * 3 + 0];
+        acc[o] += m[o + dy] * fc[dy * 3 + 1];
+        acc[o] += r[o + dy] * fc[dy * 3 + 2];
+      }
+  }
+#pragma unroll
+  for (int o = 0; o < R; ++o) red[wid][o][lane] = acc[o];
+  __syncthreads();
+  float* on = out + ((size_t)blockIdx.y * N + n) * h * w;
+  for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
+    const int o = i >> 6, x = i & 63, yy = y0 + o;
+    if (x < w && yy < h) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; k += 4) sum += (red[k][o][x] + red[k + 1][o][x]) + (red[k + 2][o][x] + red[k + 3][o][x]);
+      on[yy * w + x] = sum;
+    }
+  }
+}
+
+// ---- composed form, tail: q1 = sign * ( expand(sum of the raw features' gradient slabs) + lam1 p1 ),  q2 = sign * ( sum of the
+// projected features' gradient slabs + lam2 p2 ) and (partial != null) the per-block partials of <p,q> (and <p,r>).
+// Part 1: a wave per input channel -- lanes 0..8 add the slabs of its nine taps, the sums are broadcast, every lane forms its c's.
+__global__ __launch_bounds__(256) void k_joint_q_pq_c(const float* __restrict__ GX, int nslabX, int Cin, int c, const float* __restrict__ w2,
+                                                       float lam1, const float* __restrict__ slabs, int nslab, int stride, int n2, float lam2,
+                                                       const float* __restrict__ p1, const float* __restrict__ p2, float sign,
+                                                       float* __restrict__ q, const float* __restrict__ r, float* __restrict__ partial) {
+  __shared__ float red[16];
+  __shared__ float wl[128 * 9];
+  for (int i = threadIdx.x; i < c * 9; i += 256) wl[i] = w2[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n1 = Cin * c;
+  float d = 0.f, e = 0.f;
+  for (int ci = blockIdx.x * 4 + wid; ci < Cin; ci += gridDim.x * 4) {
+    float gv = 0.f;
+    if (lane < 9)
+      for (int sl = 0; sl < nslabX; ++sl) gv += GX[((size_t)sl * Cin + ci) * 9 + lane];      // fixed order: deterministic
+    float G[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) G[t] = __shfl(gv, t, 64);
+    for (int cc = lane; cc < c; cc += 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v += G[t] * wl[cc * 9 + t];
+      const size_t i = (size_t)ci * c + cc;
+      const float pv = p1[i];
+      v = sign * (v + lam1 * pv);
+      q[i] = v;
+      d += pv * v;
+      if (r) e += pv * r[i];
+    }
+  }
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < n2; j += gridDim.x * 256) {
+    const float* sp = slabs + j;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += sp[(size_t)(k + u) * stride];
+    }
+    for (; k < nslab; ++k) a[0] += sp[(size_t)k * stride];
+    const float pv = p2[j];
+    const float v = sign * ((((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + lam2 * pv);
+    q[n1 + j] = v;
+    d += pv * v;
+    if (r) e += pv * r[n1 + j];
+  }
+  if (partial) {
+    d = block_sum(d, red);
+    e = block_sum(e, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = d; partial[blockIdx.x * 2 + 1] = e; }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +426,44 @@ int frtm_joint_q_pq(const float* g1, int n1, float lam1, const float* slabs, int
                     const float* p2, float sign, float* q, const float* r, float* partial, frtm_stream_t stream) {
   FRTM_CHECK_ARG(g1 && slabs && p1 && p2 && q && n1 > 0 && n2 > 0 && nslab > 0, "frtm_joint_q_pq: bad argument");
   k_joint_q_pq<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(g1, n1, lam1, slabs, nslab, stride, n2, lam2, p1, p2, sign, q, r, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+
+int frtm_joint_compose(const float* p1, const float* w2, int Cin, int c, float* K, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(p1 && w2 && K && Cin > 0 && c > 0 && c <= 128, "frtm_joint_compose: bad argument (c <= 128)");
+  k_joint_compose<<<ceil_div(Cin, 4), 256, 0, (hipStream_t)stream>>>(p1, w2, Cin, c, K);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_joint_expand(const float* G, int nslab, const float* w2, int Cin, int c, float lam2, const float* p1, float sign, float* q1,
+                      frtm_stream_t stream) {
+  FRTM_CHECK_ARG(G && w2 && p1 && q1 && nslab >= 1 && Cin > 0 && c > 0, "frtm_joint_expand: bad argument");
+  k_joint_expand<<<ceil_div(Cin, 4), 256, 0, (hipStream_t)stream>>>(G, nslab, w2, Cin, c, lam2, p1, sign, q1);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+
+int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const float* Z, const float* p2, int Cz, int N, int h, int w,
+                               int splits, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && K && Z && p2 && partial && N > 0 && Cx > 0 && Cz > 0 && h > 0 && w > 0 && w <= 64 && splits >= 1 && splits <= 64,
+                 "frtm_joint_scores_composed: bad argument (maps at most 64 wide)");
+  dim3 g(ceil_div(h, 3) * N, splits + 1);
+  k_scores_composed<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, K, Cx, Z, p2, Cz, h, w, partial);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_joint_q_pq_composed(const float* GX, int nslabX, int Cin, int c, const float* w2, float lam1, const float* slabs, int nslab,
+                             int stride, int n2, float lam2, const float* p1, const float* p2, float sign, float* q, const float* r,
+                             float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(GX && w2 && slabs && p1 && p2 && q && nslabX > 0 && nslab > 0 && Cin > 0 && c > 0 && c <= 128 && n2 > 0,
+                 "frtm_joint_q_pq_composed: bad argument");
+  k_joint_q_pq_c<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(GX, nslabX, Cin, c, w2, lam1, slabs, nslab, stride, n2, lam2, p1, p2, sign, q, r,
+                                                                   partial);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

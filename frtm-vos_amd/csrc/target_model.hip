@@ -276,8 +276,13 @@ __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __r
   const int n = logical / rbs, y0 = (logical - n * rbs) * R;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool xin = lane < w, has_l = lane > 0, has_r = lane + 1 < w;
-  const int cper = (C + NW - 1) / NW;
-  const int c0 = wid * cper, c1 = min(C, c0 + cper);
+  // gridDim.y > 1: channel split -- block (., cs) sums the channels [cs * Cs, (cs + 1) * Cs) only and writes partial map cs
+  // (out + cs * N * h * w; the consumer adds the maps up): for few samples and many channels (the raw 1024-channel features of the
+  // first-frame problem: 5 samples x 10 row blocks would be 50 workgroups)
+  const int CS = gridDim.y, Cs = (C + CS - 1) / CS, cb = blockIdx.y * Cs, ce = min(C, cb + Cs);
+  const int cper = (Cs + NW - 1) / NW;
+  const int c0 = cb + wid * cper, c1 = min(ce, c0 + cper);
+  out += (size_t)blockIdx.y * (nb / rbs) * h * w;
   float acc[R];
 #pragma unroll
   for (int o = 0; o < R; ++o) acc[o] = 0.f;
@@ -322,9 +327,11 @@ __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __r
 }
 
 // t = sw[n] * (B s - c): elementwise with a 3x3 neighbourhood of s.
+// nsum > 1: s is given as nsum partial maps (stride N*h*w), summed here in a fixed order.
 __global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ B, const float* __restrict__ c, const float* __restrict__ sw,
-                                                  const float* __restrict__ s, int h, int w, float* __restrict__ t) {
+                                                  const float* __restrict__ s, int h, int w, float* __restrict__ t, int nsum = 1) {
   const int n = blockIdx.y, hw = h * w;
+  const size_t pstride = (size_t)gridDim.y * hw;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= hw) return;
   const int py = p / w, px = p % w;
@@ -336,10 +343,40 @@ __global__ __launch_bounds__(256) void k_stencil(const float* __restrict__ B, co
 #pragma unroll
     for (int dj = 0; dj < 3; ++dj) {
       const int yy = py + di - 1, xx = px + dj - 1;
-      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) acc += Bn[(size_t)(di * 3 + dj) * hw + p] * sn[yy * w + xx];
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+        float sv = sn[yy * w + xx];
+        for (int k = 1; k < nsum; ++k) sv += sn[k * pstride + yy * w + xx];
+        acc += Bn[(size_t)(di * 3 + dj) * hw + p] * sv;
+      }
     }
   if (c) acc -= c[(size_t)n * hw + p];
   t[(size_t)n * hw + p] = sw[n] * acc;
+}
+
+// The same over the SUM of nsum partial score maps (frtm_filter_scores_split): one workgroup per sample adds the maps up into a
+// zero-bordered LDS copy first (nsum coalesced loads per pixel), then takes the 3x3 neighbourhoods from there.
+__global__ __launch_bounds__(1024) void k_stencil_sum(const float* __restrict__ B, const float* __restrict__ c, const float* __restrict__ sw,
+                                                       const float* __restrict__ sp, int nsum, int N, int h, int w, float* __restrict__ t) {
+  extern __shared__ float sl[];                       // (h+2) x (w+2)
+  const int n = blockIdx.x, hw = h * w, wp = w + 2;
+  for (int i = threadIdx.x; i < (h + 2) * wp; i += 1024) sl[i] = 0.f;
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    float v = sp[(size_t)n * hw + p];
+    for (int k = 1; k < nsum; ++k) v += sp[((size_t)k * N + n) * hw + p];
+    sl[(p / w + 1) * wp + (p % w) + 1] = v;
+  }
+  __syncthreads();
+  const float* Bn = B + (size_t)n * 9 * hw;
+  const float swn = sw[n];
+  for (int p = threadIdx.x; p < hw; p += 1024) {
+    const int i = (p / w + 1) * wp + (p % w) + 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) acc += Bn[(size_t)d * hw + p] * sl[i + (d / 3 - 1) * wp + (d % 3 - 1)];
+    if (c) acc -= c[(size_t)n * hw + p];
+    t[(size_t)n * hw + p] = swn * acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -795,6 +832,29 @@ int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int 
   } else {
     dim3 g(ceil_div(h * w, 64), N);
     k_filter_scores<64><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate);
+  }
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_filter_scores_split(const float* X, const float* f, int N, int C, int h, int w, int splits, float* partial, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && f && partial && N > 0 && C > 0 && h > 0 && w > 0 && w <= 64 && splits >= 1 && splits <= 64,
+                 "frtm_filter_scores_split: bad argument (maps at most 64 wide)");
+  dim3 g(ceil_div(h, 3) * N, splits);
+  k_filter_scores_rows<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, f, C, h, w, partial, 0);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_stencil_sum(const float* B, const float* c, const float* sw, const float* partials, int nsum, int N, int h, int w, float* t,
+                     frtm_stream_t stream) {
+  FRTM_CHECK_ARG(B && sw && partials && t && N > 0 && nsum >= 1, "frtm_stencil_sum: bad argument");
+  const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);
+  if (lds <= 64 * 1024) {
+    k_stencil_sum<<<N, 1024, lds, (hipStream_t)stream>>>(B, c, sw, partials, nsum, N, h, w, t);
+  } else {
+    dim3 g(ceil_div(h * w, 256), N);
+    k_stencil<<<g, 256, 0, (hipStream_t)stream>>>(B, c, sw, partials, h, w, t, nsum);
   }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;

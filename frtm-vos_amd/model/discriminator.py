@@ -87,6 +87,10 @@ class DiscriminatorLoss(MinimizationProblem):
             # streams and must not meet in the per-stream scratch of ops.conv2d
             self.ws = torch.empty(max(4 * cap * self.c * self.hw, 32 * C * self.c), device=dev)
             self._xt_for = None
+            self.Kp = torch.empty(C * 9, device=dev)                 # composed 3x3 kernel over the raw features
+            self.partialX = torch.empty(cap * 8, C * 9, device=dev)  # per-sample slabs of the raw features' 3x3 weight gradient
+            self.CS = 8                                              # channel groups of the composed score pass over the raw features
+            self._sp_all = torch.empty((self.CS + 1) * cap * self.hw, device=dev)   # their partial score maps (+ one for the filter-direction term)
 
     def rebind(self, filter_regs, precond, filter_weight, project_weight=None):
         """Serve another object on the same memory: new variables / regularisation, cached derived data dropped."""
@@ -106,7 +110,7 @@ class DiscriminatorLoss(MinimizationProblem):
             self.mem.refresh_normals()
             self._xt_for = None
         self.N = self.mem.current_size
-        if self.joint and self._xt_for != (self.mem.samples.data_ptr(), self.N):
+        if self.joint and not self._use_composed() and self._xt_for != (self.mem.samples.data_ptr(), self.N):
             for n in range(self.N):
                 ops.transpose2d(self.mem.samples[n].view(self.Cin, self.hw), out=self.Xt[n])
             self._xt_for = (self.mem.samples.data_ptr(), self.N)
@@ -153,6 +157,36 @@ class DiscriminatorLoss(MinimizationProblem):
         return dict(X=m.samples, B=m.normal_B, c_map=m.normal_c, sw=m.weights, N=self.N, c=self.c, h=self.h, w=self.w,
                     w2=self.w2.data, lam2=self.filter_regs[0] ** 2)
 
+    # True: the projection part of the joint problem in its composed form (csrc/joint_fit.hip: k_joint_compose / k_joint_expand):
+    # the raw features are filtered with the composed 3x3 kernel p1 . w2 and their 3x3 weight gradient is expanded through w2 --
+    # two HBM-bound passes over the raw features per operator application instead of two Cin x c x pixels GEMMs.
+    composed = True
+
+    def _use_composed(self):
+        return bool(self.joint and self.composed and self.c <= 128 and self.w <= 64 and 4 * (self.h + 2) * (self.w + 2) <= 64 * 1024)
+
+    @property
+    def sp(self):
+        """(CS+1, N, h*w) view of the partial score maps, dense for the current number of samples."""
+        return self._sp_all[:(self.CS + 1) * self.N * self.hw].view(self.CS + 1, self.N, self.hw)
+
+    def _composed_scores(self, p2):
+        """Partial score maps: the raw features under the composed kernel in CS channel groups, Z under p2 as one more map."""
+        H.call('frtm_joint_scores_composed', H.ptr(self.mem.samples), H.ptr(self.Kp), self.Cin, H.ptr(self.Z), H.ptr(p2), self.c,
+               self.N, self.h, self.w, self.CS, H.ptr(self.sp))
+
+    def _composed_tail(self, p1, p2, sign, q, r, partial):
+        """The two 3x3 weight gradients against t (raw features: Cin x 9 slabs, projected features: c x 9 slabs), then q = sign *
+        [ expand(raw slabs) through w2 + lam1 p1 | projected slabs + lam2 p2 ] and the partials of <p,q> (and <p,r>)."""
+        N, c = self.N, self.c
+        px = H.lib().frtm_filter_wgrad_parts(N, self.Cin)
+        pz = H.lib().frtm_filter_wgrad_parts(N, c)
+        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), N, self.Cin, self.h, self.w, px, H.ptr(self.partialX))
+        H.call('frtm_filter_wgrad', H.ptr(self.Z), H.ptr(self.t), N, c, self.h, self.w, pz, H.ptr(self.partial))
+        H.call('frtm_joint_q_pq_composed', H.ptr(self.partialX), N * px, self.Cin, c, H.ptr(self.w2.data), self.filter_regs[0] ** 2,
+               H.ptr(self.partial), N * pz, c * 9, c * 9, self.filter_regs[1] ** 2, p1, p2, float(sign), H.ptr(q),
+               None if r is None else H.ptr(r), None if partial is None else H.ptr(partial))
+
     def _project_grad(self, lam2, pvec, sign, out):
         """g1^T (Cin,c) = sum_{n,pix} X[n,pix,ci] * D[n,pix,c]  as one GEMM with K = N*h*w."""
         H.call('frtm_filter_igrad', H.ptr(self.t), H.ptr(self.w2.data), self.N, self.c, self.h, self.w, H.ptr(self.D), 1)
@@ -172,6 +206,10 @@ class DiscriminatorLoss(MinimizationProblem):
         ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
         ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
+        if self._use_composed():
+            self._stencil(True)
+            self._composed_tail(H.ptr(self.w1T), H.ptr(self.w2.data), -1.0, b, None, None)
+            return
         if not self._use_fused():
             self._stencil(True)
             self._filter_grad(self.Z, self.filter_regs[1] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b[n1:]))
@@ -187,6 +225,8 @@ class DiscriminatorLoss(MinimizationProblem):
             self._stencil(False)
             self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(p), 1.0, H.ptr(q))
             return
+        if self._use_composed():
+            return self.apply_A_pq(p, q, None, None)
         if self._use_fused():
             return self.apply_A_pq(p, q, None, None)
         n1 = self.Cin * c
@@ -200,9 +240,13 @@ class DiscriminatorLoss(MinimizationProblem):
 
     fused = True        # joint problem: merged glue kernels (csrc/joint_fit.hip), 8 instead of 13 launches per CG iteration
 
+    def has_pq(self):
+        """Does apply_A_pq leave the partials of <p,q> itself (the solver then skips its own frtm_cg_pq launch)?"""
+        return bool(self.joint and (self._use_composed() or self._use_fused()))
+
     def _use_fused(self):
         # k_joint_mid keeps two zero-padded score maps in LDS: grids beyond ~135x135 take the launch-per-step chain
-        return self.fused and 8 * (self.h + 2) * (self.w + 2) <= 144 * 1024
+        return self.fused and not self._use_composed() and 8 * (self.h + 2) * (self.w + 2) <= 144 * 1024
 
     def apply_A_pq(self, p, q, r, partial):
         """Joint problem: q <- J^T J p + lam^2 p and, if ``partial`` is given, the partial dot products <p,q> (and <p,r>) the
@@ -210,6 +254,15 @@ class DiscriminatorLoss(MinimizationProblem):
         N, c = self.N, self.c
         n1 = self.Cin * c
         p1, p2 = p[:n1], p[n1:]
+        if self._use_composed():
+            # 6 launches: compose, scores (raw features under p1 . w2 in channel groups + the filter-direction term), stencil over
+            # the summed maps, the two weight gradients, q / <p,q>
+            H.call('frtm_joint_compose', H.ptr(p1), H.ptr(self.w2.data), self.Cin, c, H.ptr(self.Kp))
+            self._composed_scores(p2)
+            m = self.mem
+            H.call('frtm_stencil_sum', H.ptr(m.normal_B), None, H.ptr(m.weights), H.ptr(self.sp), self.CS + 1, N, self.h, self.w, H.ptr(self.t))
+            self._composed_tail(H.ptr(p1), H.ptr(p2), 1.0, q, r, partial)
+            return
         ops.conv2d(self.mem.samples, p1, c, out=self.P, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
         H.call('frtm_filter_scores2', H.ptr(self.P), H.ptr(self.w2.data), H.ptr(self.Z), H.ptr(p2), N, c, self.h, self.w, H.ptr(self.s))
         self._joint_tail(False, H.ptr(p1), H.ptr(p2), 1.0, q, r, partial)

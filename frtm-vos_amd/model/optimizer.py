@@ -273,7 +273,7 @@ class GaussNewtonCG:
             H.call('frtm_cg_direction', r, p, n1, n2, im1, im2, int(self._has_p), apply_dff if ii == 0 else 0, fr,
                    dff if dff != 0 else 1.0, st, part)
             self._has_p = True
-            if getattr(pr, 'joint', False) and getattr(pr, 'fused', False) and pr._use_fused():
+            if getattr(pr, 'joint', False) and hasattr(pr, 'has_pq') and pr.has_pq():
                 # the problem's last kernel also leaves the partials of <p,q> (and <p,r>): no separate frtm_cg_pq launch
                 pr.apply_A_pq(self._buf[3], self._buf[4], None if self.standard_alpha else self._buf[1], self._partial)
             else:

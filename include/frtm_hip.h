@@ -74,6 +74,12 @@ int frtm_memory_insert(const float* src, float* dst_base, int len, const int* sl
 int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w,
                        float* out, int accumulate, frtm_stream_t stream);
 
+/* frtm_filter_scores with the channels split over `splits` groups of workgroups (maps at most 64 wide): partial map k
+ * (partial + k*N*h*w) holds the sum over channel group k; for FEW samples with MANY channels (raw trunk features of the
+ * first-frame problem).  frtm_stencil_sum is frtm_stencil over the sum of nsum such partial maps (fixed summation order). */
+int frtm_filter_scores_split(const float* X, const float* f, int N, int C, int h, int w, int splits, float* partial, frtm_stream_t stream);
+int frtm_stencil_sum(const float* B, const float* c, const float* sw, const float* partials, int nsum, int N, int h, int w, float* t,
+                     frtm_stream_t stream);
 /* t[n,i,j] = sw[n] * ( sum_{di,dj} B[n,(di,dj),i,j] * s[n,i+di,j+dj]  -  (c ? c[n,i,j] : 0) ).
  * This is U^T W^2 (U s - y) of the reference residual (discriminator.py:47-49) in low-res form. */
 int frtm_stencil(const float* B, const float* c, const float* sw, const float* s, int N, int h, int w,
@@ -136,6 +142,23 @@ int frtm_joint_mid(const float* s, const float* Bm, const float* cm, const float
                    int h, int w, int parts, float* partial, float* D, frtm_stream_t stream);
 int frtm_joint_q_pq(const float* g1, int n1, float lam1, const float* slabs, int nslab, int stride, int n2, float lam2, const float* p1,
                     const float* p2, float sign, float* q, const float* r, float* partial, frtm_stream_t stream);
+/* Fused launches of the composed form.  frtm_joint_scores_composed: partial score maps 0..splits-1 = channel groups of X under K,
+ * map `splits` = Z under p2 (partial: (splits+1, N, h, w); sum them with frtm_stencil_sum).  frtm_joint_q_pq_composed: q1 as
+ * frtm_joint_expand, q2 = sign * (sum of the nslab slabs of the projected features' gradient + lam2 p2) and, if partial != NULL,
+ * the FRTM_CG_BLOCKS per-block partials of <p,q> (and <p,r> if r != NULL) that frtm_cg_update sums. */
+int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const float* Z, const float* p2, int Cz, int N, int h, int w,
+                               int splits, float* partial, frtm_stream_t stream);
+int frtm_joint_q_pq_composed(const float* GX, int nslabX, int Cin, int c, const float* w2, float lam1, const float* slabs, int nslab,
+                             int stride, int n2, float lam2, const float* p1, const float* p2, float sign, float* q, const float* r,
+                             float* partial, frtm_stream_t stream);
+/* Composed form of the joint problem's projection part (the score has ONE channel, so project-then-filter is a single 3x3
+ * filter over the raw features): K[ci][tap] = sum_c p1[ci][c] w2[c][tap] (p1 as (Cin,c), w2 as (c,9), c <= 128) -- use K with
+ * frtm_filter_scores on the raw features -- and, for the gradient, q1[ci][c] = sign * ( sum_tap (sum_slab G[slab][ci][tap])
+ * w2[c][tap] + lam2 p1[ci][c] ) from the per-sample slabs G that frtm_filter_wgrad leaves for the raw features against t.
+ * Replaces the two Cin x c x pixels GEMMs of an operator application (discriminator.py:165-176 through autograd). */
+int frtm_joint_compose(const float* p1, const float* w2, int Cin, int c, float* K, frtm_stream_t stream);
+int frtm_joint_expand(const float* G, int nslab, const float* w2, int Cin, int c, float lam2, const float* p1, float sign, float* q1,
+                      frtm_stream_t stream);
 
 /* One whole Gauss-Newton iteration of the FILTER problem (reference optimizer.py:77-153 on the problem of
  * discriminator.py:187-196) as ONE persistent launch: right-hand side b = -(J^T f(w2) + lam2 w2), `iters` CG steps with the
