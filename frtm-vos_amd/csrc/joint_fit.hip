@@ -343,27 +343,30 @@ __global__ __launch_bounds__(256) void k_joint_q_pq_c(const float* __restrict__ 
   __shared__ float wl[128 * 9];
   for (int i = threadIdx.x; i < c * 9; i += 256) wl[i] = w2[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n1 = Cin * c;
   float d = 0.f, e = 0.f;
-  for (int ci = blockIdx.x * 4 + wid; ci < Cin; ci += gridDim.x * 4) {
+  // Part 1 in two rounds of independent loads: the block's input channels [ci0, ci1) -- first all their slab sums (one (ci, tap)
+  // pair per thread) into LDS, then every thread forms its share of the (ci, c) outputs from them.
+  __shared__ float gs[32 * 9];
+  const int per = (Cin + gridDim.x - 1) / gridDim.x;                 // <= 32 channels per block (Cin <= 32 * FRTM_CG_BLOCKS)
+  const int ci0 = blockIdx.x * per, ci1 = min(Cin, ci0 + per);
+  for (int i = threadIdx.x; i < (ci1 - ci0) * 9; i += 256) {
     float gv = 0.f;
-    if (lane < 9)
-      for (int sl = 0; sl < nslabX; ++sl) gv += GX[((size_t)sl * Cin + ci) * 9 + lane];      // fixed order: deterministic
-    float G[9];
+    for (int sl = 0; sl < nslabX; ++sl) gv += GX[((size_t)sl * Cin + ci0) * 9 + i];          // fixed order: deterministic
+    gs[i] = gv;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < (ci1 - ci0) * c; o += 256) {
+    const int k = o / c, cc = o - k * c;
+    float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) G[t] = __shfl(gv, t, 64);
-    for (int cc = lane; cc < c; cc += 64) {
-      float v = 0.f;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) v += G[t] * wl[cc * 9 + t];
-      const size_t i = (size_t)ci * c + cc;
-      const float pv = p1[i];
-      v = sign * (v + lam1 * pv);
-      q[i] = v;
-      d += pv * v;
-      if (r) e += pv * r[i];
-    }
+    for (int t = 0; t < 9; ++t) v += gs[k * 9 + t] * wl[cc * 9 + t];
+    const size_t i = (size_t)(ci0 + k) * c + cc;
+    const float pv = p1[i];
+    v = sign * (v + lam1 * pv);
+    q[i] = v;
+    d += pv * v;
+    if (r) e += pv * r[i];
   }
   for (int j = blockIdx.x * 256 + threadIdx.x; j < n2; j += gridDim.x * 256) {
     const float* sp = slabs + j;
@@ -460,8 +463,8 @@ int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const flo
 int frtm_joint_q_pq_composed(const float* GX, int nslabX, int Cin, int c, const float* w2, float lam1, const float* slabs, int nslab,
                              int stride, int n2, float lam2, const float* p1, const float* p2, float sign, float* q, const float* r,
                              float* partial, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(GX && w2 && slabs && p1 && p2 && q && nslabX > 0 && nslab > 0 && Cin > 0 && c > 0 && c <= 128 && n2 > 0,
-                 "frtm_joint_q_pq_composed: bad argument");
+  FRTM_CHECK_ARG(GX && w2 && slabs && p1 && p2 && q && nslabX > 0 && nslab > 0 && Cin > 0 && Cin <= 32 * FRTM_CG_BLOCKS && c > 0 && c <= 128 &&
+                 n2 > 0, "frtm_joint_q_pq_composed: bad argument (Cin <= %d, c <= 128)", 32 * FRTM_CG_BLOCKS);
   k_joint_q_pq_c<<<FRTM_CG_BLOCKS, 256, 0, (hipStream_t)stream>>>(GX, nslabX, Cin, c, w2, lam1, slabs, nslab, stride, n2, lam2, p1, p2, sign, q, r,
                                                                    partial);
   FRTM_LAUNCH_CHECK();
