@@ -293,29 +293,39 @@ __global__ __launch_bounds__(64 * NW) void k_scores_composed(const float* __rest
   float acc[R];
 #pragma unroll
   for (int o = 0; o < R; ++o) acc[o] = 0.f;
-  for (int c = c0; c < c1; ++c) {
-    const float* Xc = Xn + (size_t)c * h * w;
-    const float* fc = f + c * 9;
-    float m[R + 2], l[R + 2], r[R + 2];
+  // UN channels per trip: all of their row loads are issued before the first one is used (a wave has only a handful of channels;
+  // one channel per trip made the kernel a chain of memory latencies)
+  constexpr int UN = 4;
+  for (int cg = c0; cg < c1; cg += UN) {
+    float m[UN][R + 2];
 #pragma unroll
-    for (int i = 0; i < R + 2; ++i) {
-      const int yy = y0 - 1 + i;
-      m[i] = (xin && (unsigned)yy < (unsigned)h) ? Xc[yy * w + lane] : 0.f;
-    }
+    for (int u = 0; u < UN; ++u) {
+      const float* Xc = Xn + (size_t)min(cg + u, c1 - 1) * h * w;
 #pragma unroll
-    for (int i = 0; i < R + 2; ++i) {
-      const float up = __shfl_up(m[i], 1, 64), dn = __shfl_down(m[i], 1, 64);
-      l[i] = has_l ? up : 0.f;
-      r[i] = has_r ? dn : 0.f;
-    }
-#pragma unroll
-    for (int o = 0; o < R; ++o)
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        acc[o] += l[o + dy] * fc[dy * 3 + 0];
-        acc[o] += m[o + dy] * fc[dy * 3 + 1];
-        acc[o] += r[o + dy] * fc[dy * 3 + 2];
+      for (int i = 0; i < R + 2; ++i) {
+        const int yy = y0 - 1 + i;
+        m[u][i] = (xin && cg + u < c1 && (unsigned)yy < (unsigned)h) ? Xc[yy * w + lane] : 0.f;
       }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float* fc = f + (size_t)min(cg + u, c1 - 1) * 9;
+      float l[R + 2], r[R + 2];
+#pragma unroll
+      for (int i = 0; i < R + 2; ++i) {
+        const float up = __shfl_up(m[u][i], 1, 64), dn = __shfl_down(m[u][i], 1, 64);
+        l[i] = has_l ? up : 0.f;
+        r[i] = has_r ? dn : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          acc[o] += l[o + dy] * fc[dy * 3 + 0];
+          acc[o] += m[u][o + dy] * fc[dy * 3 + 1];
+          acc[o] += r[o + dy] * fc[dy * 3 + 2];
+        }
+    }
   }
 #pragma unroll
   for (int o = 0; o < R; ++o) red[wid][o][lane] = acc[o];

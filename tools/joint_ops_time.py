@@ -52,3 +52,5 @@ pz = H.lib().frtm_filter_wgrad_parts(N, c)
 tm('wgrad Z parts=%d' % pz, lambda: H.call('frtm_filter_wgrad', H.ptr(Z), H.ptr(t), N, c, h, w, pz, H.ptr(partZ)))
 tm('expand (sum 5 slabs, x w2)', lambda: H.call('frtm_joint_expand', H.ptr(partX), N, H.ptr(w2), Cin, c, 1e-4, H.ptr(p1), 1.0, H.ptr(q1)))
 tm('GEMM forward X . p1 (the form it replaces)', lambda: ops.conv2d(X, p1, c, shape=(N, Cin, h, w), w_pitch=c))
+spc = torch.empty(CS + 1, N, h * w, device=dev)
+tm('scores composed (X in 8 groups + Z), one launch', lambda: H.call('frtm_joint_scores_composed', H.ptr(X), H.ptr(Kp), Cin, H.ptr(Z), H.ptr(p2), c, N, h, w, CS, H.ptr(spc)))
