@@ -33,10 +33,6 @@ for fb, lanes, graphs in first:
     if k == 'del':
         import gc
         del trk, params, seq, labels
-        if os.environ.get('CLEARWS'):
-            from frtm_vos_amd import ops
-            print('workspaces', [(k[1], v.numel()) for k, v in ops._workspaces.items()], flush=True)
-            ops._workspaces.clear()
         gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache(); print('destroyed at a quiet point', flush=True)
     if k == 'del_nocache':
         import gc
