@@ -693,3 +693,17 @@ def test_edge_case_sequences():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'edge_cases.py')], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'EDGE OK' in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize('shape', [(24, 480, 854), (3, 479, 853), (5, 64, 64), (1, 7, 3)])
+def test_count_above_exact(shape):
+    """ops.count_above (vector loads, one atomic per workgroup): exact counts for aligned and misaligned planes, odd sizes, tails."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    m = torch.rand(*shape, generator=g).to(DEV)
+    assert torch.equal(ops.count_above(m).cpu(), (m > 0.5).flatten(1).sum(1).cpu().int())
+    flat = m.flatten()[1:]
+    n = flat.numel() // shape[0]
+    mm = flat[:n * shape[0]].view(shape[0], n)                     # base address off by 4 bytes
+    assert torch.equal(ops.count_above(mm).cpu(), (mm > 0.5).sum(1).cpu().int())
+    assert int(ops.count_above(torch.zeros(2, 33, 17, device=DEV)).sum()) == 0
