@@ -186,6 +186,9 @@ class Tracker(nn.Module):
         with torch.cuda.stream(self._main_stream):
             out = self._run_sequence(sequence, speedrun, ytvos_merge)
         cur.wait_stream(self._main_stream)
+        for o in out[0]:                                     # the label images were allocated on this tracker's stream and are
+            if torch.is_tensor(o) and o.is_cuda:             # now the caller's: tell the allocator who reads them
+                o.record_stream(cur)
         return out
 
     def _run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
