@@ -39,7 +39,8 @@ def test_pixel_weights_g1(golden, ops):
     assert torch.all(ones == 1)
 
 
-@pytest.mark.parametrize('H,W,h,w', [(48, 70, 6, 9), (480, 854, 30, 54), (64, 64, 64, 64), (37, 53, 5, 7)])
+@pytest.mark.parametrize('H,W,h,w', [(48, 70, 6, 9), (480, 854, 30, 54), (64, 64, 64, 64), (37, 53, 5, 7), (240, 432, 15, 27), (360, 640, 23, 40),
+                                     (482, 850, 31, 54), (720, 1280, 45, 80), (64, 64, 2, 2), (33, 47, 3, 3)])
 def test_normal_build(H, W, h, w):
     from frtm_vos_amd.model.memory import Memory
     g = gen(H * W)
