@@ -197,34 +197,58 @@ def require_gpu(t, what):
         raise TypeError('%s: expected float32/uint8, got %s' % (what, t.dtype))
 
 
-class capture:
-    """``with capture(graph, pool=None):`` -- torch.cuda.graph with the garbage collector under control.
+_capture_stream = None
 
-    hipGraph stream capture runs in GLOBAL mode: a hipFree / hipStreamDestroy / hipGraphExecDestroy issued by ANY code of the
-    process while a capture is open is illegal.  Destructors issue exactly those (a dead tracker's native trunk, its graphs,
-    its memory pool), and Python's cyclic collector runs them whenever an allocation count crosses its threshold -- also in the
-    middle of a capture.  So: collect BEFORE the capture opens, keep the collector off while it is open."""
+
+class capture:
+    """``with capture(graph, pool=None):`` -- stream capture into a torch.cuda.CUDAGraph, like ``torch.cuda.graph`` but
+
+    * with the garbage collector OFF while the capture is open.  hipGraph stream capture runs in GLOBAL mode: a hipFree /
+      hipStreamDestroy / hipGraphExecDestroy issued by ANY code of the process meanwhile is illegal, destructors issue exactly those
+      (a dead tracker's native trunk, its graphs, its memory pool), and Python's cyclic collector runs them whenever an allocation
+      count crosses its threshold -- also in the middle of a capture;
+    * WITHOUT ``gc.collect()`` and ``torch.cuda.empty_cache()`` before it.  PyTorch dropped the first for being "really
+      expensive" with several captures in a row (measured here: a sequence of a new frame size ran at 150 instead of 610 frames/s
+      because of it); the second hands every cached block back to the driver, so the frames after a capture pay hipMalloc again
+      (milliseconds each, and the reason bench.py had to run its warm-up sequence twice).
+
+    The capture runs on one side stream of the process, which first waits for the caller's stream."""
 
     def __init__(self, graph, pool=None):
-        self._ctx = torch.cuda.graph(graph, pool=pool) if pool is not None else torch.cuda.graph(graph)
+        self.graph, self.pool = graph, pool
         self._was_enabled = False
+        self._ctx = None
 
     def __enter__(self):
         import gc
-        gc.collect()
+        global _capture_stream
         self._was_enabled = gc.isenabled()
         gc.disable()
         try:
-            return self._ctx.__enter__()
+            torch.cuda.synchronize()
+            if _capture_stream is None:
+                _capture_stream = torch.cuda.Stream()
+            _capture_stream.wait_stream(torch.cuda.current_stream())
+            self._ctx = torch.cuda.stream(_capture_stream)
+            self._ctx.__enter__()
+            if self.pool is not None:
+                self.graph.capture_begin(self.pool, capture_error_mode='global')
+            else:
+                self.graph.capture_begin(capture_error_mode='global')
         except BaseException:
+            if self._ctx is not None:
+                self._ctx.__exit__(None, None, None)
             if self._was_enabled:
                 gc.enable()
             raise
+        return self
 
     def __exit__(self, *exc):
         import gc
         try:
-            return self._ctx.__exit__(*exc)
+            self.graph.capture_end()
         finally:
+            self._ctx.__exit__(*exc)
             if self._was_enabled:
                 gc.enable()
+        return False
