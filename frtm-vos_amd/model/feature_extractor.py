@@ -155,6 +155,7 @@ class ResnetFeatureExtractor:
         self._lanes = 1
         self._winograd = True
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
+        self.capture_after = 1         # trunk shapes are replayed as hipGraphs from their (capture_after + 1)-th use on
         self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
         self.pass_frames = []
         self.pass_events = None        # a list: every pass appends (start event, end event, FLOPs, conv launches)  (bench.py's roofline leg)
@@ -287,16 +288,20 @@ class ResnetFeatureExtractor:
         if ent is None:
             if len(self._out_cache) > 64:
                 self._out_cache.clear()
-            ent = self._out_cache[key] = dict(out={L: t[:B] for L, t in buf['t'].items()}, graph=None)
-            self._forward(x, ent['out'], args, stop)           # first call of a shape: eager (allocates arenas / workspaces)
-            ent['stats'] = (self.last_flops, self.last_conv_launches)
-            if self.use_graph:                                 # ... and captured right away: the second call already replays
+            ent = self._out_cache[key] = dict(out={L: t[:B] for L, t in buf['t'].items()}, graph=None, uses=0)
+        ent['uses'] += 1
+        # A shape is launched kernel by kernel until it has been used ``capture_after`` times, then captured (one-off: an eager
+        # pass, a device synchronise, ~210 recorded launches, instantiation = tens of ms) and replayed from then on.  Full trunk
+        # batches come back in every sequence; the tail batch of a sequence (1 .. 19 frames, whatever its length leaves) mostly does
+        # not -- on a 30-sequence dataset capturing every shape at first sight cost more than replay ever gave back.
+        replay = self.use_graph and ent['uses'] > self.capture_after
+        if replay:
+            gen = H.lib().frtm_backbone_generation(self._handle)
+            if ent['graph'] is None or ent['gen'] != gen:
+                if ent['graph'] is None and ent['uses'] == 1:
+                    self._forward(x, ent['out'], args, stop)   # never run before: eager once (allocates arenas / workspaces)
                 self._capture(ent, x, args, stop)
-            return ent['out']
-        gen = H.lib().frtm_backbone_generation(self._handle)
-        if self.use_graph and (ent['graph'] is None or ent['gen'] != gen):
-            self._capture(ent, x, args, stop)
-        if self.use_graph:
+        if replay:
             ent['in'].copy_(x)
             ent['graph'].replay()
             self.last_flops, self.last_conv_launches = ent['stats']

@@ -144,6 +144,8 @@ class SegNetwork(nn.Module):
         self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
         self._side = None
         self._pool = None
+        self._uses = {}
+        self.capture_after = 1           # a (taps, window shape) is replayed as a hipGraph from its (capture_after + 1)-th use on
 
     def invalidate(self):
         """Drop the packed HIP weights and captured graphs (call after editing parameters in place)."""
@@ -197,6 +199,14 @@ class SegNetwork(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     # HIP path
     # ------------------------------------------------------------------------------------------------------
+    def _side_streams(self):
+        if self._side is None:
+            # ONE side stream carries all deep levels (two parallel graph branches).  A stream per level measured slower
+            # and bimodal on MI355X (1.25-1.31 ms vs 1.22 ms serial; this form 1.15 ms, stable).
+            dev = next(self.parameters()).device
+            self._side = [torch.cuda.Stream(device=dev)] * (len(self.ft_channels) - 1)
+        return self._side
+
     def _forward_graphed(self, scores, features, image_size):
         """The ~80 launches of _forward_hip are a static sequence for a given object count and set of tap tensors:
         capture them once in a hipGraph and replay it per frame (one host call instead of ~80).  The graph is keyed by the
@@ -210,15 +220,20 @@ class SegNetwork(nn.Module):
                tuple(scores.shape), tuple(image_size[-2:]), self._pack_key)
         entry = self._graphs.pop(key, None)
         if entry is None:
+            # launched kernel by kernel until this (taps, window shape) has come up ``capture_after`` times: windows of 8 frames
+            # recur all the time, the tail window of a sequence mostly not (a capture costs tens of ms and a device synchronise)
+            uses = self._uses[key] = self._uses.get(key, 0) + 1
+            if uses <= self.capture_after:
+                if len(self._uses) > 4096:
+                    self._uses.clear()
+                return self._forward_hip(scores, features, image_size)       # (one stream: no cross-stream temporaries outside a graph)
             while len(self._graphs) >= 32:                                   # least recently used first
                 self._graphs.pop(next(iter(self._graphs)))
             static_scores = scores.clone()
             self._forward_hip(static_scores, features, image_size)          # warm-up outside capture (allocator, workspaces)
             torch.cuda.synchronize()
-            if self.parallel_levels and self._side is None:
-                # ONE side stream carries all deep levels (two parallel graph branches).  A stream per level measured slower
-                # and bimodal on MI355X (1.25-1.31 ms vs 1.22 ms serial; this form 1.15 ms, stable).
-                self._side = [torch.cuda.Stream(device=scores.device)] * (len(self.ft_channels) - 1)
+            if self.parallel_levels:
+                self._side_streams()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()

@@ -164,11 +164,23 @@ class Tracker(nn.Module):
         A sequence then only replays.  Sequence lengths are chosen so that every window length 1..8 and a full trunk batch occur."""
         from ..lib.synthetic import SyntheticSequence
         fb = max(1, int(self.feature_batch))
-        for n in object_counts:
-            for residual in range(1, 9):
-                seq = SyntheticSequence('prewarm', 1 + fb + residual, tuple(size), n, seed=seed + n)
-                seq.preload(self.device)
-                self.run_sequence(seq)
+        ext, ref = self.feature_extractor, self.refiner
+        saved = (getattr(ext, 'capture_after', None), getattr(ref, 'capture_after', None))
+        if saved[0] is not None:
+            ext.capture_after = 0                            # capture at first sight (normally: from the second use on)
+        if saved[1] is not None:
+            ref.capture_after = 0
+        try:
+            for n in object_counts:
+                for residual in range(1, 9):
+                    seq = SyntheticSequence('prewarm', 1 + fb + residual, tuple(size), n, seed=seed + n)
+                    seq.preload(self.device)
+                    self.run_sequence(seq)
+        finally:
+            if saved[0] is not None:
+                ext.capture_after = saved[0]
+            if saved[1] is not None:
+                ref.capture_after = saved[1]
         self.release_targets()
         torch.cuda.synchronize()
 

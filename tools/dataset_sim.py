@@ -1,0 +1,39 @@
+"""A DAVIS-2017-val-like run through ONE tracker (30 synthetic sequences, 34-104 frames, 1-5 objects, 480p with three widths):
+what the reference's run_dataset reports (mean of the per-sequence frames/s, model/tracker.py:82-99) next to total frames /
+total time, with and without Tracker.prewarm.        python tools/dataset_sim.py [--prewarm]"""
+import os, random, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from frtm_vos_amd.evaluate import Parameters
+from frtm_vos_amd.lib.synthetic import SyntheticSequence, make_score_following_refiner
+from frtm_vos_amd.model.seg_network import SegNetwork
+torch.set_grad_enabled(False)
+
+
+def _refiner(chans):
+    torch.manual_seed(1)
+    return make_score_following_refiner(SegNetwork(1, 64, chans, True).eval())
+
+
+rng = random.Random(2017)
+params = Parameters(None, device='cuda:0')
+params.refiner_factory = _refiner
+trk = params.get_model().eval()
+objs = [1] * 8 + [2] * 9 + [3] * 8 + [4] * 2 + [5] * 3
+sizes = [(480, 854)] * 25 + [(480, 910)] * 3 + [(480, 1152)] * 2
+rng.shuffle(objs); rng.shuffle(sizes)
+cfg = [(sizes[i], objs[i], rng.randint(34, 104)) for i in range(30)]
+if '--prewarm' in sys.argv:
+    t0 = time.time()
+    for size in sorted(set(sizes)):
+        trk.prewarm(size, object_counts=sorted(set(o for s, o, _ in cfg if s == size)))
+    print('prewarm: %.1f s' % (time.time() - t0), flush=True)
+fps_all, frames, t_all = [], 0, 0.0
+for i, (size, n, L) in enumerate(cfg):
+    seq = SyntheticSequence('d%d' % i, L, size, n, seed=500 + i)
+    seq.preload('cuda:0')
+    t0 = time.time()
+    out, fps = trk.run_sequence(seq)
+    dt = time.time() - t0
+    fps_all.append(fps); frames += L; t_all += dt
+    print('%2d %s x%d %3d frames: %6.1f fps' % (i, size, n, L, fps), flush=True)
+print('mean of per-sequence fps %.1f   total %d frames / %.2f s = %.1f fps' % (sum(fps_all) / len(fps_all), frames, t_all, frames / t_all))
