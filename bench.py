@@ -69,7 +69,8 @@ def parse(argv=None):
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
-    ap.add_argument('--no-trunk-graph', action='store_true', help='trunk passes launched kernel by kernel instead of replayed as hipGraphs')
+    ap.add_argument('--no-refiner-graph', action='store_true', help='refiner windows launched kernel by kernel instead of replayed as hipGraphs')
+    ap.add_argument('--trunk-graph', action='store_true', help='trunk passes replayed as hipGraphs instead of launched kernel by kernel (no gain measured)')
     ap.add_argument('--no-fold-tail', action='store_true', help='a last trunk batch of 1-3 frames stays a pass of its own instead of joining the one before it')
     ap.add_argument('--balance', action='store_true', help='trunk batches of similar size instead of full ones and a short tail pass (measured slower at 20 frames)')
     ap.add_argument('--pipeline', action='store_true', help='two tap sets, trunk passes one ahead on a side stream, one beside the first-frame fits (measured: +4 %% frames/s at 20 frames, trunk passes 5 %% slower)')
@@ -467,7 +468,8 @@ def main():
     if args.no_fold_tail:
         tracker.fold_tail = 0
     tracker.first_batch = args.first_batch or None
-    tracker.graph_trunk = not args.no_trunk_graph
+    tracker.graph_trunk = args.trunk_graph
+    tracker.graph_refiner = not args.no_refiner_graph
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
     tracker.overlap_first_pass = args.first_pass_overlap

@@ -69,7 +69,9 @@ class Tracker(nn.Module):
         super().__init__()
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
-        self.graph_trunk = True
+        self.graph_trunk = False         # trunk passes replayed as hipGraphs: nothing to gain since the host no longer waits for the GPU
+                                         # while tracking (64 frames: 498 vs 499 frames/s), and every new batch shape costs a capture
+                                         # (30 DAVIS-like sequences: 350 frames/s with lazily captured trunk graphs, 378 without)
         self.overlap_first_pass = False  # first trunk pass of a sequence on a side stream, next to initialize()'s fits (measured: no gain
                                          # with 2 objects -- the fits just run slower next to the trunk kernels --, +3 % with 5)
         self._after_init_trunk = None

@@ -130,6 +130,7 @@ def test_one_tracker_serves_sequences_with_different_object_counts_under_graph_r
             outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
         return outs
     shared = _tracker(memory_size=8, init_iters=(2, 3), update_iters=(3,))
+    shared.graph_trunk = True                           # (off by default: the graph path of the trunk stays under test here)
     a = run(shared)
     eager = _tracker(memory_size=8, init_iters=(2, 3), update_iters=(3,))
     eager.graph_refiner = False

@@ -18,6 +18,8 @@ rng = random.Random(2017)
 params = Parameters(None, device='cuda:0')
 params.refiner_factory = _refiner
 trk = params.get_model().eval()
+trk.graph_trunk = '--trunk-graph' in sys.argv
+trk.graph_refiner = '--no-refiner-graph' not in sys.argv
 objs = [1] * 8 + [2] * 9 + [3] * 8 + [4] * 2 + [5] * 3
 sizes = [(480, 854)] * 25 + [(480, 910)] * 3 + [(480, 1152)] * 2
 rng.shuffle(objs); rng.shuffle(sizes)
