@@ -505,9 +505,9 @@ def main():
     _TR.TargetObject.initialize = timer.wrap('init_fit', _TR.TargetObject.initialize)
 
     # Untimed warm-up: a throw-away sequence (other seed) of the SAME length and object count as the timed one, so that every
-    # hipGraph the timed frames replay (trunk pass per batch size, refiner per window shape) exists and the caching allocator holds
+    # hipGraph the timed frames replay (refiner per window shape; captured at the SECOND use of a shape) exists and the caching allocator holds
     # every block size the timed sequence asks for; preceded by a W-frame sequence when W asks for more than that.
-    # The same-length sequence runs TWICE: hipGraph capture empties the caching allocator (torch.cuda.graph does), so only a pass
+    # The same-length sequence runs TWICE: graphs are captured on the second use of a shape, so only a second pass
     # without captures leaves every block the timed sequence needs in the cache (device_mallocs_in_timed_region must be 0).
     warm_lengths = ([args.warmup] if args.warmup > args.steps else []) + [args.steps, args.steps]
     seq = SyntheticSequence('bench', args.steps, size, args.objects, seed=1 + rank, late_object_at=args.late_object)
