@@ -279,10 +279,14 @@ __global__ __launch_bounds__(64 * NW) void k_scores_composed(const float* __rest
                                                               const float* __restrict__ Z, const float* __restrict__ p2, int Cz, int h, int w,
                                                               float* __restrict__ out) {
   __shared__ float red[NW][R][64];
-  const int rbs = (h + R - 1) / R, N = gridDim.x / rbs, CS = gridDim.y - 1;
-  const int n = blockIdx.x / rbs, y0 = (blockIdx.x - n * rbs) * R;
+  // maps wider than a wavefront (720p: 80, 1080p: 120 columns) go in column tiles of 64: blockIdx.x = (sample, row block, tile)
+  const int rbs = (h + R - 1) / R, ct = (w + 63) / 64, N = gridDim.x / (rbs * ct), CS = gridDim.y - 1;
+  const int cx = blockIdx.x % ct, rbi = blockIdx.x / ct;
+  const int n = rbi / rbs, y0 = (rbi - n * rbs) * R;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const bool xin = lane < w, has_l = lane > 0, has_r = lane + 1 < w;
+  const int x = cx * 64 + lane;
+  const bool xin = x < w, has_l = x > 0, has_r = x + 1 < w;
+  const bool edge_l = lane == 0 && has_l, edge_r = lane == 63 && has_r;      // neighbours that live in the next tile: loaded
   const bool zsrc = (int)blockIdx.y == CS;
   const int C = zsrc ? Cz : Cx;
   const int Cs = zsrc ? Cz : (Cx + CS - 1) / CS, cb = zsrc ? 0 : blockIdx.y * Cs, ce = min(C, cb + Cs);
@@ -304,18 +308,25 @@ __global__ __launch_bounds__(64 * NW) void k_scores_composed(const float* __rest
 #pragma unroll
       for (int i = 0; i < R + 2; ++i) {
         const int yy = y0 - 1 + i;
-        m[u][i] = (xin && cg + u < c1 && (unsigned)yy < (unsigned)h) ? Xc[yy * w + lane] : 0.f;
+        m[u][i] = (xin && cg + u < c1 && (unsigned)yy < (unsigned)h) ? Xc[yy * w + x] : 0.f;
       }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const float* fc = f + (size_t)min(cg + u, c1 - 1) * 9;
+      const float* Xe = Xn + (size_t)min(cg + u, c1 - 1) * h * w;
+      const bool live = cg + u < c1;
       float l[R + 2], r[R + 2];
 #pragma unroll
       for (int i = 0; i < R + 2; ++i) {
+        const int yy = y0 - 1 + i;
         const float up = __shfl_up(m[u][i], 1, 64), dn = __shfl_down(m[u][i], 1, 64);
         l[i] = has_l ? up : 0.f;
         r[i] = has_r ? dn : 0.f;
+        if (ct > 1 && live && (unsigned)yy < (unsigned)h) {
+          if (edge_l) l[i] = Xe[yy * w + x - 1];
+          if (edge_r) r[i] = Xe[yy * w + x + 1];
+        }
       }
 #pragma unroll
       for (int o = 0; o < R; ++o)
@@ -332,12 +343,12 @@ __global__ __launch_bounds__(64 * NW) void k_scores_composed(const float* __rest
   __syncthreads();
   float* on = out + ((size_t)blockIdx.y * N + n) * h * w;
   for (int i = threadIdx.x; i < R * 64; i += 64 * NW) {
-    const int o = i >> 6, x = i & 63, yy = y0 + o;
-    if (x < w && yy < h) {
+    const int o = i >> 6, xl = i & 63, xg = cx * 64 + xl, yy = y0 + o;
+    if (xg < w && yy < h) {
       float sum = 0.f;
 #pragma unroll
-      for (int k = 0; k < NW; k += 4) sum += (red[k][o][x] + red[k + 1][o][x]) + (red[k + 2][o][x] + red[k + 3][o][x]);
-      on[yy * w + x] = sum;
+      for (int k = 0; k < NW; k += 4) sum += (red[k][o][xl] + red[k + 1][o][xl]) + (red[k + 2][o][xl] + red[k + 3][o][xl]);
+      on[yy * w + xg] = sum;
     }
   }
 }
@@ -462,9 +473,9 @@ int frtm_joint_expand(const float* G, int nslab, const float* w2, int Cin, int c
 
 int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const float* Z, const float* p2, int Cz, int N, int h, int w,
                                int splits, float* partial, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(X && K && Z && p2 && partial && N > 0 && Cx > 0 && Cz > 0 && h > 0 && w > 0 && w <= 64 && splits >= 1 && splits <= 64,
-                 "frtm_joint_scores_composed: bad argument (maps at most 64 wide)");
-  dim3 g(ceil_div(h, 3) * N, splits + 1);
+  FRTM_CHECK_ARG(X && K && Z && p2 && partial && N > 0 && Cx > 0 && Cz > 0 && h > 0 && w > 0 && splits >= 1 && splits <= 64,
+                 "frtm_joint_scores_composed: bad argument");
+  dim3 g(ceil_div(h, 3) * N * ceil_div(w, 64), splits + 1);
   k_scores_composed<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, K, Cx, Z, p2, Cz, h, w, partial);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;

@@ -163,7 +163,7 @@ class DiscriminatorLoss(MinimizationProblem):
     composed = True
 
     def _use_composed(self):
-        return bool(self.joint and self.composed and self.c <= 128 and self.Cin <= 2048 and self.w <= 64 and 4 * (self.h + 2) * (self.w + 2) <= 64 * 1024)
+        return bool(self.joint and self.composed and self.c <= 128 and self.Cin <= 2048 and 4 * (self.h + 2) * (self.w + 2) <= 64 * 1024)
 
     @property
     def sp(self):
