@@ -20,10 +20,18 @@ params.refiner_factory = _refiner
 trk = params.get_model().eval()
 trk.graph_trunk = '--trunk-graph' in sys.argv
 trk.graph_refiner = '--no-refiner-graph' not in sys.argv
-objs = [1] * 8 + [2] * 9 + [3] * 8 + [4] * 2 + [5] * 3
-sizes = [(480, 854)] * 25 + [(480, 910)] * 3 + [(480, 1152)] * 2
-rng.shuffle(objs); rng.shuffle(sizes)
-cfg = [(sizes[i], objs[i], rng.randint(34, 104)) for i in range(30)]
+if '--ytvos' in sys.argv:           # YouTube-VOS-valid-like: 720p, 20-36 frames, 1-4 objects, every third sequence with a late object
+    objs = [1] * 10 + [2] * 10 + [3] * 6 + [4] * 4
+    sizes = [(720, 1280)] * 30
+    rng.shuffle(objs)
+    cfg = [(sizes[i], objs[i], rng.randint(20, 36)) for i in range(30)]
+    late = [rng.randint(3, 15) if (objs[i] > 1 and i % 3 == 0) else None for i in range(30)]
+else:
+    objs = [1] * 8 + [2] * 9 + [3] * 8 + [4] * 2 + [5] * 3
+    sizes = [(480, 854)] * 25 + [(480, 910)] * 3 + [(480, 1152)] * 2
+    rng.shuffle(objs); rng.shuffle(sizes)
+    cfg = [(sizes[i], objs[i], rng.randint(34, 104)) for i in range(30)]
+    late = [None] * 30
 if '--prewarm' in sys.argv:
     t0 = time.time()
     for size in sorted(set(sizes)):
@@ -31,11 +39,11 @@ if '--prewarm' in sys.argv:
     print('prewarm: %.1f s' % (time.time() - t0), flush=True)
 fps_all, frames, t_all = [], 0, 0.0
 for i, (size, n, L) in enumerate(cfg):
-    seq = SyntheticSequence('d%d' % i, L, size, n, seed=500 + i)
+    seq = SyntheticSequence('d%d' % i, L, size, n, seed=500 + i, late_object_at=late[i])
     seq.preload('cuda:0')
     t0 = time.time()
     out, fps = trk.run_sequence(seq)
     dt = time.time() - t0
     fps_all.append(fps); frames += L; t_all += dt
-    print('%2d %s x%d %3d frames: %6.1f fps' % (i, size, n, L, fps), flush=True)
+    print('%2d %s x%d %3d frames%s: %6.1f fps' % (i, size, n, L, ' (late %d)' % late[i] if late[i] else '', fps), flush=True)
 print('mean of per-sequence fps %.1f   total %d frames / %.2f s = %.1f fps' % (sum(fps_all) / len(fps_all), frames, t_all, frames / t_all))
