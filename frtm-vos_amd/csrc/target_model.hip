@@ -81,15 +81,24 @@ template <bool U8>
 __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ labels, const float* __restrict__ pw, int H, int W, int h, int w, float tf,
                                                        const float* __restrict__ partial, const int* __restrict__ slot_dev,
                                                        int slot_host, float* __restrict__ Bmem, float* __restrict__ cmem,
-                                                       const int* __restrict__ px_count) {
+                                                       const int* __restrict__ px_count, size_t label_stride = 0, int px_stride = 1,
+                                                       int slot_table = 0) {
+  // slot_table: sample n goes to slot_dev[n] (a window of frames whose slots were chosen one after the other on the device; -1 =
+  // guarded insert skipped; a slot that a LATER sample of the window takes as well is left to that sample).  label_stride / px_stride:
+  // distance between consecutive samples' label planes / pixel counts (0 / 1: dense).
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int cell = blockIdx.x * 4 + wid;
   if (cell >= h * w) return;
-  if (slot_dev && slot_dev[0] < 0) return;   // guarded insert
+  if (slot_table) {
+    const int mine = slot_dev[n];
+    if (mine < 0) return;
+    for (int g = n + 1; g < (int)gridDim.y; ++g)
+      if (slot_dev[g] == mine) return;
+  } else if (slot_dev && slot_dev[0] < 0) return;   // guarded insert
   const int ci = cell / w, cj = cell % w;
   float wf = 1.f, wb = 1.f;
-  if (!pw) hinge_weights(px_count ? (float)px_count[n] : sum_parts(partial, n), (float)(H * W), tf, wf, wb);
+  if (!pw) hinge_weights(px_count ? (float)px_count[(size_t)n * px_stride] : sum_parts(partial, n), (float)(H * W), tf, wf, wb);
   const float* pwn = pw ? pw + (size_t)n * H * W : nullptr;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   // conservative pixel window of cell (ci,cj): source coordinate in [ci-1, ci+1)
@@ -104,8 +113,9 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
   float acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-  const unsigned char* lb8 = (const unsigned char*)labels + (size_t)n * H * W;
-  const float* lbf = (const float*)labels + (size_t)n * H * W;
+  const size_t lstride = label_stride ? label_stride : (size_t)H * W;
+  const unsigned char* lb8 = (const unsigned char*)labels + (size_t)n * lstride;
+  const float* lbf = (const float*)labels + (size_t)n * lstride;
   // A cell's window is ~36 x 36 pixels (the feature stride is 16): lane = column, and the rows go in blocks of NB whose loads are
   // all issued before the first one is used -- the kernel is one memory latency per block instead of one per row.
   constexpr int NB = 20;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = wave_sum(acc[k]);
   if (lane == 0) {
-    const int slot = (slot_dev ? slot_dev[0] : slot_host) + n;
+    const int slot = slot_table ? slot_dev[n] : (slot_dev ? slot_dev[0] : slot_host) + n;
     float* B = Bmem + (size_t)slot * 9 * h * w;
 #pragma unroll
     for (int k = 0; k < 9; ++k) B[(size_t)k * h * w + cell] = acc[k];
@@ -161,11 +171,12 @@ __global__ __launch_bounds__(256) void k_normal_build(const void* __restrict__ l
 // Memory.update_sample_weights on the device (model/memory.py:65-92).  One wave.
 // state[0] = previous replace index (-1 = None), state[1] = index chosen by this call.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state,
-                                                          const int* __restrict__ count, int min_count) {
+// One update of the sample weights by one wave; returns the chosen slot (-1: skipped by the device-side early-out).
+__device__ __forceinline__ int next_slot_step(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state,
+                                              const int* __restrict__ count, int min_count) {
   const int lane = threadIdx.x;
   // device-side form of the early-out of Discriminator.update (discriminator.py:214): no weight update, no slot
-  if (count && count[0] < min_count) { if (lane == 0) { state[1] = -1; state[3] += 1; } return; }     // state[3]: skipped inserts
+  if (count && count[0] < min_count) { if (lane == 0) { state[1] = -1; state[3] += 1; } return -1; }     // state[3]: skipped inserts
   int r_ind;
   if (num_zero || lr == 1.f) {
     for (int i = lane; i < cap; i += 64) sw[i] = (i == 0) ? 1.f : 0.f;
@@ -185,10 +196,12 @@ __global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw,
     }
     r_ind = bi;
     const int prev = state[0];
+    __syncthreads();                                   // (every lane has read the weights / state before anyone rewrites them)
     if (prev < 0) {
       for (int i = lane; i < cap; i += 64) sw[i] = (i == r_ind) ? lr : sw[i] / (1.f - lr);    // :84-86
     } else {
       const float pv = sw[prev];
+      __syncthreads();
       if (lane == 0) sw[r_ind] = pv / (1.f - lr);                                              // :88
     }
   }
@@ -196,8 +209,27 @@ __global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw,
   float s = 0.f;
   for (int i = lane; i < cap; i += 64) s += sw[i];
   s = wave_sum(s);
+  __syncthreads();
   for (int i = lane; i < cap; i += 64) sw[i] = sw[i] / s;                                      // :90
   if (lane == 0) { state[0] = r_ind; state[1] = r_ind; state[2] += 1; }                        // state[2]: inserts performed
+  __syncthreads();
+  return r_ind;
+}
+
+__global__ __launch_bounds__(64) void k_memory_next_slot(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state,
+                                                          const int* __restrict__ count, int min_count) {
+  next_slot_step(sw, cap, lr, num_zero, state, count, min_count);
+}
+
+// The same for a WINDOW of W frames, one after the other in one launch: slots[f] = slot of frame f (-1: skipped).
+__global__ __launch_bounds__(64) void k_memory_next_slot_window(float* __restrict__ sw, int cap, float lr, int num_zero, int* __restrict__ state,
+                                                                 const int* __restrict__ counts, int count_stride, int min_count, int W,
+                                                                 int* __restrict__ slots) {
+  for (int f = 0; f < W; ++f) {
+    const int r = next_slot_step(sw, cap, lr, num_zero, state, counts ? counts + (size_t)f * count_stride : nullptr, min_count);
+    if (r >= 0) num_zero = 0;
+    if (threadIdx.x == 0) slots[f] = r;
+  }
 }
 
 template <typename T>
@@ -206,6 +238,20 @@ __global__ __launch_bounds__(256) void k_memory_insert(const T* __restrict__ src
   if (slot[0] < 0) return;                 // guarded insert (see k_memory_next_slot)
   T* dst = dst_base + (size_t)slot[0] * len;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// W samples (src: (W, len)) into their slots; blockIdx.y = sample.  A slot that a later sample of the window takes as well is left
+// to that sample (the slots were chosen one after the other: with a memory smaller than the window they can repeat).
+template <typename T>
+__global__ __launch_bounds__(256) void k_memory_insert_window(const T* __restrict__ src, T* __restrict__ dst_base, int len,
+                                                               const int* __restrict__ slots) {
+  const int f = blockIdx.y, mine = slots[f];
+  if (mine < 0) return;
+  for (int g = f + 1; g < (int)gridDim.y; ++g)
+    if (slots[g] == mine) return;
+  const T* s = src + (size_t)f * len;
+  T* dst = dst_base + (size_t)mine * len;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = s[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -821,6 +867,31 @@ int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int
   dim3 g(ceil_div(h * w, 4), n);
   if (labels_is_u8) k_normal_build<true><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem, px_count_dev);
   else k_normal_build<false><<<g, 256, 0, st>>>(labels, pw, H, W, h, w, tf, scratch, slot_dev, slot_host, Bmem, cmem, px_count_dev);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_memory_update_window(float* sw, int cap, float lr, int num_samp_is_zero, int* state, const int* counts, int count_stride,
+                              int min_count, int W, int* slots, const float* features, float* samples, int len, const float* labels,
+                              size_t label_stride, int H, int Wd, int h, int w, float tf, float* Bmem, float* cmem, float* scratch,
+                              frtm_stream_t stream) {
+  FRTM_CHECK_ARG(sw && state && counts && slots && features && samples && labels && Bmem && cmem && cap > 0 && W >= 1 && W <= 1024 && len > 0,
+                 "frtm_memory_update_window: bad argument");
+  FRTM_CHECK_ARG(h >= 1 && w >= 1 && H >= h && Wd >= w, "frtm_memory_update_window: needs H>=h, W>=w (got %dx%d -> %dx%d)", h, w, H, Wd);
+  hipStream_t st = (hipStream_t)stream;
+  k_memory_next_slot_window<<<1, 64, 0, st>>>(sw, cap, lr, num_samp_is_zero, state, counts, count_stride, min_count, W, slots);
+  FRTM_LAUNCH_CHECK();
+  const bool vec = (len % 4 == 0) && (((size_t)features | (size_t)samples) % 16 == 0);
+  if (vec) {
+    dim3 g(min(ceil_div(len / 4, 256), 256), W);
+    k_memory_insert_window<float4><<<g, 256, 0, st>>>((const float4*)features, (float4*)samples, len / 4, slots);
+  } else {
+    dim3 g(min(ceil_div(len, 256), 256), W);
+    k_memory_insert_window<float><<<g, 256, 0, st>>>(features, samples, len, slots);
+  }
+  FRTM_LAUNCH_CHECK();
+  dim3 gn(ceil_div(h * w, 4), W);
+  k_normal_build<false><<<gn, 256, 0, st>>>(labels, nullptr, H, Wd, h, w, tf, scratch, slots, 0, Bmem, cmem, counts, label_stride, count_stride, 1);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

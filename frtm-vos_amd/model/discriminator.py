@@ -585,6 +585,39 @@ class Discriminator(nn.Module):
         """Number of coming frames up to and including the next filter re-solve (>= 1)."""
         return self.train_skipping - (self.frame_num % self.train_skipping)
 
+    # True: the memory inserts of a tracking window go out as ONE batched update (3 launches per window and object instead of 3 per
+    # frame and object) when everything is decided on the device anyway (guards_on_device(), no full-resolution label copies)
+    window_inserts = True
+
+    def can_update_window(self, W):
+        """May update_window() serve the next W frames?  Only the LAST of them may be a filter re-solve frame."""
+        if not (self.window_inserts and self.update_filters and self.guards_on_device() and self.memory is not None and not self.memory.keep_hires):
+            return False
+        return all((self.frame_num + f) % self.train_skipping != 0 for f in range(1, W))
+
+    def update_window(self, cfts, masks, plane, counts):
+        """advance() + update() for the W frames of a tracking window at once: ``cfts`` (W,c,h,w) projected features, the soft
+        label of frame f is ``masks[f, plane]``, its pixel count ``counts[f, plane]`` (device int32).  Same memory and filter as the
+        frame-by-frame calls (test_window_inserts_equal_frame_by_frame)."""
+        W = cfts.shape[0]
+        self.frame_num += W
+        self.current_sample = cfts[W - 1:W]
+        self.memory.update_window(cfts.contiguous(), masks, plane, counts)
+        if self.frame_num % self.train_skipping == 0:
+            opt = self.update_optimizer
+            last = counts[W - 1, plane:plane + 1]
+            if opt.peek_persistent_abort() and opt.poll_persistent_abort():
+                self.num_persistent_aborts += 1
+            if opt.can_guard():
+                opt.run(self.update_iters, guard=last, guard_min=10)
+                self._guarded_runs += 1
+            else:                                                   # (shape does not fit the resident form: decide here)
+                if int(last.item()) < 10:
+                    self._early_outs_host += 1
+                else:
+                    opt.run(self.update_iters)
+                    self._solves_host += 1
+
     def update(self, train_y, num_positive=None, count_dev=None):
         """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
         The reference's early-out "fewer than 10 pixels above 0.5" (:214) needs the pixel count:

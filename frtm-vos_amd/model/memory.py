@@ -50,6 +50,7 @@ class Memory:
         self.learning_rates = learning_rates
         # {previous_replace_ind, last index, inserts performed, inserts skipped by the device-side early-out}; fills, not blocking H2D copies
         self._slot = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._slots_w = None
         self._slot[:2].fill_(-1)
         self._have_prev = False
         self._scratch = torch.zeros(max(capacity, 8) * 32, device=dev)
@@ -100,6 +101,7 @@ class Memory:
         m.device = dev
         m.learning_rates = learning_rates
         m._slot = torch.zeros(4, dtype=torch.int32, device=dev)
+        m._slots_w = None
         m._slot[:2].fill_(-1)
         m._have_prev = False
         m._scratch = torch.zeros(max(cap, 8) * 32, device=dev)
@@ -219,6 +221,27 @@ class Memory:
             H.call('frtm_memory_insert', H.ptr(labf), H.ptr(self._labels), labf.numel(), slot_dev_ptr)
             pwt = pw if pw is not None else self._hires_pw(lab)
             H.call('frtm_memory_insert', H.ptr(pwt), H.ptr(self._pixel_weights), pwt.numel(), slot_dev_ptr)
+
+    def update_window(self, features, masks, plane, counts):
+        """update() for W consecutive frames in three launches (frtm_memory_update_window) instead of 3 W: ``features`` (W,c,h,w)
+        dense, the soft label of frame f is ``masks[f, plane]`` (masks: (W,K,H,W) float, dense), its pixel count
+        ``counts[f, plane]`` (int32 (W,K), from ops.count_above); frames with fewer than 10 pixels are skipped on the device like
+        update(count_dev=...) does.  Same slots, weights, samples and normal equations as W update() calls (no full-resolution
+        copies: ``keep_hires`` memories take the frame-by-frame path)."""
+        W, K = masks.shape[0], masks.shape[1]
+        Hh, Ww = self.labels_size[-2:]
+        assert not self.keep_hires
+        assert features.is_contiguous() and masks.is_contiguous() and masks.dtype == torch.float32 and counts.is_contiguous()
+        assert features.shape[0] == W and tuple(masks.shape[-2:]) == (Hh, Ww) and tuple(counts.shape) == (W, K) and counts.dtype == torch.int32
+        if self._slots_w is None or self._slots_w.numel() < W:
+            self._slots_w = torch.empty(max(64, W), dtype=torch.int32, device=self.device)
+        ln = features[0].numel()
+        H.call('frtm_memory_update_window', H.ptr(self.weights), self._capacity, float(self.learning_rates), int(self.current_size == 0),
+               H.ptr(self._slot), counts.data_ptr() + 4 * plane, K, 10, W, H.ptr(self._slots_w), H.ptr(features), H.ptr(self.samples), ln,
+               masks.data_ptr() + 4 * plane * Hh * Ww, K * Hh * Ww, Hh, Ww, self.grid[0], self.grid[1], self._tf(),
+               H.ptr(self.normal_B), H.ptr(self.normal_c), H.ptr(self._scratch))
+        self._have_prev = True
+        self.current_size = min(self.current_size + W, self._capacity)
 
     def update(self, features, labels, pixel_weights=None, count_dev=None, px_count=None):
         """Reference memory.py:59-63.  With ``count_dev`` the insert is guarded on the device; ``current_size`` is then an

@@ -556,6 +556,12 @@ class Tracker(nn.Module):
             K = masks.shape[1]
             counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)                 # device int32, no sync
             on_device = all(t.discriminator.guards_on_device() for t in active)
+            if on_device and masks.is_contiguous() and all(t.discriminator.can_update_window(W) for t in active):
+                # every insert of the window and the re-solve at its end decided on the device: one batched update per object
+                for k, t in enumerate(active):
+                    t.discriminator.update_window(cfts[k], masks, t.index, counts)
+                self.current_masks = masks[W - 1]
+                return masks
             for f in range(W):
                 for t in active:
                     t.discriminator.advance(cfts[active.index(t)][f:f + 1])

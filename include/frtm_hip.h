@@ -56,6 +56,14 @@ int frtm_normal_build(const void* labels, int labels_is_u8, const float* pw, int
                       float tf, const int* slot_dev, int slot_host, float* Bmem, float* cmem,
                       float* scratch, const int* px_count_dev, frtm_stream_t stream);
 
+/* Memory.update (memory.py:59-92) for a WINDOW of W frames in three launches: the W slot choices one after the other on the device
+ * (sample weights updated in between exactly as W calls of frtm_memory_next_slot would; counts[f * count_stride] < min_count skips
+ * frame f), the W feature copies (features: (W, len) dense), the W low-resolution normal equations from float label planes
+ * `label_stride` elements apart (hinge pixel weights from the same counts).  slots: device int[W] scratch, left filled. */
+int frtm_memory_update_window(float* sw, int cap, float lr, int num_samp_is_zero, int* state, const int* counts, int count_stride,
+                              int min_count, int W, int* slots, const float* features, float* samples, int len, const float* labels,
+                              size_t label_stride, int H, int Wd, int h, int w, float tf, float* Bmem, float* cmem, float* scratch,
+                              frtm_stream_t stream);
 /* Memory.update_sample_weights (model/memory.py:65-92) on the device, no host sync.
  * sw: (cap) sample weights, updated in place.  state: device int32[4] = {previous_replace_ind or -1,
  * replace index written by this call, number of inserts performed so far (incremented here), number of inserts skipped

@@ -714,3 +714,39 @@ def test_count_above_exact(shape):
     mm = flat[:n * shape[0]].view(shape[0], n)                     # base address off by 4 bytes
     assert torch.equal(ops.count_above(mm).cpu(), (mm > 0.5).sum(1).cpu().int())
     assert int(ops.count_above(torch.zeros(2, 33, 17, device=DEV)).sum()) == 0
+
+
+@pytest.mark.parametrize('memory_size', [80, 6])
+def test_window_inserts_equal_frame_by_frame(memory_size):
+    """The memory inserts of a tracking window as ONE batched update (slots chosen one after the other inside one launch, W feature
+    copies, W normal-equation builds) == the frame-by-frame update() calls, bit for bit: sample weights, slots, samples, normal
+    equations, filters, counters, labels -- also with a memory SMALLER than the window (a slot is taken twice inside one window)."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.discriminator import Discriminator
+    seq = SyntheticSequence('w', 27, (192, 256), 2, seed=11)
+    seq.preload(DEV)
+    res = []
+    for batched in (False, True):
+        trk = _tracker(memory_size=memory_size, init_iters=(2, 3), update_iters=(3,))
+        torch.manual_seed(7)
+        for cls in (Discriminator,):
+            cls.window_inserts = batched
+        try:
+            labels, _ = trk.run_sequence(seq)
+        finally:
+            Discriminator.window_inserts = True
+        ds = [t.discriminator for t in trk.targets.values()]
+        res.append(dict(labels=torch.stack([l.reshape(192, 256) for l in labels]).cpu(),
+                        state=[(d.memory.weights.clone(), d.memory.samples.clone(), d.memory.normal_B.clone(), d.memory.normal_c.clone(),
+                                d.filter.weight.detach().clone()) for d in ds],
+                        counts=[(d.memory.insert_counts, d.num_solves, d.num_early_outs, d.frame_num, d.memory.current_size) for d in ds]))
+    a, b = res
+    assert a['counts'] == b['counts'], (a['counts'], b['counts'])
+    assert a['counts'][0][1] >= 2 and a['counts'][0][3] == 26 and sum(a['counts'][0][0]) == 26      # re-solves happened; every frame inserted or skipped by the early-out
+    for sa, sb in zip(a['state'], b['state']):
+        n_used = min(memory_size, 3 + 20)                     # (slots beyond the filled ones hold whatever the allocator left there)
+        for k, (x, y) in enumerate(zip(sa, sb)):
+            if k < 4:
+                x, y = x[:n_used], y[:n_used]
+            assert torch.equal(x, y), k
+    assert torch.equal(a['labels'], b['labels'])
