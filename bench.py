@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
+    ap.add_argument('--no-window-inserts', action='store_true', help='memory inserts frame by frame (3 launches per frame and object) instead of one batched update per window')
     ap.add_argument('--no-refiner-graph', action='store_true', help='refiner windows launched kernel by kernel instead of replayed as hipGraphs')
     ap.add_argument('--trunk-graph', action='store_true', help='trunk passes replayed as hipGraphs instead of launched kernel by kernel (no gain measured)')
     ap.add_argument('--no-fold-tail', action='store_true', help='a last trunk batch of 1-3 frames stays a pass of its own instead of joining the one before it')
@@ -470,6 +471,9 @@ def main():
     tracker.first_batch = args.first_batch or None
     tracker.graph_trunk = args.trunk_graph
     tracker.graph_refiner = not args.no_refiner_graph
+    if args.no_window_inserts:
+        from frtm_vos_amd.model.discriminator import Discriminator as _D
+        _D.window_inserts = False
     tracker.refiner.parallel_levels = not args.refiner_serial
     tracker.init_lanes = args.init_lanes
     tracker.overlap_first_pass = args.first_pass_overlap
