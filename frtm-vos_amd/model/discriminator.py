@@ -368,6 +368,7 @@ class Discriminator(nn.Module):
         self._solves_host = 0            # filter re-solves / "fewer than 10 pixels" early-outs decided on the host since init(); the ones
         self._early_outs_host = 0        # decided on the device are counted there (num_solves / num_early_outs add the two)
         self._guarded_runs = 0
+        self._fits_key, self._fits = None, False
         self.num_persistent_aborts = 0   # persistent CG launches that timed out (GPU shared with another resident-hungry kernel)
         self.update_optimizer = None
         self.current_sample = None
@@ -384,7 +385,15 @@ class Discriminator(nn.Module):
     def guards_on_device(self):
         """Will update() decide the early-out of a re-solve frame on the device (no host-side pixel count needed)?"""
         o = self.update_optimizer
-        return bool(self.device_early_out and self.update_filters and o is not None and o.persistent)
+        if not (self.device_early_out and self.update_filters and o is not None and o.persistent and self.memory is not None):
+            return False
+        # ... and the re-solve really runs as persistent launches for this memory (maps at most 64 wide, capacity x row blocks <= 240):
+        # otherwise the caller reads the pixel counts once per re-solve frame for all objects instead of every object waiting for its own
+        m = self.memory
+        key = (m.capacity, m.samples.shape[1], m.grid[0], m.grid[1])
+        if self._fits_key != key:
+            self._fits_key, self._fits = key, H.lib().frtm_cg_persistent_plan(key[0], key[1], key[2], key[3], None, None) > 0
+        return self._fits
 
     def _device_counts(self):
         """(re-solves, early-outs) of the device-guarded runs since init().  SYNCHRONISES (diagnostics only)."""
