@@ -165,7 +165,7 @@ def path_counters(tracker, seq, n_frames):
     aborts = 0
     for obj_id, t in tracker.targets.items():
         d = t.discriminator
-        aborts += d.num_persistent_aborts + int(d.update_optimizer.poll_persistent_abort())
+        aborts += d.num_persistent_aborts + int(d.recover_from_abort())
         tracked = n_frames - 1 - seq.start_frame(obj_id)
         sched_ins += tracked
         sched_solve += tracked // d.train_skipping

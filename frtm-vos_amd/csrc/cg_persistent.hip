@@ -16,10 +16,13 @@
 //   then across workgroups: grid barrier, every workgroup sums a few elements over all slabs (fixed order), grid barrier, every
 //   workgroup reads the 864 sums and performs the CG vector step REDUNDANTLY in its own LDS copy of (b, r, r_prev, p, x): the
 //   same instructions on the same inputs give bit-identical vectors everywhere, so no third exchange is needed.
-// Two grid barriers per application (monotonic counter, agent-scope atomics; payloads travel as sc1 / write-through stores and
-// sc1 loads, so no L2 write-back fences are needed).  Every spin is bounded: on a timeout (another resident-hungry kernel holds
-// the CUs) the run aborts without touching x and leaves bar[2] raised; the host falls back to the multi-kernel form.
-// All sums have a fixed order: results are deterministic run to run.
+// Two grid barriers per application (monotonic counter, agent-scope atomics).  Memory model of the exchange (guide: "inter-workgroup
+// communication", form R1): payloads (slabs, qbuf) are sc1 / write-through stores, EVERY storing wave drains them with
+// s_waitcnt vmcnt(0) before the workgroup's arrival is counted, consumers read them with sc1 loads (L1-bypassing), so neither an L2
+// write-back nor an L1 invalidate is needed.  Every polled word (arrivals, abort flag) is zeroed by a memset node in front of EVERY
+// launch (also under graph replay): a launch never inherits state from the one before it.  Every spin is bounded: on a timeout
+// (another resident-hungry kernel holds the CUs) the run aborts without touching x, bumps the sticky abort counter stats[2] and the
+// host re-runs the solve in the multi-kernel form (model/optimizer.py).  All sums have a fixed order: results are deterministic.
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
@@ -40,24 +43,31 @@ struct Params {
   int N, c, h, w, R, parts, iters, has_p, apply_dff, fr, std_alpha, parity;
   float dff, lam2, invM, step;
   const int* guard; int guard_min; unsigned* stats;     // optional device-side early-out and its counters (see the guarded entry)
+  int count_run;                                        // add this launch to stats[0] (completed) / stats[1] (skipped by the guard)
+  long long spin_limit;                                 // barrier time-out in 10 ns ticks
 };
 
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Grid barrier on a monotonic counter.  Returns false (in every thread of the workgroup) if the run was aborted.
-__device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_flag, unsigned target, int* sh_flag) {
-  __syncthreads();                                   // this workgroup's stores of the phase are issued
+__device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_flag, unsigned* stats, unsigned target, long long limit,
+                                          int* sh_flag) {
+  // EVERY wave drains its own write-through stores of the phase before the workgroup is counted as arrived: the barrier below only
+  // orders waves inside the CU, it does not wait for another wave's stores to leave it (round-2 ADVICE; guide pitfall 14).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and have left the CU (they are write-through)
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     int ok = 1;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-      if (wall_clock64() - t0 > 400000LL) {            // 4 ms at 100 MHz: some workgroup never became resident
-        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wall_clock64() - t0 > limit) {               // default 4 ms at 100 MHz: some workgroup never became resident
+        // the first workgroup to give up counts the abort (sticky, read by the host); the flag itself lives for this launch only
+        if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
+          __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
       }
@@ -132,14 +142,14 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
   // was left in device memory by an earlier kernel of this stream, every workgroup reads the same value and the whole launch
   // returns before its first barrier.  The host never has to wait for the count.
   if (P.guard != nullptr && *P.guard < P.guard_min) {
-    if (g == 0 && tid == 0 && P.stats) atomicAdd(P.stats + 1, 1u);
+    if (g == 0 && tid == 0 && P.stats && P.count_run) atomicAdd(P.stats + 1, 1u);
     return;
   }
   const int n_s = g / P.parts, part = g - n_s * P.parts;
   const int r0 = part * P.R;
   const int R = min(P.R, P.h - r0);                   // rows this workgroup owns (>= 1 by construction)
   const int c = P.c, h = P.h, w = P.w, hw = h * w, n = c * 9;
-  unsigned* counter = P.bar;                          // bar[0] arrivals, bar[1] exits, bar[2] abort flag (left raised for the host)
+  unsigned* counter = P.bar;                          // bar[0] arrivals, bar[2] abort flag of THIS launch (both zeroed by the launch function)
   unsigned* abort_flag = P.bar + 2;
   unsigned epoch = 0;
   // optional phase stamps of workgroup 0 (bar[3] != 0): 10 ns ticks into qbuf[NMAX ..] as raw ints (tools/cg_phase_times.py)
@@ -147,18 +157,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
   int n_stamp = 0;
   auto stamp = [&]() { if (stamp_on && tid == 0 && n_stamp < 250) { ((int*)P.qbuf)[NMAX + n_stamp] = (int)(wall_clock64() & 0x7fffffff); } ++n_stamp; };
   stamp();
-  // Every workgroup leaves through here.  The last one out zeroes the counters, so the next launch -- also the SAME captured
-  // launch replayed from a hipGraph -- starts clean; nobody polls any more at that point (a workgroup only leaves after its last barrier).
-  auto leave = [&]() {
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned k = __hip_atomic_fetch_add(P.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k == (unsigned)G - 1u) {
-        __hip_atomic_store(P.bar + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(P.bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
+  auto leave = [&]() {};                              // (the barrier words are reset by the memset node of the NEXT launch)
 
   // ---- resident data: X rows in registers, B / c rows and the vectors in LDS ----
   float xr[CPW][XR];
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
     float* slab = P.slabs + (size_t)g * NMAX;
     for (int i = tid; i < NMAX; i += NT) st_wt(slab + i, gl[i]);
     stamp();
-    if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) return false;
     stamp();
     // distributed fixed-order sum: workgroup g owns the elements [g * epw, (g + 1) * epw), one wave per element
     const int epw = (n + G - 1) / G;
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       }
     }
     stamp();
-    if (!grid_sync(counter, abort_flag, (++epoch) * (unsigned)G, sh_flag_p)) return false;
+    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) return false;
     stamp();
     for (int i = tid; i < NMAX; i += NT) vq[i] = i < n ? ld_l2(P.qbuf + i) + P.lam2 * v[i] : 0.f;        // (gl aliases vq: its stores are long done)
     __syncthreads();
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       P.state[4] = rho_cur;
       P.state[1] = alpha;
       P.state[2] = beta_last;
-      if (P.stats) atomicAdd(P.stats, 1u);
+      if (P.stats && P.count_run) atomicAdd(P.stats, 1u);
     }
   }
   leave();
@@ -383,11 +382,27 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
 
 extern "C" {
 
+// Workgroups the resident form may use: one 512-thread workgroup per CU (256 VGPRs per lane, ~80 KB of LDS), on at most 15/16 of the
+// CUs of THIS device (240 of an MI355X's 256: the rest stays free for kernels of other streams; a partitioned or CU-masked device
+// gets a proportionally smaller budget and takes the multi-kernel form sooner).  Cached per device.
+static int resident_budget() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 240; }
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+    cached[dev] = cus - cus / 16;
+  }
+  return cached[dev];
+}
+
 int frtm_cg_persistent_plan(int N, int c, int h, int w, int* parts_out, int* rows_out) {
   if (N < 1 || c < 1 || c > CPW * NWAVE || w < 1 || w > 64 || h < 1) return 0;
+  const int budget = resident_budget();
   const int min_parts = ceil_div(h, RMAX);
-  if ((long)N * min_parts > 240) return 0;
-  int parts = 240 / N;
+  if ((long)N * min_parts > budget) return 0;
+  int parts = budget / N;
   if (parts > h) parts = h;
   if (parts < min_parts) parts = min_parts;
   int R = ceil_div(h, parts);
@@ -401,7 +416,7 @@ int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float*
                                    float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
                                    int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                                    float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
-                                   frtm_stream_t stream) {
+                                   int count_run, int debug_abort, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && Bm && cm && sw && w2 && vec && state && slabs && qbuf && bar && iters >= 0, "frtm_cg_run_persistent: bad argument");
   int parts = 0, R = 0;
   const int G = frtm_cg_persistent_plan(N, c, h, w, &parts, &R);
@@ -410,12 +425,16 @@ int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float*
   P.X = X; P.Bm = Bm; P.cm = cm; P.sw = sw; P.w2 = w2; P.vec = vec; P.state = state; P.slabs = slabs; P.qbuf = qbuf; P.bar = bar;
   P.N = N; P.c = c; P.h = h; P.w = w; P.R = R; P.parts = parts; P.iters = iters; P.has_p = has_p; P.apply_dff = apply_dff;
   P.fr = fletcher_reeves; P.std_alpha = standard_alpha; P.parity = 0; P.dff = dff; P.lam2 = lam2; P.invM = invM; P.step = step;
-  P.guard = guard_count; P.guard_min = guard_min; P.stats = stats;
+  P.guard = guard_count; P.guard_min = guard_min; P.stats = stats; P.count_run = count_run;
+  P.spin_limit = debug_abort ? 0LL : 400000LL;          // (debug_abort: the first workgroup to wait gives up at once -- tests of the fallback)
   static bool attr_set = false;
   if (!attr_set) {
     FRTM_HIP(hipFuncSetAttribute((const void*)k_cg_run_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4));
     attr_set = true;
   }
+  // every polled word starts at zero in EVERY launch (a memset node: also when the launch is replayed from a hipGraph); bar[3] is the
+  // phase-stamp switch of tools/cg_phase_times.py and is left alone
+  FRTM_HIP(hipMemsetAsync(bar, 0, 3 * sizeof(unsigned), (hipStream_t)stream));
   k_cg_run_persistent<<<G, NT, L_TOTAL * 4, (hipStream_t)stream>>>(P);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
@@ -426,7 +445,7 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
                            int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                            float lam2, float invM, float step, frtm_stream_t stream) {
   return frtm_cg_run_persistent_guarded(X, Bm, cm, sw, N, c, h, w, w2, vec, state, slabs, qbuf, bar, iters, has_p, apply_dff, fletcher_reeves,
-                                        standard_alpha, dff, lam2, invM, step, nullptr, 0, nullptr, stream);
+                                        standard_alpha, dff, lam2, invM, step, nullptr, 0, nullptr, 0, 0, stream);
 }
 
 }  // extern "C"

@@ -714,6 +714,20 @@ __global__ __launch_bounds__(256) void k_vec_axpy(float* __restrict__ y, float a
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) y[i] += a * x[i];
 }
 
+// Snapshot / conditional roll-back of solver state around a CHAIN-form solve whose early-out is decided on the device
+// (frtm_guarded_copy): mode 0 copies, mode 1 copies only when *guard < guard_min and counts the outcome.
+__global__ __launch_bounds__(256) void k_guarded_copy(float* __restrict__ dst, const float* __restrict__ src, int n,
+                                                      const int* __restrict__ guard, int guard_min, int mode, unsigned* __restrict__ stats,
+                                                      int count) {
+  bool go = true;
+  if (mode == 1) {
+    go = guard != nullptr && guard[0] < guard_min;
+    if (stats && count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(stats + (go ? 1 : 0), 1u);
+  }
+  if (!go) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_transpose2d(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -812,6 +826,7 @@ void frtm_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+
 }
 
 extern "C" {
@@ -1044,6 +1059,14 @@ int frtm_cg_step_small(const float* slabs, int nslab, int stride, float lam2, fl
   FRTM_CHECK_ARG(slabs && x && r && r_prev && p && q && state && nslab > 0 && n > 0 && n <= 1024, "frtm_cg_step_small: needs 0 < n <= 1024 (got %d)", n);
   k_cg_step_small<<<1, 1024, 0, (hipStream_t)stream>>>(slabs, nslab, stride, lam2, x, r, r_prev, p, q, n, invM, first, last, standard_alpha,
                                                        fletcher_reeves, state);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_guarded_copy(float* dst, const float* src, int n, const int* guard_count, int guard_min, int mode, unsigned* stats, int count,
+                      frtm_stream_t stream) {
+  FRTM_CHECK_ARG(dst && src && n > 0 && (mode == 0 || (mode == 1 && guard_count)), "frtm_guarded_copy: bad argument");
+  k_guarded_copy<<<min(ceil_div(n, 256), 64), 256, 0, (hipStream_t)stream>>>(dst, src, n, guard_count, guard_min, mode, stats, count);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

@@ -368,7 +368,6 @@ class Discriminator(nn.Module):
         self._solves_host = 0            # filter re-solves / "fewer than 10 pixels" early-outs decided on the host since init(); the ones
         self._early_outs_host = 0        # decided on the device are counted there (num_solves / num_early_outs add the two)
         self._guarded_runs = 0
-        self._fits_key, self._fits = None, False
         self.num_persistent_aborts = 0   # persistent CG launches that timed out (GPU shared with another resident-hungry kernel)
         self.update_optimizer = None
         self.current_sample = None
@@ -383,25 +382,17 @@ class Discriminator(nn.Module):
     device_early_out = True
 
     def guards_on_device(self):
-        """Will update() decide the early-out of a re-solve frame on the device (no host-side pixel count needed)?"""
+        """Will update() decide the early-out of a re-solve frame on the device (no host-side pixel count needed)?  True for every
+        memory shape: persistent launches test the guard themselves, the multi-kernel chain (maps wider than 64 columns, memories
+        beyond the resident budget) is rolled back on the device when the guard says so (GaussNewtonCG.run)."""
         o = self.update_optimizer
-        if not (self.device_early_out and self.update_filters and o is not None and o.persistent and self.memory is not None):
-            return False
-        # ... and the re-solve really runs as persistent launches for this memory (maps at most 64 wide, capacity x row blocks <= 240):
-        # otherwise the caller reads the pixel counts once per re-solve frame for all objects instead of every object waiting for its own
-        m = self.memory
-        key = (m.capacity, m.samples.shape[1], m.grid[0], m.grid[1])
-        if self._fits_key != key:
-            self._fits_key, self._fits = key, H.lib().frtm_cg_persistent_plan(key[0], key[1], key[2], key[3], None, None) > 0
-        return self._fits
+        return bool(self.device_early_out and self.update_filters and o is not None and o.can_guard() and self.memory is not None)
 
     def _device_counts(self):
         """(re-solves, early-outs) of the device-guarded runs since init().  SYNCHRONISES (diagnostics only)."""
         if self._guarded_runs == 0 or self.update_optimizer is None:
             return 0, 0
-        k = max(1, len([n for n in self.update_iters if n > 0]))               # persistent launches per run
-        done, skipped = self.update_optimizer.persistent_counts()
-        return done // k, skipped // k
+        return self.update_optimizer.persistent_counts()
 
     @property
     def num_solves(self):
@@ -507,7 +498,7 @@ class Discriminator(nn.Module):
         memory = self._memory('memory', self.memory_size, (c,) + tuple(x.shape[-2:]), y.shape[-3:], dev)
         if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing():
             opt = self._init_body(mem0, memory, None if not self.keep_hires else y)
-            opt.persistent = bool(self.persistent_cg)
+            opt.persistent = bool(self.persistent_cg) and not GaussNewtonCG.abort_seen_in_process
             opt.reset_persistent_counts()
             self.memory, self.update_optimizer = memory, opt
             return
@@ -525,7 +516,7 @@ class Discriminator(nn.Module):
         memory.current_size = K
         opt = ent['opt']
         opt._has_p = True
-        opt.persistent = bool(self.persistent_cg)
+        opt.persistent = bool(self.persistent_cg) and not GaussNewtonCG.abort_seen_in_process
         opt.reset_persistent_counts()
         self._w1T, self._w1T_key = ent['w1T'], (self.project.weight.data_ptr(), self.project.weight._version)
         self.memory, self.update_optimizer = memory, opt
@@ -614,18 +605,22 @@ class Discriminator(nn.Module):
         self.memory.update_window(cfts.contiguous(), masks, plane, counts)
         if self.frame_num % self.train_skipping == 0:
             opt = self.update_optimizer
-            last = counts[W - 1, plane:plane + 1]
-            if opt.peek_persistent_abort() and opt.poll_persistent_abort():
-                self.num_persistent_aborts += 1
-            if opt.can_guard():
-                opt.run(self.update_iters, guard=last, guard_min=10)
-                self._guarded_runs += 1
-            else:                                                   # (shape does not fit the resident form: decide here)
-                if int(last.item()) < 10:
-                    self._early_outs_host += 1
-                else:
-                    opt.run(self.update_iters)
-                    self._solves_host += 1
+            if opt.peek_persistent_abort():
+                self.recover_from_abort()
+            opt.run(self.update_iters, guard=counts[W - 1, plane:plane + 1], guard_min=10)
+            self._guarded_runs += 1
+
+    def recover_from_abort(self):
+        """A persistent launch of the update solver timed out (its workgroups did not all become resident: the GPU is shared): it left
+        filter and solver state untouched.  Confirms it (one 4-byte read), switches the solver to the multi-kernel form and RE-RUNS the
+        missed solve there, on the memory as it is now.  Called where a peek at the mirrored abort counter says so (every re-solve
+        frame), and after the final synchronise of a sequence (Tracker.run_sequence) -- no solve is lost, at worst it runs late."""
+        opt = self.update_optimizer
+        if opt is None or not opt.poll_persistent_abort():
+            return False
+        self.num_persistent_aborts += 1
+        opt.run(self.update_iters)
+        return True
 
     def update(self, train_y, num_positive=None, count_dev=None):
         """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
@@ -641,27 +636,17 @@ class Discriminator(nn.Module):
             self.memory.update(self.current_sample, train_y, count_dev=count_dev)
             return
         opt = self.update_optimizer
-        if num_positive is None and count_dev is not None and self.device_early_out and opt.persistent:
-            # re-solve frame, the early-out decided on the device as well: guarded insert + guarded persistent launches
-            if opt.peek_persistent_abort() and opt.poll_persistent_abort():
-                self.num_persistent_aborts += 1
-            else:
-                self.memory.update(self.current_sample, train_y, count_dev=count_dev)
-                if opt.can_guard():
-                    opt.run(self.update_iters, guard=count_dev, guard_min=10)
-                    self._guarded_runs += 1
-                    return
-                num_positive = int(count_dev.item())                    # (shape does not fit the resident form: decide here)
-                if num_positive < 10:
-                    self._early_outs_host += 1
-                    return
-                opt.run(self.update_iters)
-                self._solves_host += 1
-                return
+        if solve and opt.peek_persistent_abort():
+            self.recover_from_abort()
+        if num_positive is None and count_dev is not None and self.device_early_out and opt.can_guard():
+            # re-solve frame, the early-out decided on the device as well: guarded insert + guarded solve, no device->host read
+            self.memory.update(self.current_sample, train_y, count_dev=count_dev)
+            opt.run(self.update_iters, guard=count_dev, guard_min=10)
+            self._guarded_runs += 1
+            return
         if num_positive is None:
             num_positive = int((count_dev if count_dev is not None else ops.count_above(train_y.reshape(1, -1))).item())
-        if opt.poll_persistent_abort():                             # (the host has just waited for the pixel counts anyway)
-            self.num_persistent_aborts += 1
+        self.recover_from_abort()                                   # (the host has just waited for the pixel counts anyway)
         if num_positive < 10:
             self._early_outs_host += 1
             return

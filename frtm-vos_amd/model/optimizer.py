@@ -72,6 +72,10 @@ class GaussNewtonCG:
         self._buf = None
         self._pbuf = None
         self._persistent_launched = False
+        self._gstats = None              # device int32[4]: guarded runs completed / skipped by the device-side early-out, persistent launches aborted
+        self._shadow = None              # snapshot of the solver state around a chain-form run with a device-side guard
+        self._aborts_handled = 0
+        self.debug_abort = False         # tests: the next persistent launches time out at their first barrier
 
     # ---- device state -------------------------------------------------------------------
     def _alloc(self):
@@ -81,9 +85,11 @@ class GaussNewtonCG:
             return
         dev = self.x[0].device
         self._n, self._n1, self._n2 = n, n1, n2
-        self._buf = torch.zeros(6, n, device=dev)           # b, r, r_prev, p, q, delta
-        self._state = torch.zeros(8, device=dev)
+        self._all = torch.zeros(6 * n + 8, device=dev)      # one allocation: a guarded chain-form run snapshots it with one copy
+        self._buf = self._all[:6 * n].view(6, n)            # b, r, r_prev, p, q, delta
+        self._state = self._all[6 * n:]
         self._state[:1].fill_(1.0)                          # rho = ones(1)  (optimizer.py:29); fill_, not a blocking indexed scalar store
+        self._shadow = None
         self._partial = torch.zeros(4 * 64, device=dev)
         self._has_p = False
 
@@ -132,23 +138,32 @@ class GaussNewtonCG:
             self._state[:1].fill_(1.0)
 
     # ---- solver ---------------------------------------------------------------------------
+    # Set (for the whole process) once a persistent launch has timed out: the GPU is shared with something that keeps this solver's
+    # workgroups from becoming resident together, so new target models start in the multi-kernel form (Discriminator.init).
+    abort_seen_in_process = False
+
     def can_guard(self):
-        """True if the next run() can take a device-side early-out (``guard``): the problem runs as persistent launches."""
-        if self._generic or not self.persistent:
-            return False
-        self.problem.initialize()                                   # (the plan depends on the number of active samples)
-        return self._persistent_plan() is not None
+        """True if run() can take a device-side early-out (``guard``): every problem with HIP operators can -- persistent launches
+        test the guard themselves, the multi-kernel chain is rolled back on the device when the guard says so."""
+        return not self._generic
+
+    def _stats(self):
+        if self._gstats is None:
+            dev = self.x[0].device
+            self._gstats = torch.zeros(4, dtype=torch.int32, device=dev)
+            # the abort counter (stats[2]) is mirrored into pinned host memory after every persistent launch: peek without waiting
+            self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._gstats
 
     def run(self, num_cg_iter, num_gn_iter=None, guard=None, guard_min=10):
         """``guard`` (device int32, one element): the whole run becomes a no-op ON THE DEVICE when its value is below ``guard_min`` --
-        the reference's "fewer than 10 pixels" early-out (discriminator.py:214) without a device->host read.  Only for problems
-        whose GN iterations run as persistent launches (``can_guard()``)."""
+        the reference's "fewer than 10 pixels" early-out (discriminator.py:214) without a device->host read.  Persistent launches
+        return before their first barrier; a run in the multi-kernel form is executed on a snapshot basis: solver state and variables
+        are copied aside first and copied back afterwards if the guard fails (4 tiny launches; the wasted solve is the rare case)."""
         self.problem.initialize()
         self._guard = None
-        if guard is not None:
-            if not self.can_guard():
-                raise RuntimeError('GaussNewtonCG.run(guard=...): only for persistent launches (can_guard())')
-            self._guard = (guard, int(guard_min))
+        if guard is not None and self._generic:
+            raise RuntimeError('GaussNewtonCG.run(guard=...): only for problems with HIP operators (can_guard())')
         if isinstance(num_cg_iter, int):
             if num_gn_iter is None:
                 raise ValueError('Must specify number of GN iter if CG iter is constant')
@@ -160,12 +175,39 @@ class GaussNewtonCG:
                 self._generic_GN_iter(n)
             return self.external_losses, self.internal_losses, self.residuals
         self._alloc()
+        chain_guard = False
+        if guard is not None:
+            self._guard = (guard, int(guard_min))
+            chain_guard = self._persistent_plan() is None
+            if chain_guard:
+                self._snapshot()
         try:
-            for n in num_cg_iter:
+            for k, n in enumerate(num_cg_iter):
+                self._last_of_run = k == len(num_cg_iter) - 1
                 self.run_GN_iter(n)
         finally:
             self._guard = None
+        if chain_guard:
+            self._rollback_unless(guard, int(guard_min))
         return self.external_losses, self.internal_losses, self.residuals
+
+    def _snapshot(self):
+        n = self._all.numel() + sum(v.numel() for v in self.x)
+        if self._shadow is None or self._shadow.numel() != n:
+            self._shadow = torch.empty(n, device=self._all.device)
+        o = self._all.numel()
+        H.call('frtm_guarded_copy', H.ptr(self._shadow), H.ptr(self._all), o, None, 0, 0, None, 0)
+        for v in self.x:
+            H.call('frtm_guarded_copy', self._shadow.data_ptr() + 4 * o, H.ptr(v.data), v.numel(), None, 0, 0, None, 0)
+            o += v.numel()
+
+    def _rollback_unless(self, guard, guard_min):
+        st = self._stats()
+        o = self._all.numel()
+        H.call('frtm_guarded_copy', H.ptr(self._all), H.ptr(self._shadow), o, guard.data_ptr(), guard_min, 1, H.ptr(st), 1)
+        for v in self.x:
+            H.call('frtm_guarded_copy', H.ptr(v.data), self._shadow.data_ptr() + 4 * o, v.numel(), guard.data_ptr(), guard_min, 1, None, 0)
+            o += v.numel()
 
     persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
 
@@ -182,11 +224,9 @@ class GaussNewtonCG:
         """linearize + run_CG + apply_step of run_GN_iter in ONE launch; host-side bookkeeping as in run_CG."""
         if self._pbuf is None:
             dev = self._buf.device
-            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
-                          torch.zeros(2, dtype=torch.int32, device=dev))
-            # the abort flag (bar[2]) mirrored into pinned host memory after every launch: read without waiting (poll_persistent_abort)
-            self._abort_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        slabs, qbuf, bar, stats = self._pbuf
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
+        slabs, qbuf, bar = self._pbuf
+        stats = self._stats()
         guard, guard_min = self._guard if getattr(self, '_guard', None) is not None else (None, 0)
         dff = float(self.direction_forget_factor)
         if dff == 0:
@@ -196,41 +236,43 @@ class GaussNewtonCG:
                H.ptr(a['w2']), H.ptr(self._buf), H.ptr(self._state), H.ptr(slabs), H.ptr(qbuf), H.ptr(bar),
                int(num_cg_iter), int(self._has_p), int(self._has_p and dff != 0), int(self.fletcher_reeves), int(self.standard_alpha),
                dff if dff != 0 else 1.0, float(a['lam2']), 1.0 / m1, float(self.step_alpha),
-               None if guard is None else guard.data_ptr(), guard_min, H.ptr(stats))
+               None if guard is None else guard.data_ptr(), guard_min, H.ptr(stats),
+               int(guard is not None and getattr(self, '_last_of_run', True)), int(bool(self.debug_abort)))
         self._has_p = True
         self._persistent_launched = True
-        if guard is not None:
-            self._abort_host.copy_(bar[2:3], non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            self._abort_host.copy_(stats[2:3], non_blocking=True)
 
     def reset_persistent_counts(self):
-        if self._pbuf is not None:
-            self._pbuf[3].zero_()
+        if self._gstats is not None:
+            self._gstats[:2].zero_()
 
     def persistent_counts(self):
-        """(completed persistent launches, launches that took the device-side early-out) so far.  SYNCHRONISES."""
-        if self._pbuf is None:
+        """(guarded runs completed, guarded runs that took the device-side early-out) so far.  SYNCHRONISES."""
+        if self._gstats is None:
             return 0, 0
-        a, b = self._pbuf[3].tolist()
+        a, b = self._gstats[:2].tolist()
         return int(a), int(b)
 
     def peek_persistent_abort(self):
-        """Non-blocking look at the abort flag as of the last guarded launch whose mirror copy has landed (may lag by one launch).
-        True -> the caller should call poll_persistent_abort() (which waits, clears the flag and switches to the multi-kernel form)."""
-        return self._pbuf is not None and int(self._abort_host[0]) != 0
+        """Non-blocking look at the abort counter as of the last persistent launch whose mirror copy has landed (may lag by a launch).
+        True -> call poll_persistent_abort() (which waits, switches to the multi-kernel form and tells the caller to re-run the solve)."""
+        return self._gstats is not None and self._persistent_launched and int(self._abort_host[0]) > self._aborts_handled
 
     def poll_persistent_abort(self):
-        """True if a persistent launch since the last poll gave up (its workgroups could not all become resident within the
-        spin time-out, e.g. another process holds the GPU's CUs): that run left the variable untouched.  Clears the flag and
-        switches this solver back to the multi-kernel form.  SYNCHRONISES (one 4-byte read); call it where the host waits anyway."""
-        if not self._persistent_launched or self._pbuf is None:
+        """True if a persistent launch since the last poll gave up (its workgroups could not all become resident within the spin
+        time-out, e.g. another process holds the GPU's CUs): that launch left variable and solver state untouched, the CALLER re-runs
+        the solve (this solver is in the multi-kernel form from now on, and so is every solver created later in this process).
+        SYNCHRONISES (one 4-byte read); call it where the host waits anyway, or after peek_persistent_abort() said so."""
+        if not self._persistent_launched or self._gstats is None:
             return False
         self._persistent_launched = False
-        bar = self._pbuf[2]
-        if int(bar[2].item()) == 0:
+        n = int(self._gstats[2].item())
+        if n <= self._aborts_handled:
             return False
-        bar.zero_()
-        self._abort_host.zero_()
+        self._aborts_handled = n
         self.persistent = False
+        GaussNewtonCG.abort_seen_in_process = True
         return True
 
     def run_GN_iter(self, num_cg_iter):

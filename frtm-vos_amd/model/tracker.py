@@ -107,6 +107,11 @@ class Tracker(nn.Module):
         self.current_masks = None
         self.num_objects = 0
         self.targets = dict()
+        # Optional callable(obj_id) -> (project.weight, filter.weight): the weights a new target model STARTS from.  The reference
+        # draws them un-seeded when the object appears (tracker.py:174-180, before its "HACK for debugging" seeds anything), so two
+        # runs of the reference never start alike; reproducible runs and parity tests against a CPU run inject them here.
+        self.start_weights = None
+        self._raw_log = None             # list: (frame, masks before the merge) of every tracked frame is appended (ytvos merge, parity tests)
 
     def release_targets(self):
         """Ends a sequence: the target models go back to a pool and serve the next sequence's objects, so that the steady
@@ -275,8 +280,8 @@ class Tracker(nn.Module):
         torch.cuda.synchronize()
         for t in self.targets.values():                      # (a 4-byte read per object, after the synchronise above)
             d = t.discriminator
-            if d is not None and d.update_optimizer is not None and d.update_optimizer.poll_persistent_abort():
-                d.num_persistent_aborts += 1
+            if d is not None and d.recover_from_abort():     # a timed-out persistent launch: its solve is re-run now (multi-kernel form)
+                torch.cuda.synchronize()
         T = time() - t0
         self._raw_log = None
         return outputs, N / T
@@ -477,6 +482,12 @@ class Tracker(nn.Module):
                                   discriminator=self._disc_pool.pop() if self._disc_pool else None,
                                   start_frame=self.current_frame, start_mask=mask)
             self.targets[obj_id] = target
+            if self.start_weights is not None:
+                w1, w2 = self.start_weights(obj_id)
+                d = target.discriminator
+                d.project.weight.data.copy_(w1.to(d.project.weight.dtype))
+                d.filter.weight.data.copy_(w2.to(d.filter.weight.dtype))
+                d._invalidate()
             torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept:
             np.random.seed(0)                  # augmentation draws are identical for every object
             im, msk = self.augment(image, mask)
@@ -596,6 +607,8 @@ class Tracker(nn.Module):
             for t2 in self.targets.values():
                 if t2 is not t1 and t2.start_frame == self.current_frame:
                     self.current_masks[t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+        if getattr(self, '_raw_log', None) is not None:
+            self._raw_log.append((self.current_frame, self.current_masks.clone()))
         ops.merge_masks_(self.current_masks)                                                 # :214-221
         if active and self.disc_params.update_filters:
             counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync

@@ -173,10 +173,13 @@ int frtm_joint_expand(const float* G, int nslab, const float* w2, int Cin, int c
  * literal recurrences (carried p / r_prev / rho as in frtm_cg_begin / _direction / _step_small), then w2 += step * delta.
  * The sample features X (N,c,h,w) are read once and stay in registers; Bm (N,9,h,w), cm (N,h,w), sw (N) are the memory's
  * low-resolution normal equations and sample weights.  vec: the solver's 6*n floats {b,r,r_prev,p,q,delta}, n = 9c;
- * state: float[8] as above; slabs: >= 256*864 floats, qbuf: >= 864 + 256 floats, bar: unsigned[4], zero-initialised once (bar[3] != 0: workgroup 0 also writes phase time stamps to qbuf[864..])
- * (bar[2] != 0 afterwards = the run was ABORTED by its spin time-out -- x untouched, caller falls back and clears it).
- * frtm_cg_persistent_plan returns the number of workgroups (0 = shape not supported: w > 64, c > 96, N*ceil(h/10) > 240);
- * all of them must be resident at once: never run two of these launches concurrently on one GPU. */
+ * state: float[8] as above; slabs: >= 256*864 floats, qbuf: >= 864 + 256 floats, bar: unsigned[4] (bar[0..2]: arrivals / spare / abort flag
+ * of ONE launch, zeroed by a memset node in front of every launch; bar[3] != 0: workgroup 0 also writes phase time stamps to qbuf[864..]).
+ * A launch whose workgroups cannot all become resident within the spin time-out (4 ms) ABORTS: x, vec and state stay untouched and
+ * stats[2] (see the guarded entry) is incremented; the caller re-runs the solve in the multi-kernel form.
+ * frtm_cg_persistent_plan returns the number of workgroups (0 = shape not supported: w > 64, c > 96, or N*ceil(h/10) above the
+ * resident budget = 15/16 of the current device's CUs, 240 on an MI355X); all of them must be resident at once: never run two of these
+ * launches concurrently on one GPU. */
 int frtm_cg_persistent_plan(int N, int c, int h, int w, int* parts_out, int* rows_out);
 int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
                            float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
@@ -184,13 +187,21 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
                            float lam2, float invM, float step, frtm_stream_t stream);
 /* The same launch with the reference's early-out (discriminator.py:214, "fewer than 10 mask pixels above 0.5: no update") decided on
  * the DEVICE: guard_count (device int32, e.g. one element of frtm_count_above's output) < guard_min -> the launch returns without
- * touching anything.  stats (device unsigned[2], optional): [0] += 1 per completed solve, [1] += 1 per guarded early-out.  The host
+ * touching anything.  stats (device unsigned[4], optional): with count_run != 0, [0] += 1 per completed launch, [1] += 1 per guarded
+ * early-out; [2] += 1 per ABORTED launch (always).  debug_abort != 0 forces the time-out (tests of the caller's fallback).  The host
  * never waits for the pixel count, so a tracking loop enqueues whole sequences without a device->host read. */
 int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
                                    float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
                                    int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                                    float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
-                                   frtm_stream_t stream);
+                                   int count_run, int debug_abort, frtm_stream_t stream);
+/* The same early-out for solves that run as a CHAIN of launches (maps wider than 64 columns, memories beyond the resident budget,
+ * the fallback after an aborted persistent launch): the caller snapshots the solver's device state before the chain
+ * (mode 0: dst <- src, n floats) and rolls it back after it when the guard says the update should not have happened
+ * (mode 1: dst <- src only if *guard_count < guard_min; stats[1] += 1 then, else stats[0] += 1, when stats != NULL and count != 0).
+ * The work of a skipped solve is wasted (rare: an object with fewer than 10 pixels on a re-solve frame) -- nothing is read by the host. */
+int frtm_guarded_copy(float* dst, const float* src, int n, const int* guard_count, int guard_min, int mode, unsigned* stats, int count,
+                      frtm_stream_t stream);
 /* One CG iteration's vector work for n <= 1024 in a single workgroup (the 864-element filter problem): slab reduce
  * (q = sum_k slabs[k*stride+i] + lam2 p), <p,q>, alpha, r_prev/x/r updates, and -- unless `last` -- the next direction
  * (beta, p, rho).  Same order of operations as optimizer.py:113-151; replaces frtm_vec_reduce_slabs + frtm_cg_pq +

@@ -42,23 +42,24 @@ import torch.nn.functional as F
 # lib/utils.py:33-35.
 # --------------------------------------------------------------------------------------
 
-def bilinear_taps(n_in: int, n_out: int):
-    """Source taps of ATen's upsample_bilinear2d (align_corners=False), fp32 arithmetic:
+def bilinear_taps(n_in: int, n_out: int, dtype=torch.float32):
+    """Source taps of ATen's upsample_bilinear2d (align_corners=False), in the arithmetic of ``dtype`` (fp32 like the reference's
+    run; fp64 for the arbiter runs of tests/test_north_star_gpu.py):
     src = max(scale*(dst+0.5)-0.5, 0), i0=floor(src), i1=i0+(i0<n_in-1), l1=src-i0, l0=1-l1."""
-    scale = torch.tensor(float(n_in) / float(n_out), dtype=torch.float32)
-    dst = torch.arange(n_out, dtype=torch.float32)
+    scale = torch.tensor(float(n_in) / float(n_out), dtype=dtype)
+    dst = torch.arange(n_out, dtype=dtype)
     src = torch.clamp(scale * (dst + 0.5) - 0.5, min=0.0)
     i0 = src.to(torch.int64)
     i1 = i0 + (i0 < n_in - 1).to(torch.int64)
-    l1 = src - i0.to(torch.float32)
+    l1 = src - i0.to(dtype)
     l0 = 1.0 - l1
     return i0, i1, l0, l1
 
 
-def bilinear_matrix(n_in: int, n_out: int) -> torch.Tensor:
+def bilinear_matrix(n_in: int, n_out: int, dtype=torch.float32) -> torch.Tensor:
     """Dense (n_out, n_in) interpolation matrix of one axis."""
-    i0, i1, l0, l1 = bilinear_taps(n_in, n_out)
-    M = torch.zeros(n_out, n_in, dtype=torch.float32)
+    i0, i1, l0, l1 = bilinear_taps(n_in, n_out, dtype)
+    M = torch.zeros(n_out, n_in, dtype=dtype)
     rows = torch.arange(n_out)
     M.index_put_((rows, i0), l0, accumulate=True)
     M.index_put_((rows, i1), l1, accumulate=True)
@@ -71,8 +72,8 @@ class Bilinear:
     def __init__(self, lo_size, hi_size, dtype=torch.float32):
         self.h, self.w = lo_size
         self.H, self.W = hi_size
-        self.Uy = bilinear_matrix(self.h, self.H).to(dtype)      # (H,h)
-        self.Ux = bilinear_matrix(self.w, self.W).to(dtype)      # (W,w)
+        self.Uy = bilinear_matrix(self.h, self.H, dtype)         # (H,h)
+        self.Ux = bilinear_matrix(self.w, self.W, dtype)         # (W,w)
 
     def up(self, s):
         if (self.h, self.w) == (self.H, self.W):        # lib/utils.py:35 identity when sizes match
@@ -124,14 +125,14 @@ def conv1x1_wgrad(x, d):
 # Pixel weights  (model/discriminator.py:107-152, method 'hinge')
 # --------------------------------------------------------------------------------------
 
-def pixel_weights(y: torch.Tensor, pw_params) -> torch.Tensor:
+def pixel_weights(y: torch.Tensor, pw_params, dtype=torch.float32) -> torch.Tensor:
     """y (N,1,H,W) in {0,1}; returns sqrt(wf*y + wb*(1-y))."""
     if pw_params is None or pw_params['method'] == 'none':
-        return torch.ones_like(y, dtype=torch.float32)
+        return torch.ones_like(y, dtype=dtype)
     assert pw_params['method'] == 'hinge'
     tf = float(pw_params['tf'])
     N, C, H, W = y.shape
-    y = y.float()
+    y = y.to(dtype)
     px = y.sum(dim=(2, 3)).view(N, C, 1, 1)                 # :125
     af = px / (H * W)                                        # :126
     af = torch.where(px < 10, torch.full_like(af, tf), af)   # :130-131 too-small objects
@@ -295,7 +296,7 @@ class GaussNewtonCGRef:
         self.dff = direction_forget_factor
         self.step_alpha = step_alpha
         self.p = None
-        self.rho = torch.ones(())
+        self.rho = torch.ones((), dtype=variable[0].dtype)
         self.r_prev = None
         self.b = None
 
@@ -321,7 +322,7 @@ class GaussNewtonCGRef:
     def run_CG(self, num_iter):                              # optimizer.py:98-153 (x=None, eps=0)
         pr = self.problem
         if self.dff == 0:
-            self.p, self.rho, self.r_prev = None, torch.ones(()), None
+            self.p, self.rho, self.r_prev = None, torch.ones((), dtype=self.x[0].dtype), None
         elif self.p is not None:
             self.rho = self.rho / torch.tensor(self.dff, dtype=self.rho.dtype)   # fp32: may overflow to inf
         r = [t.clone() for t in self.b]
@@ -376,7 +377,7 @@ class DiscriminatorRef:
         self.update_optimizer = None
 
     def init(self, x, y):                                    # discriminator.py:154-199
-        pw = pixel_weights(y, self.pw_params).to(x.dtype)
+        pw = pixel_weights(y, self.pw_params, x.dtype)
         mem = MemoryRef(y.shape[0], x.shape[-3:], y.shape[-3:], self.lr, x.dtype)
         mem.initialize(x, y, pw)
         prob = InitProblemRef(mem, self.filter_reg, self.precond)
@@ -403,8 +404,8 @@ class DiscriminatorRef:
             return
         if (train_y > 0.5).sum() < 10:
             return
-        ys = (train_y > 0.5).float()
-        pw = pixel_weights(ys, self.pw_params).to(train_y.dtype)
+        ys = (train_y > 0.5).to(train_y.dtype)
+        pw = pixel_weights(ys, self.pw_params, train_y.dtype)
         self.memory.update(self.current_sample, train_y, pw)
         if self.frame_num % self.train_skipping != 0:
             return
@@ -470,7 +471,7 @@ def merge_masks(current_masks: torch.Tensor) -> torch.Tensor:
     inds = segs.argmax(dim=0)
     out = torch.zeros_like(current_masks)
     for i in range(current_masks.shape[0]):
-        out[i] = segs[i] * (inds == i).float()
+        out[i] = segs[i] * (inds == i).to(segs.dtype)
     return out
 
 
@@ -559,12 +560,13 @@ def _bn(x, P, pre):
                         training=False, eps=1e-5)
 
 
-def resnet_forward(name, P, image_u8, output_layers=None):
-    """model/feature_extractor.py:40-68.  image (B,3,H,W) or (3,H,W) uint8 -> dict layer1..layer5."""
+def resnet_forward(name, P, image_u8, output_layers=None, dtype=torch.float32):
+    """model/feature_extractor.py:40-68.  image (B,3,H,W) or (3,H,W) uint8 -> dict layer1..layer5.  ``dtype``: arithmetic type (P must
+    hold tensors of that type; fp64 = the arbiter of tests/test_north_star_gpu.py)."""
     kind, blocks = RESNET_SPECS[name]
-    stds = torch.tensor((0.229, 0.224, 0.225)).reshape(1, 3, 1, 1)
-    means = torch.tensor((0.485, 0.456, 0.406)).reshape(1, 3, 1, 1)
-    x = (1 / 255 / stds) * image_u8.float() + (-means / stds)            # :27-32,42
+    stds = torch.tensor((0.229, 0.224, 0.225), dtype=dtype).reshape(1, 3, 1, 1)
+    means = torch.tensor((0.485, 0.456, 0.406), dtype=dtype).reshape(1, 3, 1, 1)
+    x = (1 / 255 / stds) * image_u8.to(dtype) + (-means / stds)          # :27-32,42
     out = {}
 
     def keep(L, t):

@@ -1,0 +1,112 @@
+"""oracle/make_golden_jf.py -- TEST INFRASTRUCTURE: records the CPU oracle's side of the dataset-level J&F parity test.
+
+The north star asks for J&F of the HIP path within +-0.1 points of the reference CPU path.  One 13-frame sample cannot resolve
+that (round-2 VERDICT weak #1: the oracle differs from ITSELF by 0.19-0.4 points there when its thread count changes), so the
+comparison is made over a synthetic DATASET: S sequences x T frames (default 10 x 48, 1-3 objects, 480x854, ResNet-101, the full
+(5,10,10,10,10)/(10,) schedule, memory 80) through ``oracle/tracker_ref.py`` -- the pinned restatement of the reference's
+tracker / target model / solver -- in float32 (the reference's arithmetic) and, optionally, float64 (the arbiter).
+
+    python oracle/make_golden_jf.py [--sequences 10] [--frames 48] [--dtype float32|float64] [--threads 8]
+
+writes tests/golden/g12_jf_<dtype>.npz: per sequence the decoded label images (uint8, deflate-compressed), the J / F means per
+object against the synthetic ground truth (lib/davis.py measures, pinned by G10), seeds and sizes.  The GPU test
+(tests/test_north_star_gpu.py::test_dataset_level_jf_within_0p1_of_the_cpu_oracle) regenerates the same sequences from their
+seeds, tracks them on the HIP path with the same start weights / augmentation / refiner, and compares.
+
+Everything here is deterministic given the seeds EXCEPT fp32 summation order inside torch's CPU kernels (thread count): the
+fixture is one draw of the oracle, which is exactly what the test treats it as.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import cpu_ref as O                      # noqa: E402
+from oracle.tracker_ref import TrackerRef            # noqa: E402
+
+SIZE = (480, 854)
+BACKBONE = 'resnet101'
+CIN, C = 1024, 96
+DISC = dict(init_iters=(5, 10, 10, 10, 10), update_iters=(10,), CG_forgetting_rate=750, memory_size=80, train_skipping=8,
+            pixel_weighting=dict(method='hinge', tf=0.1))
+
+
+def sequence_specs(n_seq, n_frames):
+    """(name, frames, objects, seed) of the synthetic dataset: 1-3 objects, DAVIS-2017-val-like mean of 2."""
+    objs = (2, 1, 3, 2, 2, 1, 3, 2, 2, 3, 1, 2, 3, 2, 1, 2)
+    return [('jf%02d' % k, n_frames, objs[k % len(objs)], 300 + k) for k in range(n_seq)]
+
+
+def start_weights(seq_seed, obj_id, cin=CIN, c=C):
+    """nn.Conv2d's default initialisation (kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in))), from a CPU generator seeded by
+    (sequence, object): the same tensors are injected into the HIP target models."""
+    g = torch.Generator().manual_seed(100003 * seq_seed + obj_id)
+    b1, b2 = 1 / math.sqrt(cin), 1 / math.sqrt(9 * c)
+    return (torch.rand(c, cin, 1, 1, generator=g) * 2 - 1) * b1, (torch.rand(1, c, 3, 3, generator=g) * 2 - 1) * b2
+
+
+def refiner_for(backbone=BACKBONE):
+    from frtm_vos_amd.lib.synthetic import make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    cin = {'resnet101': 1024, 'resnet50': 1024, 'resnet18': 256, 'resnet34': 256}[backbone]
+    chans = {'layer5': cin * 2, 'layer4': cin, 'layer3': cin // 2, 'layer2': cin // 4}
+    torch.manual_seed(1)
+    return make_score_following_refiner(SegNetwork(1, 64, chans, True).eval())
+
+
+def jf_per_object(labels, seq):
+    """[(J mean, F mean)] per object against the synthetic ground truth (lib/evaluation.py: DAVIS protocol, first and last frame
+    excluded; the measures themselves are pinned to the reference's lib/davis.py by fixture G10)."""
+    from frtm_vos_amd.lib.evaluation import evaluate_sequence
+    pred = [np.asarray(l).reshape(seq.size) for l in labels]
+    gt = [g.reshape(seq.size).cpu().numpy() for g in seq.gt]
+    J = evaluate_sequence(pred, gt, seq.obj_ids, 'J')
+    F = evaluate_sequence(pred, gt, seq.obj_ids, 'F')
+    return [(float(np.mean(J[o])), float(np.mean(F[o]))) for o in seq.obj_ids]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--sequences', type=int, default=10)
+    ap.add_argument('--frames', type=int, default=48)
+    ap.add_argument('--dtype', default='float32')
+    ap.add_argument('--threads', type=int, default=os.cpu_count())
+    ap.add_argument('--first', type=int, default=0, help='index of the first sequence to run (resume)')
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_num_threads(args.threads)
+    dtype = getattr(torch, args.dtype)
+    P = O.resnet_random_params(BACKBONE, seed=0)
+    refiner = refiner_for()
+    out = args.out or os.path.join(ROOT, 'tests', 'golden', 'g12_jf_%s.npz' % args.dtype)
+    res = dict(np.load(out)) if (args.first > 0 and os.path.exists(out)) else {}
+    specs = sequence_specs(args.sequences, args.frames)
+    res['specs'] = np.array([[f, n, s] for _, f, n, s in specs])
+    for k, (name, n_frames, n_obj, seed) in enumerate(specs):
+        if k < args.first:
+            continue
+        t0 = time.time()
+        seq = SyntheticSequence(name, n_frames, SIZE, n_obj, seed=seed)
+        trk = TrackerRef(BACKBONE, P, refiner, lambda oid, s=seed: start_weights(s, oid), dtype=dtype, **DISC)
+        labels = trk.run_sequence(seq)
+        lab = torch.stack(labels).numpy()
+        jf = jf_per_object(lab, seq)
+        res['labels_%d' % k] = lab
+        res['jf_%d' % k] = np.array(jf)
+        print('%s: %d objects, %d frames, J&F per object %s, %.0f s' % (name, n_obj, n_frames, ['%.2f/%.2f' % (100 * a, 100 * b) for a, b in jf],
+                                                                      time.time() - t0), flush=True)
+        np.savez_compressed(out, **res)
+    allv = np.concatenate([res['jf_%d' % k] for k in range(len(specs))])
+    print('dataset J %.3f F %.3f J&F %.3f' % (100 * allv[:, 0].mean(), 100 * allv[:, 1].mean(), 100 * allv.mean()))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,340 @@
+"""The north-star numerical bar, demonstrated (round-2 VERDICT, "Next round" #1):
+
+  (a) TEACHER-FORCED parity at the headline config (ResNet-101, 480x854, 2 objects, full (5,10,10,10,10)/(10,) schedule): before
+      every frame the CPU oracle's state (project, filter, memory, CG carry) is copied into the HIP target models, both sides
+      track that ONE frame (reference model/tracker.py:193-227, model/discriminator.py:201-227), and the masks must agree to
+      1e-3 max-abs -- the chaos of the truncated GN/CG trajectories is removed, what remains is exactly what the north star states.
+  (b) an fp64 ARBITER for the chaotic quantities: the oracle in float64 decides on which side of the fp32 rounding noise the HIP path
+      sits -- |HIP - fp64| <= 1.5 x |fp32 oracle - fp64| for the update-problem filter (N = 80, full size), the joint first-frame fit
+      (Cin = 1024, full schedule) and free-running masks.
+  (c) J&F at DATASET level: 12 synthetic sequences x 48 frames (24 objects) against the pre-recorded run of the CPU oracle
+      (oracle/make_golden_jf.py -> tests/golden/g12_jf_float32.npz): |dJ&F| <= 0.1 points.
+"""
+import copy
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from oracle import make_golden_jf as JF
+from oracle.tracker_ref import TrackerRef, shift_flip_augment
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+PW = dict(method='hinge', tf=0.1)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def rms(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float(((a - b) ** 2).mean().sqrt())
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def _hip_tracker(backbone, refiner, fast=False, **disc):
+    from frtm_vos_amd.evaluate import Parameters
+    params = Parameters(None, fast=fast, device=DEV, feature_extractor=backbone)
+    params.refiner_factory = lambda chans: copy.deepcopy(refiner)
+    params.disc_params.update(**disc)
+    trk = params.get_model().eval()
+    trk.augment = shift_flip_augment
+    return trk
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (a) teacher-forced, headline config
+# ------------------------------------------------------------------------------------------------------------------
+
+def _force_state(hd, od):
+    """Copies the oracle's target-model state (DiscriminatorRef) into the HIP Discriminator: weights, memory (features, sample
+    weights, the low-resolution normal equations rebuilt from the oracle's label / pixel-weight maps, replace index), CG carry."""
+    hd.project.weight.data.copy_(od.w1.float())
+    hd.filter.weight.data.copy_(od.w2.float())
+    hd._invalidate()
+    m, om = hd.memory, od.memory
+    n = om.current_size
+    assert m.capacity == om.capacity
+    m.samples[:n].copy_(om.samples[:n].float())
+    m.weights.copy_(om.weights.float())
+    m._build_normals(om.labels[:n].float().to(DEV), om.pixel_weights[:n].float().to(DEV), n, None, 0)
+    m.current_size = n
+    m._slot[:1].fill_(-1 if om.prev_ind is None else int(om.prev_ind))
+    m._have_prev = om.prev_ind is not None
+    hd.frame_num = od.frame_num
+    ho, oo = hd.update_optimizer, od.update_optimizer
+    ho._alloc()
+    if oo.p is not None:
+        ho._buf[3].copy_(oo.p[0].reshape(-1).float())
+        ho._buf[2].copy_(oo.r_prev[0].reshape(-1).float())
+        ho._state[:1].copy_(oo.rho.reshape(1).float())
+        ho._has_p = True
+
+
+def _clone_disc(od, dtype):
+    """A copy of a DiscriminatorRef in another arithmetic (the solver's variable list must keep aliasing the filter)."""
+    d = copy.deepcopy(od)
+    d.w1, d.w2 = d.w1.to(dtype), d.w2.to(dtype)
+    m = d.memory
+    for k in ('samples', 'weights', 'labels', 'pixel_weights'):
+        setattr(m, k, getattr(m, k).to(dtype))
+    o = d.update_optimizer
+    o.x = [d.w2]
+    o.rho = o.rho.to(dtype)
+    for k in ('p', 'r_prev', 'b'):
+        if getattr(o, k) is not None:
+            setattr(o, k, [t.to(dtype) for t in getattr(o, k)])
+    return d
+
+
+def test_teacher_forced_masks_within_1e3_at_the_headline_config():
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(min(32, os.cpu_count()))
+    n_frames = 18                                   # frame 0 initialises, 17 tracked frames: filter re-solves on tracked frames 8 and 16
+    seed = 300
+    seq = SyntheticSequence('tf', n_frames, JF.SIZE, 2, seed=seed)
+    refiner = JF.refiner_for('resnet101')
+    trk = _hip_tracker('resnet101', refiner)
+    trk.start_weights = lambda oid: JF.start_weights(seed, oid)
+    P = O.resnet_random_params('resnet101', seed=0)
+    cpu = TrackerRef('resnet101', P, refiner, lambda oid: JF.start_weights(seed, oid), **JF.DISC)
+    t0 = time.time()
+    image, labels, new = seq[0]
+    trk.current_frame, trk.targets = 0, dict()
+    trk.initialize(image.to(DEV), labels.to(DEV), new)
+    cpu.initialize(image, labels, new)
+    # the first-frame fits themselves are 45 CG iterations each: they amplify the 2e-4 difference between the two trunks (the fp64
+    # arbiter below measures 10 % rms between the float32 and float64 runs of the SAME fit); here only that they land in the same place
+    for oid in new:
+        hd, od = trk.targets[oid].discriminator, cpu.targets[oid]['d']
+        e2, e1 = rms(hd.filter.weight, od.w2) / rms(od.w2, 0 * od.w2), rms(hd.project.weight, od.w1) / rms(od.w1, 0 * od.w1)
+        print('first-frame fit, object %d: HIP vs fp32 oracle rms relative filter %.3f, projection %.3f' % (oid, e2, e1))
+        assert e2 < 0.3 and e1 < 0.3
+    trk.current_frame, cpu.current_frame = 1, 1
+    trk._raw_log = []
+    worst = dict(raw=0.0, merged=0.0, filt=0.0, filt_solve=0.0, sw=0.0, flips=0, arb=0.0)
+    for t in range(1, n_frames):
+        for oid in new:
+            _force_state(trk.targets[oid].discriminator, cpu.targets[oid]['d'])
+        trk.current_masks.copy_(cpu.current_masks.float())
+        image = seq[t][0]
+        will_solve = (cpu.targets[new[0]]['d'].frame_num + 1) % 8 == 0
+        d64 = {oid: _clone_disc(cpu.targets[oid]['d'], torch.float64) for oid in new} if will_solve else {}
+        trk.track(image.to(DEV))
+        cpu.track(image)
+        raw_h, raw_c = trk._raw_log[-1][1].cpu(), cpu.raw_masks
+        e_raw = float((raw_h[1:] - raw_c[1:]).abs().max())
+        # merged masks: the merge contains an arg-max (tracker.py:217-221); a pixel whose two best classes are closer than the tolerance
+        # may flip, and the mask value jumps with it.  Those pixels are counted, not compared.
+        p = torch.clamp(raw_c, 1e-7, 1 - 1e-7)
+        p[0:1] = torch.min(1 - p[1:], dim=0, keepdim=True)[0]
+        top2 = torch.softmax(p / (1 - p), dim=0).topk(2, dim=0)[0]
+        stable = (top2[0] - top2[1]) > 4e-3
+        mh, mc = trk.current_masks.cpu(), cpu.current_masks
+        e_mrg = float(((mh - mc).abs() * stable).max())
+        flips = int((~stable).sum())
+        worst['flips'] = max(worst['flips'], flips)
+        assert flips < 2e-3 * stable.numel(), (t, flips)
+        solve = cpu.targets[new[0]]['d'].frame_num % 8 == 0
+        for oid in new:
+            hd, od = trk.targets[oid].discriminator, cpu.targets[oid]['d']
+            e_f = relmax(hd.filter.weight, od.w2)
+            worst['filt_solve' if solve else 'filt'] = max(worst['filt_solve' if solve else 'filt'], e_f)
+            if solve:
+                # The re-solve is ten truncated CG iterations: not a 1e-4 quantity in float32 at all (the float32 oracle itself is
+                # percent-level away from exact arithmetic after one run, see the arbiter tests).  So the SAME step is taken a third
+                # time in float64 from the same state, on the float32 oracle's own sample and mask: the HIP filter must be as close to
+                # that as the float32 oracle's is.
+                a = d64[oid]
+                a.frame_num, a.current_sample = od.frame_num, od.current_sample.double()
+                a.update(cpu.current_masks[cpu.targets[oid]['index']][None, None].double())
+                e_h, e_o = rms(hd.filter.weight, a.w2), rms(od.w2, a.w2)
+                print('   re-solve, object %d: rms |HIP - fp64| %.2e, |fp32 oracle - fp64| %.2e, |HIP - fp32 oracle| %.2e (rms of the filter %.2e)'
+                      % (oid, e_h, e_o, rms(hd.filter.weight, od.w2), rms(a.w2, 0 * a.w2)))
+                worst['arb'] = max(worst['arb'], e_h / max(e_o, 1e-12))
+            assert hd.memory.previous_replace_ind == od.memory.prev_ind, (t, oid)
+            worst['sw'] = max(worst['sw'], float((hd.memory.weights.cpu() - od.memory.weights).abs().max()))
+        worst['raw'], worst['merged'] = max(worst['raw'], e_raw), max(worst['merged'], e_mrg)
+        print('frame %2d%s: max |mask diff| before merge %.2e, merged (stable pixels) %.2e, %d unstable pixels' %
+              (t, ' (re-solve)' if solve else '', e_raw, e_mrg, flips), flush=True)
+        trk.current_frame += 1
+        cpu.current_frame += 1
+    trk._raw_log = None
+    print('teacher-forced, RN101 480x854, 2 objects, %d tracked frames: %s  (%.0f s)' % (n_frames - 1, worst, time.time() - t0))
+    assert worst['raw'] <= 1e-3, worst            # the north star's bar: masks within 1e-3 max-abs (fp32)
+    assert worst['merged'] <= 1e-3, worst
+    assert worst['filt'] == 0.0                   # frames without a re-solve leave the (forced) filter alone
+    assert worst['arb'] <= 1.5, worst             # re-solves: as close to exact arithmetic as the float32 oracle is
+    assert worst['sw'] <= 1e-6, worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (b) fp64 arbiter
+# ------------------------------------------------------------------------------------------------------------------
+
+def _oracle_update_run(dtype, X, Y, sw, w2, runs):
+    N = X.shape[0]
+    mem = O.MemoryRef(N, X.shape[1:], Y.shape[1:], 0.1, dtype)
+    mem.samples[:] = X.to(dtype)
+    mem.labels[:] = Y.to(dtype)
+    mem.pixel_weights[:] = O.pixel_weights((Y > 0.5).to(dtype), PW, dtype)
+    mem.weights[:] = sw.to(dtype)
+    mem.current_size = N
+    w = w2.clone().to(dtype)
+    opt = O.GaussNewtonCGRef(O.UpdateProblemRef(mem, 1e-2, 1e-2), [w], fletcher_reeves=False, direction_forget_factor=0.9 ** 750)
+    out = []
+    for _ in range(runs):
+        opt.run((10,))
+        out.append(w.clone())
+    return out
+
+
+def test_fp64_arbiter_update_problem_full_memory():
+    """GaussNewtonCG.run((10,)) of the filter problem on a FULL memory (N = 80, c = 96, 30x54 / 480x854), twice in a row (the second
+    run carries the CG state, optimizer.py:98-110): float64 oracle = truth, float32 oracle = the reference's arithmetic, HIP path."""
+    from test_fullsize_gpu import _fullsize_inputs, _problem
+    torch.set_num_threads(min(32, os.cpu_count()))
+    N, c, h, w, H, W = 80, 96, 30, 54, 480, 854
+    X, Y, sw, w2, _ = _fullsize_inputs(21, N, c, h, w, H, W)
+    f64 = _oracle_update_run(torch.float64, X, Y, sw, w2, 2)
+    f32 = _oracle_update_run(torch.float32, X, Y, sw, w2, 2)
+    for persistent in (True, False):
+        mem, prob, opt, wv = _problem(N, c, h, w, H, W, X, Y, sw, w2)
+        opt.persistent = persistent
+        for k in range(2):
+            opt.run((10,))
+            e_h, e_o = rms(wv, f64[k]), rms(f32[k], f64[k])
+            scale = float(f64[k].double().pow(2).mean().sqrt())
+            print('update problem N=80, run %d (%s): rms |HIP - fp64| %.2e, |fp32 oracle - fp64| %.2e (rms of the filter %.2e), max-abs %.2e / %.2e'
+                  % (k + 1, 'persistent' if persistent else 'multi-kernel', e_h, e_o, scale, relmax(wv, f64[k]), relmax(f32[k], f64[k])))
+            assert e_h <= 1.5 * e_o + 1e-6 * scale, (persistent, k, e_h, e_o)
+
+
+def test_fp64_arbiter_joint_first_frame_fit():
+    """The joint (project, filter) fit of Discriminator.init (discriminator.py:165-176) at Cin = 1024, K = 5, 30x54 / 480x854 through the
+    full (5,10,10,10,10) schedule = 45 CG iterations."""
+    from test_oracle_golden import _joint_inputs
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    torch.set_num_threads(min(32, os.cpu_count()))
+    K, cin, c, h, w, H, W = 5, 1024, 96, 30, 54, 480, 854
+    X, Y, w1, w2, _, _, _ = _joint_inputs(77, K, cin, c, h, w, H, W)
+    iters = (5, 10, 10, 10, 10)
+
+    def oracle(dtype):
+        mem = O.MemoryRef(K, X.shape[1:], Y.shape[1:], 0.1, dtype)
+        mem.initialize(X.to(dtype), Y.to(dtype), O.pixel_weights(Y.to(dtype), PW, dtype))
+        a, b = w1.clone().to(dtype), w2.clone().to(dtype)
+        O.GaussNewtonCGRef(O.InitProblemRef(mem, (1e-4, 1e-2), (1e-4, 1e-2)), [a, b], fletcher_reeves=False,
+                           direction_forget_factor=0.9 ** 750).run(iters)
+        return a, b
+    a64, b64 = oracle(torch.float64)
+    a32, b32 = oracle(torch.float32)
+    for composed in (True, False):
+        mem = Memory(K, (cin, h, w), (1, H, W), DEV, 0.1, pixel_weighting=PW)
+        mem.initialize(X.to(DEV), Y.to(torch.uint8).to(DEV))
+        w1d = torch.nn.Parameter(w1.clone().to(DEV), requires_grad=False)
+        w2d = torch.nn.Parameter(w2.clone().to(DEV), requires_grad=False)
+        prob = DiscriminatorLoss(mem, (1e-4, 1e-2), (1e-4, 1e-2), w2d, w1d)
+        prob.composed = composed
+        GaussNewtonCG(prob, TensorList([w1d, w2d]), fletcher_reeves=False, standard_alpha=True, direction_forget_factor=0.9 ** 750).run(iters)
+        for name, hv, v32, v64 in (('project', w1d, a32, a64), ('filter', w2d, b32, b64)):
+            e_h, e_o = rms(hv, v64), rms(v32, v64)
+            scale = float(v64.pow(2).mean().sqrt())
+            print('joint fit Cin=1024 (%s form), %s: rms |HIP - fp64| %.2e, |fp32 oracle - fp64| %.2e (rms of the weights %.2e)'
+                  % ('composed' if composed else 'GEMM', name, e_h, e_o, scale))
+            assert e_h <= 1.5 * e_o + 1e-6 * scale, (composed, name, e_h, e_o)
+
+
+def test_fp64_arbiter_free_running_masks():
+    """A free-running sequence (ResNet-18, 192x256, 2 objects, 18 frames, fast schedule, re-solves on tracked frames 8 and 16) in three
+    arithmetics.  Per frame: distance of the pre-merge masks to the float64 run."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(min(16, os.cpu_count()))
+    seed, n_frames = 404, 18
+    seq = SyntheticSequence('arb', n_frames, (192, 256), 2, seed=seed)
+    refiner = JF.refiner_for('resnet18')
+    sw = lambda oid: JF.start_weights(seed, oid, cin=256)
+    disc = dict(JF.DISC, init_iters=(5, 10, 10, 10), update_iters=(5,))
+    P = O.resnet_random_params('resnet18', seed=0)
+    runs = {}
+    for name, dtype in (('f64', torch.float64), ('f32', torch.float32)):
+        cpu = TrackerRef('resnet18', P, refiner, sw, dtype=dtype, **disc)
+        raws = []
+        for t, (image, labels, new) in enumerate(seq):
+            if new:
+                cpu.initialize(image, labels, new)
+            else:
+                cpu.track(image)
+                raws.append(cpu.raw_masks[1:].double().clone())
+            cpu.current_frame += 1
+        runs[name] = raws
+    trk = _hip_tracker('resnet18', refiner, fast=True)
+    trk.start_weights = sw
+    trk.current_frame, trk.targets, trk._raw_log = 0, dict(), []
+    for t, (image, labels, new) in enumerate(seq):
+        if new:
+            trk.initialize(image.to(DEV), labels.to(DEV), new)
+        else:
+            trk.track(image.to(DEV))
+        trk.current_frame += 1
+    hip = [m[1:].double().cpu() for _, m in trk._raw_log]
+    trk._raw_log = None
+    e_h = [float((a - b).abs().mean()) for a, b in zip(hip, runs['f64'])]
+    e_o = [float((a - b).abs().mean()) for a, b in zip(runs['f32'], runs['f64'])]
+    print('free-running masks, mean |x - fp64| per frame:  HIP ' + ' '.join('%.1e' % v for v in e_h))
+    print('                                        fp32 oracle ' + ' '.join('%.1e' % v for v in e_o))
+    assert np.mean(e_h) <= 1.5 * np.mean(e_o) + 1e-5, (np.mean(e_h), np.mean(e_o))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (c) dataset-level J&F
+# ------------------------------------------------------------------------------------------------------------------
+
+def test_dataset_level_jf_within_0p1_of_the_cpu_oracle():
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    fx = np.load(os.path.join(GOLDEN, 'g12_jf_float32.npz'))
+    f64 = os.path.join(GOLDEN, 'g12_jf_float64.npz')
+    fx64 = np.load(f64) if os.path.exists(f64) else None
+    specs = [tuple(int(v) for v in row) for row in fx['specs']]
+    assert len(specs) >= 8 and all(f >= 40 for f, _, _ in specs)
+    trk = _hip_tracker('resnet101', JF.refiner_for('resnet101'))
+    hip, ora, ora64, agree = [], [], [], []
+    for k, (n_frames, n_obj, seed) in enumerate(specs):
+        seq = SyntheticSequence('jf%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed)
+        trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
+        seq.preload(DEV)
+        labels, _ = trk.run_sequence(seq)
+        seq.release()
+        lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
+        jf = np.array(JF.jf_per_object(lab, seq))
+        hip.append(jf)
+        ora.append(fx['jf_%d' % k])
+        if fx64 is not None and ('jf_%d' % k) in fx64:
+            ora64.append(fx64['jf_%d' % k])
+        agree.append(float((lab[1:] == fx['labels_%d' % k][1:]).mean()))
+        print('seq %2d (%d objects): J&F HIP %.2f  oracle %.2f  label agreement %.5f' %
+              (k, n_obj, 100 * jf.mean(), 100 * fx['jf_%d' % k].mean(), agree[-1]), flush=True)
+    hip, ora = np.concatenate(hip), np.concatenate(ora)
+    jf_h, jf_o = 100 * hip.mean(), 100 * ora.mean()
+    print('dataset (%d sequences, %d objects): J&F HIP %.3f (J %.3f F %.3f)  CPU oracle %.3f (J %.3f F %.3f)  diff %.3f  mean label agreement %.5f'
+          % (len(specs), len(hip), jf_h, 100 * hip[:, 0].mean(), 100 * hip[:, 1].mean(), jf_o, 100 * ora[:, 0].mean(), 100 * ora[:, 1].mean(),
+             abs(jf_h - jf_o), np.mean(agree)))
+    if ora64:
+        o64 = np.concatenate(ora64)
+        n = len(o64)
+        print('fp64 arbiter on the first %d objects: |HIP - fp64| %.3f, |fp32 oracle - fp64| %.3f points'
+              % (n, abs(100 * hip[:n].mean() - 100 * o64.mean()), abs(100 * ora[:n].mean() - 100 * o64.mean())))
+    assert abs(jf_h - jf_o) <= 0.1, (jf_h, jf_o)
+    assert np.mean(agree) > 0.995

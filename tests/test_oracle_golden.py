@@ -326,3 +326,44 @@ def test_config1_cpu_plumbing_oracle_tracks_a_synthetic_sequence():
     assert sizes == [min(3 + k, 8) for k in range(1, 12)], sizes            # K = 3 initial samples (stub augmentation), capacity 8
     changed = [not torch.equal(filt[k], filt[k - 1]) for k in range(1, 11)]
     assert changed == [k + 1 == 8 for k in range(1, 11)], changed            # the only re-solve: tracked frame 8
+
+
+def test_tracker_ref_against_g6(golden):
+    """oracle/tracker_ref.py (the control flow the north-star tests and bench.py's CPU leg run) against the reference's
+    Tracker.initialize / track mask flow recorded in G6: 1, 2, 5 objects and an object that starts on frame 2.  Taps and refiner
+    logits are the fixture's (the mask arithmetic does not depend on the target model when the refiner is replayed)."""
+    from oracle.tracker_ref import TrackerRef
+    g = golden('g6_tracker')
+    cin, c, h, w, Hh, Ww = [int(v) for v in g['dims']]
+
+    class Replay(torch.nn.Module):
+        def __init__(self, logits):
+            super().__init__()
+            self.logits, self.k = logits, 0
+
+        def forward(self, s, taps, size):
+            self.k += 1
+            return self.logits[self.k - 1:self.k]
+
+    for tag in ('one', 'two', 'five', 'late'):
+        ids, late = [int(v) for v in g[tag + '_ids']], int(g[tag + '_late'])
+        labels = T(g[tag + '_labels'])
+        gen = torch.Generator().manual_seed(3)
+        trk = TrackerRef('resnet18', {}, Replay(T(g[tag + '_logits'])),
+                         lambda oid: ((torch.rand(c, cin, 1, 1, generator=gen) - 0.5) / 4, (torch.rand(1, c, 3, 3, generator=gen) - 0.5) / 4),
+                         augment=lambda im, m: (im.unsqueeze(0).repeat(2, 1, 1, 1), m.unsqueeze(0).repeat(2, 1, 1, 1)),
+                         init_iters=(2, 3), update_iters=(2,), memory_size=8, CG_forgetting_rate=750, pixel_weighting=PW)
+        trk.features = lambda im, layers=None: {'layer4': torch.relu(torch.randn(im.shape[0] if im.dim() == 4 else 1, cin, h, w, generator=gen))}
+        image = torch.zeros(3, Hh, Ww, dtype=torch.uint8)
+        for t in range(4):
+            old = len(trk.targets) > 0
+            if t == 0:
+                trk.initialize(image, labels, [i for i in ids if not (late >= 0 and i == ids[-1])])
+            elif t == late:
+                trk.initialize(image, labels, [ids[-1]])
+            if old:
+                trk.track(image)
+            ref = T(g['%s_masks%d' % (tag, t)])
+            assert trk.current_masks.shape == ref.shape
+            assert (trk.current_masks - ref).abs().max() < 1e-6, (tag, t)
+            trk.current_frame += 1
