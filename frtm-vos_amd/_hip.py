@@ -71,6 +71,8 @@ SIGNATURES = {
     'frtm_merge_masks': (I, [P, I, I, P]),
     'frtm_merge_masks_frames': (I, [P, I, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),
+    'frtm_track_merge': (I, [P, I, I, I, P, P, P, I, P, F, P]),
+    'frtm_filter_scores_pitched': (I, [P, P, I, I, I, I, P, I, I, P]),
     'frtm_bilinear_resize': (I, [P, I, I, I, P, I, I, P]),
     'frtm_tse_inject': (I, [P, P, P, P, I, I, I, I, I, I, I, P, P]),
     'frtm_cab_combine': (I, [P, P, P, I, I, I, I, I, I, I, P, P]),

@@ -15,6 +15,7 @@
 //  * the trunk runs at batch 1 on 30x54 .. 120x214 maps, i.e. 400..25k pixels per conv: small
 //    tiles (32x64 / 64x64 / 128x64) plus split-K keep >= 256 workgroups in flight.
 #include <algorithm>
+#include <cstdlib>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
@@ -23,6 +24,12 @@
 // conv_wino.hip
 int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_t st);
 int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st);
+// conv_gemm32.hip
+int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
+// FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
+// measured equal inside the trunk (round 3, rocprofv3 kernel trace of tools/trunk_bench.py 8 1: 78.4 vs 76.9 us per 1x1 launch,
+// pass 9.59 vs 9.56 ms) -- at these sizes neither the MFMA form nor the staging path bounds the kernel.
+static const bool g_use_g32 = getenv("FRTM_USE_G32") && atoi(getenv("FRTM_USE_G32"));
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
@@ -526,6 +533,19 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     halo_tw = halo_tile_width(p.Ho, p.Wo);
   }
   int tile = d->tile, splitk = d->splitk;
+  // (opt-in) launches that fill the chip without split-K on the 32x32x2-MFMA GEMM kernel
+  if (tile == 0 && splitk <= 1 && vec1x1 && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0 && g_use_g32 &&
+      (long)ceil_div(p.M, 64) * ceil_div(p.Ntot, 64) >= 512 && (p.M % 64 == 0 || p.M >= 256))
+    tile = FRTM_TILE_G32_64x64;
+  if (tile >= FRTM_TILE_G32_128x128) {
+    FRTM_CHECK_ARG(vec1x1 && !halo && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0,
+                   "frtm_conv2d: the G32 tiles need a 1x1 stride-1 conv, NCHW output, H*W %% 4 == 0 and 16-byte aligned operands");
+    p.splitk = 1; p.chunks_per_split = p.nchunks;
+    int rc = frtm_g32_launch(p, tile, (hipStream_t)stream);
+    if (rc) return rc;
+    FRTM_LAUNCH_CHECK();
+    return FRTM_OK;
+  }
   if (halo) {
     const int ptiles = d->B * ceil_div(p.Ho, 64 / halo_tw) * ceil_div(p.Wo, halo_tw);
     // 32-row tiles measured best for the stride-1 trunk / refiner shapes; the stride-2 convs (4x the input patch per output

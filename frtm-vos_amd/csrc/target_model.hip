@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_memory_insert_window(const T* __restric
 // ------------------------------------------------------------------------------------------
 template <int PX>
 __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__ X, const float* __restrict__ f, int C, int h, int w,
-                                                        float* __restrict__ out, int accumulate) {
+                                                        float* __restrict__ out, int accumulate, int opitch) {
   // PX pixels per block; the 64 / PX lane groups of each of the 4 waves take disjoint channel ranges (16 channel groups for
   // PX = 16: the 1..5-sample calls of Discriminator.apply and of the init problem are only 26 blocks per sample at PX = 64,
   // each lane walking 24 channels x 9 taps in sequence -- latency bound).  PX = 64 is the plain one-group-per-wave form.
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__
   __syncthreads();
   if (wid == 0 && lane < PX && live) {
     const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    float* o = out + (size_t)n * hw + p;
+    float* o = out + (size_t)n * opitch + p;
     *o = accumulate ? (*o + s) : s;
   }
 }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_filter_scores(const float* __restrict__
 // of the pixel form, which is what bounds that kernel.  NW waves per block = NW channel groups, combined in a fixed order.
 template <int R, int NW>
 __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __restrict__ X, const float* __restrict__ f, int C, int h, int w,
-                                                                 float* __restrict__ out, int accumulate) {
+                                                                 float* __restrict__ out, int accumulate, int opitch) {
   __shared__ float red[NW][R][64];
   // Workgroup b runs on XCD b % 8 (private L2 each).  Give every XCD a contiguous range of (sample, row block) pairs, row
   // blocks fastest, so the two halo rows neighbouring row blocks share are L2 hits instead of a second fetch by another XCD.
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) void k_filter_scores_rows(const float* __r
       float sum = 0.f;
 #pragma unroll
       for (int k = 0; k < NW; k += 4) sum += (red[k][o][x] + red[k + 1][o][x]) + (red[k + 2][o][x] + red[k + 3][o][x]);
-      float* q = out + (size_t)n * h * w + yy * w + x;
+      float* q = out + (size_t)n * opitch + yy * w + x;
       *q = accumulate ? (*q + sum) : sum;
     }
   }
@@ -817,6 +817,78 @@ __global__ __launch_bounds__(256) void k_count_above(const float* __restrict__ m
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The tail of Tracker.track for a whole window of frames in ONE pass (reference model/tracker.py:200-221 + the label decoding of
+// run_sequence, :143-150 + the pixel counts Discriminator.update's early-out needs, discriminator.py:214):
+//   logits (W, n, HW) of the refiner  ->  sigmoid  ->  merge (clamp, background = min(1 - p), soft-max of p / (1 - p), arg-max keeps one
+//   plane)  ->  masks (W, n+1, HW)  +  counts[f][k] = #{masks > thr}  +  labels (W, HW) uint8 = lut[decode(masks)]
+// where decode is the reference's: one object: masks[1] > 0.5; several: the same merge applied to the MERGED masks, arg-max.
+// Replaces sigmoid + repeat + n plane copies + merge + count + clone + merge + argmax + index (ATen launches) of the window.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_track_merge(const float* __restrict__ logits, int n, int HW, float* __restrict__ masks,
+                                                     unsigned char* __restrict__ labels, const unsigned char* __restrict__ lut, int single,
+                                                     int* __restrict__ counts, float thr) {
+  const int K = n + 1, f = blockIdx.y;
+  logits += (size_t)f * n * HW;
+  masks += (size_t)f * K * HW;
+  int cnt[MERGE_MAX];
+#pragma unroll
+  for (int k = 0; k < MERGE_MAX; ++k) cnt[k] = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    float p[MERGE_MAX];
+    float bg = INFINITY;
+    for (int k = 1; k < K; ++k) {
+      const float x = logits[(size_t)(k - 1) * HW + i];
+      float v = 1.f / (1.f + expf(-x));                       // torch.sigmoid
+      v = fminf(fmaxf(v, 1e-7f), 1.f - 1e-7f);
+      p[k] = v;
+      bg = fminf(bg, 1.f - v);
+    }
+    p[0] = bg;
+    float mx = -INFINITY; int arg = 0;
+    for (int k = 0; k < K; ++k) { p[k] = p[k] / (1.f - p[k]); if (p[k] > mx) { mx = p[k]; arg = k; } }
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) { p[k] = expf(p[k] - mx); den += p[k]; }
+    const float win = p[arg] / den;
+    for (int k = 0; k < K; ++k) masks[(size_t)k * HW + i] = (k == arg) ? win : 0.f;
+    if (win > thr) {
+#pragma unroll
+      for (int k = 0; k < MERGE_MAX; ++k) cnt[k] += (k == arg) ? 1 : 0;
+    }
+    if (labels) {
+      int lab;
+      if (single) lab = (arg == 1 && win > 0.5f) ? 1 : 0;     // :145  object_ids[(masks[1:2] > 0.5)]
+      else {
+        // :147-150 on the merged masks: every plane but `arg` is 0 -> 1e-7 after the clamp
+        const float v = fminf(fmaxf(win, 1e-7f), 1.f - 1e-7f), z = 1e-7f;
+        float b2 = INFINITY;
+        for (int k = 1; k < K; ++k) b2 = fminf(b2, 1.f - ((k == arg) ? v : z));
+        float m2 = -INFINITY; lab = 0;
+        for (int k = 0; k < K; ++k) {
+          const float q = (k == 0) ? b2 : ((k == arg) ? v : z);
+          const float o = q / (1.f - q);
+          if (o > m2) { m2 = o; lab = k; }
+        }
+      }
+      labels[(size_t)f * HW + i] = lut[lab];
+    }
+  }
+  if (counts) {
+    __shared__ int wsum[4][MERGE_MAX];
+    for (int k = 0; k < K; ++k) {
+      int c = cnt[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6][k] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+      const int tot = (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+      if (tot) atomicAdd(&counts[(size_t)f * K + threadIdx.x], tot);
+    }
+  }
+}
+
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -928,28 +1000,35 @@ int frtm_memory_insert(const float* src, float* dst_base, int len, const int* sl
   return FRTM_OK;
 }
 
-int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w, float* out, int accumulate, frtm_stream_t stream) {
-  FRTM_CHECK_ARG(X && f && out && N > 0 && C > 0 && h > 0 && w > 0, "frtm_filter_scores: bad argument");
+// out_pitch: floats between the score maps of consecutive samples (h*w = dense).  A tracking window writes the maps of object k
+// straight into the frame-major (frame, object) score batch of the refiner: out = batch + k*h*w, out_pitch = objects*h*w.
+int frtm_filter_scores_pitched(const float* X, const float* f, int N, int C, int h, int w, float* out, int out_pitch, int accumulate,
+                               frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && f && out && N > 0 && C > 0 && h > 0 && w > 0 && out_pitch >= h * w, "frtm_filter_scores: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (w <= 64 && N >= 4) {
     // row form, 16 waves = 16 channel groups per block: 18.9 us at N = 80 (pixel form 41.9), 5.9 us at N = 10 (10.3)
-    k_filter_scores_rows<3, 16><<<ceil_div(h, 3) * N, 1024, 0, st>>>(X, f, C, h, w, out, accumulate);
+    k_filter_scores_rows<3, 16><<<ceil_div(h, 3) * N, 1024, 0, st>>>(X, f, C, h, w, out, accumulate, out_pitch);
   } else if ((long)N * ceil_div(h * w, 64) < 512) {       // few samples (Discriminator.apply: N = 1): 16-pixel blocks
     dim3 g(ceil_div(h * w, 16), N);
-    k_filter_scores<16><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate);
+    k_filter_scores<16><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate, out_pitch);
   } else {
     dim3 g(ceil_div(h * w, 64), N);
-    k_filter_scores<64><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate);
+    k_filter_scores<64><<<g, 256, 0, st>>>(X, f, C, h, w, out, accumulate, out_pitch);
   }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
+}
+
+int frtm_filter_scores(const float* X, const float* f, int N, int C, int h, int w, float* out, int accumulate, frtm_stream_t stream) {
+  return frtm_filter_scores_pitched(X, f, N, C, h, w, out, h * w, accumulate, stream);
 }
 
 int frtm_filter_scores_split(const float* X, const float* f, int N, int C, int h, int w, int splits, float* partial, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && f && partial && N > 0 && C > 0 && h > 0 && w > 0 && w <= 64 && splits >= 1 && splits <= 64,
                  "frtm_filter_scores_split: bad argument (maps at most 64 wide)");
   dim3 g(ceil_div(h, 3) * N, splits);
-  k_filter_scores_rows<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, f, C, h, w, partial, 0);
+  k_filter_scores_rows<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, f, C, h, w, partial, 0, h * w);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
@@ -1095,6 +1174,18 @@ int frtm_merge_masks_frames(float* masks, int frames, int n_plus_1, int HW, frtm
   dim3 g(min(ceil_div(HW, 256), 1024), frames);
   if (n_plus_1 <= MERGE_MAX) k_merge_masks<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);
   else k_merge_masks_any<<<g, 256, 0, (hipStream_t)stream>>>(masks, n_plus_1, HW);      // > 15 objects (the reference has no limit)
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_track_merge(const float* logits, int frames, int n_obj, int HW, float* masks, unsigned char* labels, const unsigned char* lut,
+                     int single_object_decode, int* counts, float thr, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(logits && masks && frames > 0 && n_obj >= 1 && n_obj + 1 <= MERGE_MAX && HW > 0 && (labels == nullptr || lut != nullptr),
+                 "frtm_track_merge: bad argument (at most %d objects)", MERGE_MAX - 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (counts) FRTM_HIP(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)frames * (n_obj + 1), st));
+  dim3 g(min(ceil_div(HW, 256 * 4), 256), frames);
+  k_track_merge<<<g, 256, 0, st>>>(logits, n_obj, HW, masks, labels, lut, single_object_decode, counts, thr);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

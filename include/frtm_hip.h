@@ -262,6 +262,16 @@ typedef struct {
 #define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
 #define FRTM_TILE_128x128_16W 9
 #define FRTM_TILE_80x64 10       /* halo (3x3) kernel only: 65..80 output channels in one M tile */
+/* 1x1 / stride-1 convs on v_mfma_f32_32x32x2_f32 (csrc/conv_gemm32.hip; NCHW output, H*W % 4 == 0, no split-K): Cout x pixel tile */
+#define FRTM_TILE_G32_128x128 20 /* 4 waves of 64x64 */
+#define FRTM_TILE_G32_64x128 21  /* 4 waves of 32x64 */
+#define FRTM_TILE_G32_128x64 22  /* 4 waves of 64x32 */
+#define FRTM_TILE_G32_64x64 23   /* 4 waves of 32x32 */
+#define FRTM_TILE_G32_256x128_8W 24
+#define FRTM_TILE_G32_128x256_8W 25
+#define FRTM_TILE_G32_64x64_S3 26   /* three LDS stages (loads two chunks ahead) */
+#define FRTM_TILE_G32_128x128_S3 27
+#define FRTM_TILE_G32_128x64_S3 28
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,
@@ -309,6 +319,16 @@ int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable);
 int frtm_merge_masks(float* masks, int n_plus_1, int HW, frtm_stream_t stream);
 /* The same for `frames` consecutive (n_obj+1, H*W) stacks (a tracking window), one launch. */
 int frtm_merge_masks_frames(float* masks, int frames, int n_plus_1, int HW, frtm_stream_t stream);
+/* The tail of Tracker.track for a window of `frames` frames in one pass (reference model/tracker.py:200-221, label decoding of
+ * run_sequence :143-150, pixel counts for discriminator.py:214): logits (frames, n_obj, HW) of the refiner -> sigmoid -> merge ->
+ * masks (frames, n_obj + 1, HW); optional labels (frames, HW) uint8 = lut[decoded class] (lut: n_obj + 1 bytes on the device;
+ * single_object_decode != 0: the one-object rule masks[1] > 0.5) and counts (frames, n_obj + 1) int32 = pixels above thr per plane.
+ * At most 15 objects (more: frtm_merge_masks_frames + frtm_count_above). */
+int frtm_track_merge(const float* logits, int frames, int n_obj, int HW, float* masks, unsigned char* labels, const unsigned char* lut,
+                     int single_object_decode, int* counts, float thr, frtm_stream_t stream);
+/* frtm_filter_scores with a pitch (floats) between the output maps of consecutive samples (>= h*w). */
+int frtm_filter_scores_pitched(const float* X, const float* f, int N, int C, int h, int w, float* out, int out_pitch, int accumulate,
+                               frtm_stream_t stream);
 /* count[k] = #pixels with masks[k] > 0.5   (the early-out test of discriminator.py:214), int32[n] */
 int frtm_count_above(const float* masks, int n, int HW, float thr, int* count, frtm_stream_t stream);
 
