@@ -84,6 +84,11 @@ def parse(argv=None):
     ap.add_argument('--launch-check', action='store_true',
                     help='exercise only the multi-process machinery (self-launch, process group, barrier, max-reduce, rank reports) with a '
                          'stub workload; needs no GPU with --dist-backend gloo (CPU test of the N > 1 path)')
+    ap.add_argument('--sequences', type=int, default=0,
+                    help='sharded (strong-scaling) mode, BASELINE config 4 shape: S dv2017-like synthetic sequences (1-5 objects, 34-104 frames) are '
+                         'sharded over the ranks, length-balanced; value = sum of frames / max rank wall time')
+    ap.add_argument('--no-dataset-sim', action='store_true', help='skip the dataset-level leg (30 dv2017-like sequences through the same tracker, N = 1 only)')
+    ap.add_argument('--no-pin', action='store_true', help='do not restrict every rank to its own GPU through HIP_VISIBLE_DEVICES')
     ap.add_argument('--debug-allocs', action='store_true', help='print the Python stacks of device allocations (hipMalloc) made inside the timed region')
     ap.add_argument('--report-dir', default=os.path.join(ROOT, 'gpurun_out', 'bench_ranks'), help='where every rank writes rank_<r>.json')
     return ap.parse_args(argv)
@@ -352,6 +357,36 @@ def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20, persistent=Tru
             'frac_on_reference_bytes': ref_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
 
+def dataset_specs(n_seq, size=(480, 854), seed=2017):
+    """(name, frames, objects, seed) of a DAVIS-2017-val-like synthetic dataset: 1-5 objects (mean ~2.4), 34-104 frames (SURVEY.md 8d config 3;
+    the reference's dv2017val has 30 sequences).  Deterministic: every rank derives the same list."""
+    import random
+    rng = random.Random(seed)
+    base = [1] * 8 + [2] * 9 + [3] * 8 + [4] * 2 + [5] * 3
+    objs = [base[i % len(base)] for i in range(n_seq)]
+    rng.shuffle(objs)
+    return [('d%03d' % i, rng.randint(34, 104), objs[i], 500 + i) for i in range(n_seq)]
+
+
+def run_dataset_shard(tracker, specs, size, dev):
+    """The reference's run_dataset loop (model/tracker.py:82-99) over this rank's sequences: per-sequence frames/s as run_sequence reports it
+    (initialize() included), total frames, total seconds, and the update-work counters summed over the sequences."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    fps, frames, agg = [], 0, {}
+    t0 = time.time()
+    for name, L, n_obj, seed in specs:
+        seq = SyntheticSequence(name, L, size, n_obj, seed=seed)
+        seq.preload(dev)                                # (like the reference's sequence.preload(device), tracker.py:91: inside the dataset loop)
+        out, f = tracker.run_sequence(seq)
+        c = path_counters(tracker, seq, len(out))
+        for k, v in c.items():
+            agg[k] = (agg.get(k, True) and v) if isinstance(v, bool) else agg.get(k, 0) + v
+        fps.append(f)
+        frames += len(out)
+    torch.cuda.synchronize()
+    return fps, frames, time.time() - t0, agg
+
+
 def init_sweep(tracker, size, dev, counts=(1, 2, 5), reps=3):
     """Device time of Tracker.initialize() (augmentation + trunk on the augmented stacks + joint GN/CG fits) for 1 / 2 / 5
     objects starting on frame 0, HIP events, best of `reps` after one untimed call."""
@@ -397,22 +432,34 @@ def launch_check(args, rank, world):
     if world > 1:
         dist.init_process_group(args.dist_backend)
         dist.barrier()
+    my_frames, mine = args.steps, None
+    if args.sequences > 0:                      # sharded mode: this rank's share of the dataset (the same cut main() makes)
+        from frtm_vos_amd.shard import shard_indices
+        specs = dataset_specs(args.sequences, (480, 854))
+        mine = shard_indices(len(specs), rank, world, costs=[L * k for _, L, k, _ in specs])
+        my_frames = sum(specs[i][1] for i in mine)
     t0 = time.time()
     time.sleep(0.01 * (rank + 1))
     if world > 1:
         dist.barrier()
     T_rank = T = time.time() - t0
+    total = world * my_frames
     if world > 1:
         tt = torch.tensor([T], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         T = float(tt.item())
-    write_rank_report(args.report_dir, rank, world, dict(frames=args.steps, seconds=T_rank, fps=args.steps / T_rank, launch_check=True))
+        if mine is not None:
+            ff = torch.tensor([float(my_frames)], dtype=torch.float64)
+            dist.all_reduce(ff, op=dist.ReduceOp.SUM)
+            total = int(ff.item())
+    write_rank_report(args.report_dir, rank, world, dict(frames=my_frames, seconds=T_rank, fps=my_frames / T_rank, launch_check=True,
+                                                         sequence_ids=mine))
     if world > 1:
         dist.barrier()
     if rank == 0:
         fps_files, frames, _ = aggregate_reports(args.report_dir, world)
-        print(json.dumps({'launch_check': True, 'n_gpus': world, 'steps': args.steps, 'value': world * args.steps / T, 'unit': 'frames/s',
-                          'frames_from_rank_reports': frames, 'scaling': 'weak'}))
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'steps': args.steps, 'value': total / T, 'unit': 'frames/s',
+                          'frames_from_rank_reports': frames, 'frames_total': total, 'scaling': 'weak' if mine is None else 'strong'}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -436,6 +483,12 @@ def main():
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus, or let bench.py start the ranks)'
                  % (args.gpus, world))
     if args.share_gpu:
+        local = 0
+    elif world > 1 and not args.no_pin and not args.launch_check:
+        # one process per GPU means ONE GPU per process: the rank sees only its own device, as device 0 -- set before
+        # the HIP runtime initialises (nothing has touched the GPU yet).  An existing HIP_VISIBLE_DEVICES list is indexed, not replaced.
+        vis = [v for v in os.environ.get('HIP_VISIBLE_DEVICES', '').split(',') if v != '']
+        os.environ['HIP_VISIBLE_DEVICES'] = vis[local] if local < len(vis) else str(local)
         local = 0
     if args.launch_check:
         return launch_check(args, rank, world)
@@ -495,6 +548,7 @@ def main():
     ext = tracker.feature_extractor
     ext.pass_frames = []
     ext.pass_events = []                     # HIP events around every trunk pass, recorded on the stream the pass runs on
+    ext.pass_exec_flops = []                 # executed (Winograd-aware) FLOPs of the same passes
     aug_log = []
     raw_augment = tracker.augment
 
@@ -527,6 +581,7 @@ def main():
     del aug_log[:]
     del ext.pass_events[:]
     del ext.pass_frames[:]
+    del ext.pass_exec_flops[:]
 
     if dist is not None:
         dist.barrier()
@@ -538,7 +593,17 @@ def main():
     if args.debug_allocs:
         torch.cuda.memory._record_memory_history(enabled='all', context='alloc', stacks='python')
     t0 = time.time()
-    outputs = run_sequence(tracker, seq)
+    shard = None
+    if args.sequences > 0:
+        # sharded mode (BASELINE config 4's shape): the dataset is cut over the ranks by cost = frames x objects, longest first
+        from frtm_vos_amd.shard import shard_indices
+        specs = dataset_specs(args.sequences, size)
+        mine = shard_indices(len(specs), rank, world, costs=[L * k for _, L, k, _ in specs])
+        seq_fps, n_shard, _, shard_counters = run_dataset_shard(tracker, [specs[i] for i in mine], size, dev)
+        shard = dict(sequences=len(mine), sequence_ids=mine, mean_of_per_sequence_fps=sum(seq_fps) / max(len(seq_fps), 1))
+        outputs = []
+    else:
+        outputs = run_sequence(tracker, seq)
     torch.cuda.synchronize()
     if args.debug_allocs:
         snap = torch.cuda.memory._snapshot()
@@ -553,16 +618,21 @@ def main():
     if dist is not None:
         dist.barrier()
     T_rank = T = time.time() - t0
-    n = len(outputs)
+    n = len(outputs) if shard is None else n_shard
+    n_total = world * n
     mallocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - dev_allocs0
     if dist is not None:
         tt = torch.tensor([T], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         T = float(tt.item())
+        if shard is not None:                       # ranks hold different numbers of frames: sum them
+            nn_ = torch.tensor([float(n)], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(nn_, op=dist.ReduceOp.SUM)
+            n_total = int(nn_.item())
 
     # ---- what the timed region did ---------------------------------------------------------------------------------
-    counters = path_counters(tracker, seq, n)
-    quality = tracking_quality(outputs, seq)
+    counters = path_counters(tracker, seq, n) if shard is None else shard_counters
+    quality = tracking_quality(outputs, seq) if shard is None else float('nan')
     tot = timer.totals()
     # trunk passes of the timed region: the time the stream spent in each pass (events recorded after the pass's wait for the
     # previous pass), its algorithmic FLOPs and conv launches.  The first tracking pass runs on a side stream under the host-bound
@@ -573,7 +643,7 @@ def main():
     n_launch = sum(n for _, _, _, n in ext.pass_events)
     tot['trunk'] = (bb_ms, bb_calls)
     achieved = flops_total / (bb_ms * 1e-3) / 1e12 if bb_ms > 0 else 0.0
-    report = dict(counters, frames=n, seconds=T_rank, fps=n / T_rank, mean_iou_vs_synthetic_gt=quality,
+    report = dict(counters, frames=n, seconds=T_rank, fps=n / T_rank, mean_iou_vs_synthetic_gt=None if quality != quality else quality,
                   device_mallocs_in_timed_region=mallocs, stage_ms_total={k: round(v[0], 2) for k, v in tot.items()},
                   trunk_tflops=achieved, seed=1 + rank)
     write_rank_report(args.report_dir, rank, world, report)
@@ -595,6 +665,18 @@ def main():
     if problems:
         print('bench.py rank %d: INVALID RUN: %s' % (rank, '; '.join(problems)), file=sys.stderr)
 
+    exec_flops = sum(getattr(ext, 'pass_exec_flops', []) or [0.0])
+    exec_ratio = (exec_flops / flops_total) if (flops_total > 0 and exec_flops > 0) else 1.0
+    wino_share = round((1.0 - exec_ratio) / (1.0 - 16.0 / 36.0), 4) if exec_ratio < 1.0 else 0.0
+    sq_busy = None
+    for cand in ('r03_sq_busy.json', 'r02_sq_busy.json'):
+        sf = os.path.join(ROOT, 'profiles', cand)
+        if os.path.exists(sf):
+            try:
+                sq_busy = dict(json.load(open(sf))['conv_family'], source='profiles/' + cand)
+            except Exception:
+                sq_busy = None
+            break
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # written by tools/pmc_summary.py from the rocprofv3 --pmc passes
     if os.path.exists(tf):
@@ -604,10 +686,11 @@ def main():
             traffic = None
     out = {
         'metric': 'segmented frames/sec/GPU (480p, ResNet101, full CG iters)',
-        'value': world * n / T, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * T / n, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': n_total / T, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * T * world / max(n_total, 1), 'higher_is_better': True, 'scaling': 'weak' if shard is None else 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
+        'config': {'workload': ('' if shard is None else '%d dv2017val-like synthetic sequences (1-5 objects, 34-104 frames) SHARDED over the ranks by frames x objects; per sequence as in: ' % args.sequences) +
+                               'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
                                '%s iterations, memory %d, c=96, synthetic weights (trunk: seeded random, residual-branch BN x0.25; refiner: %s), '
                                'trunk fed %d frames per pass in %d concurrent lanes, '
                                'frames between two filter re-solves tracked as one window%s, 3x3 stride-1 convs %s (fp32)' %
@@ -620,6 +703,16 @@ def main():
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
+                     # `frac` counts ALGORITHMIC (direct-form) FLOPs.  The 3x3 stride-1 convs of large launches run as Winograd F(2x2,3x3):
+                     # 16 instead of 36 multiplications per 2x2 outputs, so the MACs the matrix pipes EXECUTE are fewer.  frac_executed
+                     # counts those (frtm_backbone_last_flops_executed); mfma_pipe_busy is the SQ counter ratio of the committed PMC pass
+                     # over the same kernels (profiles/*_sq_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / active cycles, every kernel alone).
+                     'achieved_executed': achieved * exec_ratio, 'frac_executed': achieved * exec_ratio / PEAK_F32_TFLOPS,
+                     'winograd_share_of_algorithmic_flops': wino_share, 'mfma_pipe_busy': sq_busy,
+                     # v_mfma_f32_16x16x4_f32 (the instruction of these kernels) sustains 123-139 TFLOP/s with register operands and nothing
+                     # else in the loop, v_mfma_f32_32x32x2_f32 155 (tools/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt): `peak` stays the
+                     # data-sheet number
+                     'instruction_ceiling_16x16x4': 139.8,
                      'traffic': traffic,
                      # avg_ms = HIP-event time of the trunk passes / conv launches: the EFFECTIVE duration per launch.  With
                      # trunk_lanes concurrent sub-batches the kernel-trace mean duration is ~lanes x this (kernels share the GPU);
@@ -633,18 +726,31 @@ def main():
                                 for (a, b, f, _), nf in zip(ext.pass_events, ext.pass_frames)]},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
         'path_counters': counters,
-        'mean_iou_vs_synthetic_gt': round(quality, 4),
+        'mean_iou_vs_synthetic_gt': None if quality != quality else round(quality, 4),
         'device_mallocs_in_timed_region': mallocs,
         # wall-clock until the host had enqueued the whole sequence (run_sequence, before its final synchronise)
         'host_enqueue_ms_total': round(1e3 * getattr(tracker, 'last_enqueue_seconds', 0.0), 2),
         'valid': bool(ok.item() > 0),
     }
+    if shard is not None:
+        out['shard_rank0'] = shard
+        out['frames_total'] = n_total
     if rank == 0 and world == 1:
         aug_cpu = [(a.cpu(), b.cpu()) for a, b in aug_log]
         _phase('timed sequence and checks done')
         if not args.no_init_sweep:
             out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev)
             _phase('init sweep done')
+        if not args.no_dataset_sim and shard is None:
+            # the headline above is ONE sequence; this is the dataset-level figure the reference's run_dataset prints (mean of the per-
+            # sequence frames/s, model/tracker.py:94,101) over 30 dv2017-like sequences through the same tracker, first-use costs of new
+            # shapes included, with the same counters of the update work
+            fps_l, fr, sec, cnt = run_dataset_shard(tracker, dataset_specs(30, size), size, dev)
+            out['dataset_sim'] = {'sequences': len(fps_l), 'frames': fr, 'mean_of_per_sequence_fps': round(sum(fps_l) / len(fps_l), 1),
+                                  'total_fps': round(fr / sec, 1), 'min_sequence_fps': round(min(fps_l), 1), 'max_sequence_fps': round(max(fps_l), 1),
+                                  'path_counters': cnt,
+                                  'note': '30 synthetic dv2017val-like sequences (1-5 objects, mean 2.4; 34-104 frames; 480x854), frames pre-loaded per sequence inside the loop like the reference'}
+            _phase('dataset leg done')
         if not args.no_cg_roofline:
             out['roofline_cg'] = cg_roofline(dev, size)
             mk = cg_roofline(dev, size, persistent=False)

@@ -64,6 +64,7 @@ SIGNATURES = {
     'frtm_backbone_set_conv': (I, [P, I, P, P, P, P]),
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_last_flops': (D, [P]),
+    'frtm_backbone_last_flops_executed': (D, [P]),
     'frtm_backbone_last_conv_launches': (I, [P]),
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),
@@ -81,6 +82,7 @@ SIGNATURES = {
     'frtm_cab_gate': (I, [P, P, I, P, P, P, P, I, I, P, P]),
     'frtm_project_tail': (I, [P, I, I, I, I, P, P, I, I, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
+    'frtm_warp_affine_u8': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_mask_batch': (I, [P, I, I, P, I, I, P, I, P, P]),
     'frtm_blur2d': (I, [P, I, I, I, P, I, I, P, P]),
     'frtm_blur_gauss2d': (I, [P, I, I, I, I, F, F, F, P, P]),
@@ -106,10 +108,15 @@ def lib():
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on the CURRENT device: the native side
+    launches on the current device's stream and allocates its own arenas / streams there (one process per GPU: always true; a
+    process that drives several GPUs must torch.cuda.set_device() before calling in)."""
     if t is None:
         return None
     assert t.is_contiguous(), 'libfrtm_hip needs dense tensors'
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError('libfrtm_hip: tensor on cuda:%d but the current device is cuda:%d (torch.cuda.set_device first)'
+                           % (t.device.index, torch.cuda.current_device()))
     return t.data_ptr()
 
 

@@ -38,6 +38,7 @@ struct frtm_backbone {
   int nlanes = 1;
   hipEvent_t fork = nullptr;
   double last_flops = 0.0;
+  double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (16 of 36 per 2x2 outputs)
   int last_launches = 0;
   bool use_winograd = true;
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
@@ -116,8 +117,10 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       (long)B * ceil_div(*Ho, 8) * ceil_div(*Wo, 8) * ceil_div(c.Cout, 32) >= FRTM_WINO_MIN_BLOCKS) {
     d.w_layout = FRTM_WLAYOUT_WINO3X3;
     d.splitk = 1;
+    bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks * (16.0 / 36.0);
     return frtm_conv2d(&d, in, c.wW, nullptr, c.scale, c.shift, residual, out, ln.ws, st);
   }
+  bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
 }
 
@@ -302,6 +305,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 }
 
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
+double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb) { return bb ? bb->last_flops_exec : 0.0; }
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
 int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->generation : 0; }
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
@@ -330,6 +334,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   FRTM_CHECK_ARG(stop_after_layer >= 1 && stop_after_layer <= 5, "frtm_backbone_forward: stop_after_layer must be 1..5");
   hipStream_t st = (hipStream_t)stream;
   bb->last_flops = 0.0;
+  bb->last_flops_exec = 0.0;
   bb->last_launches = 0;
   const int L = std::min(bb->nlanes, B);
   // the conv kernels address activations with 32-bit byte offsets: at most this many images per forward_lane call

@@ -20,22 +20,28 @@ __device__ __forceinline__ void cubic_w(float t, float* w) {
 
 struct Affine { float m[6]; };
 
-__global__ __launch_bounds__(256) void k_warp_affine(const float* __restrict__ src, int C, int Hs, int Ws, float* __restrict__ dst,
+// TS / TD: float -> float, or uint8 -> uint8 (the reference's two NPP entry points, nppig.cpp:94-104: nppiWarpAffine_32f_C1R /
+// nppiWarpAffine_8u_C1R); uint8 results are the float interpolant rounded to nearest and saturated.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_warp_affine(const TS* __restrict__ src, int C, int Hs, int Ws, TD* __restrict__ dst,
                                                       int Hd, int Wd, Affine inv, int mode) {
   const size_t total = (size_t)C * Hd * Wd;
+  auto fetch = [&](const TS* s, int y, int x) -> float {
+    return ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) ? (float)s[(size_t)y * Ws + x] : 0.f;
+  };
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int x = (int)(i % Wd), y = (int)((i / Wd) % Hd), c = (int)(i / ((size_t)Wd * Hd));
     const float sx = inv.m[0] * x + inv.m[1] * y + inv.m[2];
     const float sy = inv.m[3] * x + inv.m[4] * y + inv.m[5];
-    const float* s = src + (size_t)c * Hs * Ws;
+    const TS* s = src + (size_t)c * Hs * Ws;
     float v = 0.f;
     if (mode == 0) {
-      v = fetch(s, Hs, Ws, (int)floorf(sy + 0.5f), (int)floorf(sx + 0.5f));
+      v = fetch(s, (int)floorf(sy + 0.5f), (int)floorf(sx + 0.5f));
     } else if (mode == 1) {
       const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
       const float fx = sx - x0, fy = sy - y0;
-      v = (1 - fy) * ((1 - fx) * fetch(s, Hs, Ws, y0, x0) + fx * fetch(s, Hs, Ws, y0, x0 + 1)) +
-          fy * ((1 - fx) * fetch(s, Hs, Ws, y0 + 1, x0) + fx * fetch(s, Hs, Ws, y0 + 1, x0 + 1));
+      v = (1 - fy) * ((1 - fx) * fetch(s, y0, x0) + fx * fetch(s, y0, x0 + 1)) +
+          fy * ((1 - fx) * fetch(s, y0 + 1, x0) + fx * fetch(s, y0 + 1, x0 + 1));
     } else {
       const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
       float wx[4], wy[4];
@@ -45,26 +51,44 @@ __global__ __launch_bounds__(256) void k_warp_affine(const float* __restrict__ s
       for (int j = 0; j < 4; ++j) {
         float r = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r += wx[k] * fetch(s, Hs, Ws, y0 - 1 + j, x0 - 1 + k);
+        for (int k = 0; k < 4; ++k) r += wx[k] * fetch(s, y0 - 1 + j, x0 - 1 + k);
         v += wy[j] * r;
       }
     }
-    dst[i] = v;
+    if (sizeof(TD) == 1) dst[i] = (TD)fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);
+    else dst[i] = (TD)v;
   }
+}
+
+static int invert_affine(const float* f, Affine& inv) {
+  const float a = f[0], b = f[1], tx = f[2], c = f[3], d = f[4], ty = f[5];
+  const float det = a * d - b * c;
+  if (det == 0.f) return 0;
+  inv.m[0] = d / det;  inv.m[1] = -b / det; inv.m[2] = (b * ty - d * tx) / det;
+  inv.m[3] = -c / det; inv.m[4] = a / det;  inv.m[5] = (c * tx - a * ty) / det;
+  return 1;
 }
 
 extern "C" int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd, const float* fwd6_host, int mode,
                                 frtm_stream_t stream) {
   FRTM_CHECK_ARG(src && dst && fwd6_host && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "frtm_warp_affine: bad argument");
   FRTM_CHECK_ARG(mode >= 0 && mode <= 2, "frtm_warp_affine: mode must be 0 (nearest), 1 (bilinear) or 2 (bicubic)");
-  const float a = fwd6_host[0], b = fwd6_host[1], tx = fwd6_host[2], c = fwd6_host[3], d = fwd6_host[4], ty = fwd6_host[5];
-  const float det = a * d - b * c;
-  FRTM_CHECK_ARG(det != 0.f, "frtm_warp_affine: singular transform");
   Affine inv;
-  inv.m[0] = d / det;  inv.m[1] = -b / det; inv.m[2] = (b * ty - d * tx) / det;
-  inv.m[3] = -c / det; inv.m[4] = a / det;  inv.m[5] = (c * tx - a * ty) / det;
+  FRTM_CHECK_ARG(invert_affine(fwd6_host, inv), "frtm_warp_affine: singular transform");
   const size_t total = (size_t)C * Hd * Wd;
-  k_warp_affine<<<(int)min((total + 255) / 256, (size_t)4096), 256, 0, (hipStream_t)stream>>>(src, C, Hs, Ws, dst, Hd, Wd, inv, mode);
+  k_warp_affine<float, float><<<(int)min((total + 255) / 256, (size_t)4096), 256, 0, (hipStream_t)stream>>>(src, C, Hs, Ws, dst, Hd, Wd, inv, mode);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+extern "C" int frtm_warp_affine_u8(const unsigned char* src, int C, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* fwd6_host,
+                                   int mode, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(src && dst && fwd6_host && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "frtm_warp_affine_u8: bad argument");
+  FRTM_CHECK_ARG(mode >= 0 && mode <= 2, "frtm_warp_affine_u8: mode must be 0 (nearest), 1 (bilinear) or 2 (bicubic)");
+  Affine inv;
+  FRTM_CHECK_ARG(invert_affine(fwd6_host, inv), "frtm_warp_affine_u8: singular transform");
+  const size_t total = (size_t)C * Hd * Wd;
+  k_warp_affine<unsigned char, unsigned char><<<(int)min((total + 255) / 256, (size_t)4096), 256, 0, (hipStream_t)stream>>>(src, C, Hs, Ws, dst, Hd, Wd, inv, mode);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

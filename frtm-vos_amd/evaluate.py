@@ -20,7 +20,8 @@ class AttrDict(dict):
 
 class Parameters:
 
-    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2):
+    def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2,
+                 ytvos_fork_solver=False):
         self.device = device
         self.refiner_factory = None       # optional: callable(ft_channels) -> SegNetwork used instead of a default-initialised one
         self.feature_batch = feature_batch
@@ -61,6 +62,9 @@ class Parameters:
             pixel_weighting=dict(method='hinge', tf=0.1),
             filter_reg=(1e-4, 1e-2), precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=750,
             device=self.device, update_filters=True)
+        if ytvos_fork_solver:
+            # what evaluate_ytvos_valid_all_frames.py really runs: Fletcher-Reeves, CG state reset at every run
+            self.disc_params.update(fletcher_reeves=True, CG_forgetting_rate=None)
         self.refnet_params = AttrDict(layers=('layer5', 'layer4', 'layer3', 'layer2'), nchannels=64, use_batch_norm=True)
 
     def get_model(self):
@@ -107,6 +111,7 @@ def main(argv=None):
     ap.add_argument('--output', default='results')
     ap.add_argument('--no-eval', action='store_true', help='skip the J / F evaluation after the run (reference evaluate.py:159-165 always evaluates)')
     ap.add_argument('--ytvos-merge', action='store_true', help="decode like the reference's YouTube-VOS fork (sequence-level merge, ground truth re-inserted)")
+    ap.add_argument('--ytvos-solver', action='store_true', help="the fork's solver configuration: Fletcher-Reeves, CG state reset at every run (ytvos_validation/discriminator.py:256)")
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL); gloo for tests')
     ap.add_argument('--share-gpu', action='store_true', help='tests only: every rank uses cuda:0')
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
@@ -130,7 +135,7 @@ def main(argv=None):
     else:
         dset = YouTubeVOSDataset(args.yt2018, '2018', 'valid_all_frames')
     out_path = Path(args.output).expanduser().resolve() / (dset.name + '-' + Path(args.model).stem + ('_fast' if args.fast else ''))
-    tracker = Parameters(weights, fast=args.fast, device=args.dev).get_model()
+    tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver).get_model()
     if args.prewarm:
         tracker.prewarm(tuple(int(v) for v in args.prewarm.lower().split('x')))
 

@@ -39,12 +39,17 @@ def imwrite_indexed(filename, im, color_palette=None):
 
 
 def warp_affine(src, Hm, size, mode='bicubic'):
-    """src: (C,H,W) or (H,W) float tensor on the GPU; Hm: 3x3 (or 2x3) forward transform; size: (H,W) of the result."""
+    """src: (C,H,W) or (H,W) tensor on the GPU, float32 or uint8 (the two types the reference's extension takes, lib/_npp/nppig.cpp:94-104;
+    other types are warped as float32); Hm: 3x3 (or 2x3) FORWARD transform source -> destination, pixel centres at integer coordinates;
+    size: (H,W) of the result; taps outside the source read 0 (reference lib/image.py:38-59).  Returns the source's type."""
     assert src.dim() < 4 or src.shape[0] == 1
     H.require_gpu(src, 'warp_affine')
     no_cdim = src.dim() == 2
-    s = src.reshape(-1, *src.shape[-2:]).float().contiguous()
-    dst = torch.empty(s.shape[0], int(size[0]), int(size[1]), device=s.device)
+    u8 = src.dtype == torch.uint8
+    s = src.reshape(-1, *src.shape[-2:])
+    s = s.contiguous() if u8 else s.float().contiguous()
+    dst = torch.empty(s.shape[0], int(size[0]), int(size[1]), device=s.device, dtype=torch.uint8 if u8 else torch.float32)
     m = (ctypes.c_float * 6)(*[float(v) for v in np.asarray(Hm, dtype=np.float32)[:2].ravel()])
-    H.call('frtm_warp_affine', H.ptr(s), s.shape[0], s.shape[1], s.shape[2], H.ptr(dst), dst.shape[1], dst.shape[2], m, _MODES[mode])
+    H.call('frtm_warp_affine_u8' if u8 else 'frtm_warp_affine', s.data_ptr(), s.shape[0], s.shape[1], s.shape[2], dst.data_ptr(),
+           dst.shape[1], dst.shape[2], m, _MODES[mode])
     return dst.squeeze(0) if no_cdim else dst

@@ -335,7 +335,13 @@ class Discriminator(nn.Module):
                  init_iters=(5, 10, 10, 10, 10), update_iters=(10,), update_filters=True,
                  filter_reg=(1e-4, 1e-2), precond=(1e-4, 1e-2), precond_lr=0.1, CG_forgetting_rate=75,
                  memory_size=80, train_skipping=8, learning_rate=0.1,
-                 pixel_weighting=None, device=None, layer=None, keep_hires=False):
+                 pixel_weighting=None, device=None, layer=None, keep_hires=False, fletcher_reeves=False):
+        """Arguments of the reference (model/discriminator.py:74-79) plus
+        keep_hires       also store full-resolution labels / pixel weights (diagnostics)
+        fletcher_reeves  CG variant of BOTH solvers: False = Polak-Ribiere (what model/discriminator.py:172-173,192-193 passes);
+                         True together with CG_forgetting_rate=None (direction_forget_factor 0: CG state reset at every run) is the
+                         configuration the reference's YouTube-VOS fork actually runs -- its GaussNewtonCG is built with the optimizer's
+                         defaults (ytvos_validation/discriminator.py:256, optimizer.py:153-154; fixture G13)."""
         super().__init__()
         self.keep_hires = keep_hires     # also store full-resolution labels / pixel weights (DiscriminatorLoss.__call__)
         if out_channels != 1:
@@ -353,7 +359,9 @@ class Discriminator(nn.Module):
         self.update_iters = update_iters
         self.filter_reg = filter_reg
         self.precond = precond
-        self.direction_forget_factor = (1 - precond_lr) ** CG_forgetting_rate
+        # (the fork's rule, ytvos_validation/discriminator.py:277-281: no forgetting rate, or a learning rate of 1 -> factor 0 = reset)
+        self.direction_forget_factor = 0 if (CG_forgetting_rate is None or precond_lr >= 1) else (1 - precond_lr) ** CG_forgetting_rate
+        self.fletcher_reeves = bool(fletcher_reeves)
         self.train_skipping = train_skipping
         self.learning_rate = learning_rate
         self.memory_size = memory_size
@@ -530,8 +538,9 @@ class Discriminator(nn.Module):
 
     def _solver(self, tag, problem, variable):
         o = self._ws.get(tag)
-        if o is None or o.problem is not problem or o.direction_forget_factor != self.direction_forget_factor:
-            o = self._ws[tag] = GaussNewtonCG(problem, variable, fletcher_reeves=False, standard_alpha=True,
+        if (o is None or o.problem is not problem or o.direction_forget_factor != self.direction_forget_factor
+                or o.fletcher_reeves != self.fletcher_reeves):
+            o = self._ws[tag] = GaussNewtonCG(problem, variable, fletcher_reeves=self.fletcher_reeves, standard_alpha=True,
                                               direction_forget_factor=self.direction_forget_factor)
         o.x = variable
         o.persistent = False
@@ -560,21 +569,22 @@ class Discriminator(nn.Module):
         o1.rewind().run(self.update_iters)
         return o1
 
-    def apply(self, ft):
-        """Per-frame scoring (reference :201-206)."""
+    def apply(self, ft, interleave=None):
+        """Per-frame scoring (reference :201-206).  ``interleave`` = (batch, k, groups): the score map is written into a caller's
+        (frame, object) batch (ops.filter_scores) instead of a new tensor."""
         H.require_gpu(ft, 'Discriminator.apply')
         self.frame_num += 1
         cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)
         self.current_sample = cft
-        return ops.filter_scores(cft, self.filter.weight.data)
+        return ops.filter_scores(cft, self.filter.weight.data, interleave=interleave)
 
-    def apply_window(self, ft):
+    def apply_window(self, ft, interleave=None):
         """Scores for a WINDOW of frames at once: ft (W,Cin,h,w) -> (projected features (W,c,h,w), scores (W,1,h,w)).  Pure:
         neither the frame counter nor ``current_sample`` move; the caller replays the per-frame bookkeeping with ``advance``.
         Valid for frames between two filter re-solves (the filter is constant there, reference :221-227)."""
         H.require_gpu(ft, 'Discriminator.apply_window')
         cft = ops.conv2d(ft.contiguous(), self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels)
-        return cft, ops.filter_scores(cft, self.filter.weight.data)
+        return cft, ops.filter_scores(cft, self.filter.weight.data, interleave=interleave)
 
     def advance(self, cft_frame):
         """The bookkeeping half of apply() (:202-205) for one frame of a window: frame counter and the sample update() stores."""

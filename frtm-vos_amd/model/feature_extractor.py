@@ -146,6 +146,7 @@ class ResnetFeatureExtractor:
         self._handle = None
         self.device = None
         self.last_flops = 0.0
+        self.last_flops_executed = 0.0
         self.last_conv_launches = 0
         self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
         self._out_cache = {}
@@ -255,6 +256,8 @@ class ResnetFeatureExtractor:
                 e1.record(cur)
                 self.pass_events.append((e0, e1, self.last_flops, self.last_conv_launches))
                 self.pass_frames.append(B)
+                if getattr(self, 'pass_exec_flops', None) is not None:
+                    self.pass_exec_flops.append(self.last_flops_executed)
             if not capturing:
                 self._pass_done = torch.cuda.Event()
                 self._pass_done.record(cur)
@@ -304,7 +307,7 @@ class ResnetFeatureExtractor:
         if replay:
             ent['in'].copy_(x)
             ent['graph'].replay()
-            self.last_flops, self.last_conv_launches = ent['stats']
+            self.last_flops, self.last_conv_launches, self.last_flops_executed = ent['stats']
         else:
             self._forward(x, ent['out'], args, stop)
         return ent['out']
@@ -316,13 +319,14 @@ class ResnetFeatureExtractor:
         g = torch.cuda.CUDAGraph()
         with H.capture(g):
             self._forward(ent['in'], ent['out'], args, stop)
-        ent['stats'] = (self.last_flops, self.last_conv_launches)
+        ent['stats'] = (self.last_flops, self.last_conv_launches, self.last_flops_executed)
         ent['graph'], ent['gen'] = g, H.lib().frtm_backbone_generation(self._handle)
 
     def _forward(self, x, out, args, stop):
         ptrs = [H.ptr(out.get(L)) for L in ('layer1', 'layer2', 'layer3', 'layer4', 'layer5')]
         H.call('frtm_backbone_forward', self._handle, H.ptr(x), *args, *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
+        self.last_flops_executed = H.lib().frtm_backbone_last_flops_executed(self._handle)    # Winograd launches at the MACs they execute
         self.last_conv_launches = H.lib().frtm_backbone_last_conv_launches(self._handle)
 
     def get_out_channels(self):

@@ -59,8 +59,8 @@ class TargetObject:
     def initialize(self, ft, mask):
         self.discriminator.init(ft[self.disc_layer], mask)
 
-    def classify(self, ft):
-        return self.discriminator.apply(ft)
+    def classify(self, ft, interleave=None):
+        return self.discriminator.apply(ft, interleave=interleave)
 
 
 class Tracker(nn.Module):
@@ -111,6 +111,10 @@ class Tracker(nn.Module):
         # draws them un-seeded when the object appears (tracker.py:174-180, before its "HACK for debugging" seeds anything), so two
         # runs of the reference never start alike; reproducible runs and parity tests against a CPU run inject them here.
         self.start_weights = None
+        self.fuse_merge = True           # sigmoid + merge + pixel counts + label decoding of a window as ONE kernel (ops.track_merge)
+        self._lut = None                 # run_sequence: device uint8 table mask plane -> object id (label decoding inside the merge kernel)
+        self._single = False
+        self._window_labels = None
         self._raw_log = None             # list: (frame, masks before the merge) of every tracked frame is appended (ytvos merge, parity tests)
 
     def release_targets(self):
@@ -224,6 +228,7 @@ class Tracker(nn.Module):
         self.release_targets()
         N = 0
         object_ids = H.upload(torch.tensor([0] + list(sequence.obj_ids), dtype=torch.uint8), self.device)
+        self._lut, self._single = object_ids, len(sequence.obj_ids) == 1
         if speedrun:
             image, labels, obj_ids = sequence[0]
             self.initialize(image.to(self.device), labels.to(self.device), sequence.obj_ids)
@@ -241,7 +246,9 @@ class Tracker(nn.Module):
 
         def flush():
             if window:
-                labels_w = decode(self.track_window([im for im, _ in window], [ft for _, ft in window]))
+                masks_w = self.track_window([im for im, _ in window], [ft for _, ft in window])
+                # (the merge kernel has decoded the labels on the way when all planes came from the refiner; else: the ATen form)
+                labels_w = self._window_labels if self._window_labels is not None else decode(masks_w)
                 for f in range(labels_w.shape[0]):
                     outputs.append(labels_w[f])
                     self.current_frame += 1
@@ -284,6 +291,7 @@ class Tracker(nn.Module):
                 torch.cuda.synchronize()
         T = time() - t0
         self._raw_log = None
+        self._lut = None
         return outputs, N / T
 
     def _ytvos_labels(self, sequence, outputs, object_ids):
@@ -546,26 +554,44 @@ class Tracker(nn.Module):
             feats = first
         active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
         n = len(active)
-        masks = self.current_masks.unsqueeze(0).repeat(W, 1, 1, 1) if W > 1 else self.current_masks.unsqueeze(0)
-        cfts = []
-        if active:
-            per_obj = [t.discriminator.apply_window(feats[t.disc_layer]) for t in active]      # (W,c,h,w), (W,1,h,w)
-            cfts = [c for c, _ in per_obj]
-            scores = torch.stack([s for _, s in per_obj], dim=1).reshape(W * n, 1, *per_obj[0][1].shape[-2:])   # frame-major
-            y = torch.sigmoid(self.refiner(scores, feats, im_size)).view(W, n, *im_size)
-            for k, t in enumerate(active):
-                masks[:, t.index] = y[:, k]
-        for t1 in active:                                                                    # :208-212 (only when W == 1)
-            for t2 in self.targets.values():
-                if t2 is not t1 and t2.start_frame == self.current_frame:
-                    masks[0, t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
-        if getattr(self, '_raw_log', None) is not None:
-            for f in range(W):
-                self._raw_log.append((self.current_frame + f, masks[f].clone()))
-        ops.merge_masks_(masks)                                                              # :214-221, all frames of the window
+        self._window_labels = None
+        cfts, counts = [], None
+        # Every plane comes from the refiner (no object starts on these frames) -> the whole tail of track() is ONE kernel: sigmoid,
+        # merge, pixel counts and label decoding (ops.track_merge); the score maps are written straight into the refiner's
+        # (frame, object) batch.  Otherwise (an object starts here / raw masks are being logged): the step-by-step form below.
+        fused = bool(self.fuse_merge and active and n == len(self.targets) and n < 16 and getattr(self, '_raw_log', None) is None
+                     and all(t.index == k + 1 for k, t in enumerate(active)))
+        if fused:
+            h_, w_ = feats[active[0].disc_layer].shape[-2:]
+            scores = torch.empty(W * n, 1, h_, w_, device=self.device)
+            cfts = [t.discriminator.apply_window(feats[t.disc_layer], interleave=(scores, k, n))[0] for k, t in enumerate(active)]
+            logits = self.refiner(scores, feats, im_size)                                        # (W*n,1,H,W), frame-major
+            masks = torch.empty(W, n + 1, *im_size, device=self.device)
+            labels = torch.empty(W, 1, *im_size, dtype=torch.uint8, device=self.device) if self._lut is not None else None
+            counts = torch.empty(W, n + 1, dtype=torch.int32, device=self.device) if self.disc_params.update_filters else None
+            ops.track_merge(logits, W, n, masks, labels, self._lut, self._single, counts)
+            self._window_labels = labels
+        else:
+            masks = self.current_masks.unsqueeze(0).repeat(W, 1, 1, 1) if W > 1 else self.current_masks.unsqueeze(0)
+            if active:
+                per_obj = [t.discriminator.apply_window(feats[t.disc_layer]) for t in active]      # (W,c,h,w), (W,1,h,w)
+                cfts = [c for c, _ in per_obj]
+                scores = torch.stack([s for _, s in per_obj], dim=1).reshape(W * n, 1, *per_obj[0][1].shape[-2:])   # frame-major
+                y = torch.sigmoid(self.refiner(scores, feats, im_size)).view(W, n, *im_size)
+                for k, t in enumerate(active):
+                    masks[:, t.index] = y[:, k]
+            for t1 in active:                                                                    # :208-212 (only when W == 1)
+                for t2 in self.targets.values():
+                    if t2 is not t1 and t2.start_frame == self.current_frame:
+                        masks[0, t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+            if getattr(self, '_raw_log', None) is not None:
+                for f in range(W):
+                    self._raw_log.append((self.current_frame + f, masks[f].clone()))
+            ops.merge_masks_(masks)                                                              # :214-221, all frames of the window
         if active and self.disc_params.update_filters:
             K = masks.shape[1]
-            counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)                 # device int32, no sync
+            if counts is None:
+                counts = ops.count_above(masks.view(W * K, *im_size)).view(W, K)             # device int32, no sync
             on_device = all(t.discriminator.guards_on_device() for t in active)
             if on_device and masks.is_contiguous() and all(t.discriminator.can_update_window(W) for t in active):
                 # every insert of the window and the re-solve at its end decided on the device: one batched update per object
@@ -598,20 +624,36 @@ class Tracker(nn.Module):
         if features is None:
             features = self.feature_extractor(image)
         active = [t for t in self.targets.values() if t.start_frame < self.current_frame]
-        if active:
-            scores = torch.cat([t.classify(features[t.disc_layer]) for t in active])       # (n,1,h,w)
-            y = torch.sigmoid(self.refiner(scores, features, im_size))                       # (n,1,H,W)
+        n = len(active)
+        counts = None
+        fused = bool(self.fuse_merge and active and n == len(self.targets) and n < 16 and getattr(self, '_raw_log', None) is None
+                     and all(t.index == k + 1 for k, t in enumerate(active)) and self.current_masks.is_contiguous())
+        if fused:
+            # all planes come from the refiner: scores into one batch, then sigmoid + merge + pixel counts as one kernel (ops.track_merge)
+            h_, w_ = features[active[0].disc_layer].shape[-2:]
+            scores = torch.empty(n, 1, h_, w_, device=self.device)
             for k, t in enumerate(active):
-                self.current_masks[t.index] = y[k, 0]
-        for t1 in active:                                                                    # :208-212
-            for t2 in self.targets.values():
-                if t2 is not t1 and t2.start_frame == self.current_frame:
-                    self.current_masks[t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
-        if getattr(self, '_raw_log', None) is not None:
-            self._raw_log.append((self.current_frame, self.current_masks.clone()))
-        ops.merge_masks_(self.current_masks)                                                 # :214-221
+                t.classify(features[t.disc_layer], interleave=(scores, k, n))
+            logits = self.refiner(scores, features, im_size)
+            counts = torch.empty(1, n + 1, dtype=torch.int32, device=self.device) if self.disc_params.update_filters else None
+            ops.track_merge(logits, 1, n, self.current_masks, None, None, False, counts)
+            counts = None if counts is None else counts[0]
+        else:
+            if active:
+                scores = torch.cat([t.classify(features[t.disc_layer]) for t in active])       # (n,1,h,w)
+                y = torch.sigmoid(self.refiner(scores, features, im_size))                       # (n,1,H,W)
+                for k, t in enumerate(active):
+                    self.current_masks[t.index] = y[k, 0]
+            for t1 in active:                                                                    # :208-212
+                for t2 in self.targets.values():
+                    if t2 is not t1 and t2.start_frame == self.current_frame:
+                        self.current_masks[t1.index] *= (1 - t2.start_mask.squeeze(0)).float()
+            if getattr(self, '_raw_log', None) is not None:
+                self._raw_log.append((self.current_frame, self.current_masks.clone()))
+            ops.merge_masks_(self.current_masks)                                                 # :214-221
         if active and self.disc_params.update_filters:
-            counts = ops.count_above(self.current_masks)                                     # device int32 (n_obj+1), no sync
+            if counts is None:
+                counts = ops.count_above(self.current_masks)                                 # device int32 (n_obj+1), no sync
             solve = any(t.discriminator.frame_num % t.discriminator.train_skipping == 0 for t in active)
             host = counts.tolist() if solve and not all(t.discriminator.guards_on_device() for t in active) else None
             for k, t in enumerate(active):

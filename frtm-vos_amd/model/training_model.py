@@ -1,13 +1,19 @@
-"""Refiner-training model with the on-disk target-model cache (API of the reference's model/training_model.py:11-183).
+"""Refiner training on top of the HIP target-model fit (counterpart of the reference's model/training_model.py).
 
-SURVEY.md 8f rank 4.  What the reference's training loop spends its first ~5 days on (README.md:144-145) is exactly the hot path of
-this package: for every training sample the target model is FITTED on the augmented first frame (``Discriminator.init``: trunk on
-the augmented stack + joint GN/CG fit) and its two weight tensors are cached on disk as
-``<cache>/<sequence>/<frame0 id>.<object id>.<layer>.pth`` (reference :168-183).  Here that fit runs on the HIP kernels; the
-cache keeps the reference's file naming and state-dict layout ({project.weight, filter.weight}), so caches are interchangeable.
+What the reference's training loop spends its first days on (README.md:144-145) is this package's hot path: for every training sample
+the target model is fitted on the augmented first frame and its two weight tensors are written to
+``<cache>/<sequence>/<frame0 id>.<object id>.<layer>.pth`` (reference :168-183).  Division of labour here:
 
-The refiner itself is trained through ``SegNetwork.forward_torch`` (the PyTorch definition, autograd); the HIP inference path of the
-refiner has no backward and refuses grad mode.  Scores come from the fitted (frozen) target models on the HIP path.
+  TargetModelCache   the on-disk store: the reference's file naming and state-dict layout {project.weight, filter.weight}, so caches are
+                     interchangeable between the two code bases; a torn file is treated as a miss.
+  TargetModelBank    B frozen target models for the B samples of a batch: ``fit_or_load`` fills each from the cache or fits it on the HIP
+                     path (augmenter -> trunk -> Discriminator.init) and stores it; ``scores`` evaluates all of them on a feature batch.
+  TrainerModel       the nn.Module the training driver calls (reference interface: constructor arguments, ``forward(images, labels,
+                     meta) -> stats dict``, refiner-only checkpoints under the 'refiner.' prefix): per sample set, frame 0 goes to the bank,
+                     every later frame contributes one BCE backward pass through the refiner's PyTorch definition
+                     (``SegNetwork.forward_torch``: the HIP inference path of the refiner has no autograd and refuses grad mode).
+
+The training DRIVER (optimiser, schedule, data loaders, logging: train.py, lib/training.py) is out of scope.
 """
 import json
 from pathlib import Path
@@ -15,80 +21,116 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
-from ..lib.utils import AverageMeter, interpolate
+from ..lib.utils import interpolate
 from .discriminator import Discriminator
 
 
 class SampleSpec:
-    """One training sample: sequence, object, the frames of the sample and the id of its first frame (reference
-    lib/training_datasets.py:16-34; the dataset classes around it are file I/O and stay out of scope)."""
+    """Identity of a training sample as it travels through a DataLoader's collate step: JSON in, JSON out
+    (fields of the reference's lib/training_datasets.py:16-34)."""
+    FIELDS = ('seq_name', 'obj_id', 'frames', 'frame0_id')
 
     def __init__(self, seq_name=None, obj_id=None, frames=None, frame0_id=None):
         self.seq_name, self.obj_id, self.frames, self.frame0_id = seq_name, obj_id, frames, frame0_id
 
-    def __repr__(self):
-        return 'SampleSpec: ' + str(vars(self))
-
     def encoded(self):
-        return json.dumps(vars(self))
+        return json.dumps({k: getattr(self, k) for k in self.FIELDS})
 
-    @staticmethod
-    def from_encoded(meta):
-        return [SampleSpec(**json.loads(m)) for m in meta]
+    @classmethod
+    def from_encoded(cls, meta):
+        return [cls(**json.loads(m)) for m in meta]
+
+    def __repr__(self):
+        return 'SampleSpec(%s)' % ', '.join('%s=%r' % (k, getattr(self, k)) for k in self.FIELDS)
 
 
 class TargetModelCache:
-    """``enable`` / ``read_only`` / ``path`` like the reference's ``tmodel_cache`` dict (train.py:73-78), plus the file scheme
-    of training_model.py:168-183."""
 
     def __init__(self, path=None, enable=True, read_only=False):
-        self.path = None if path is None else Path(path)
-        self.enable = bool(enable) and path is not None
-        self.read_only = read_only
+        self.path = Path(path) if path is not None else None
+        self.enable = bool(enable and path is not None)
+        self.read_only = bool(read_only)
+
+    @classmethod
+    def from_config(cls, cfg):
+        """Accepts the reference's ``tmodel_cache`` dict (train.py:73-78), an instance, or None (disabled)."""
+        if isinstance(cfg, cls):
+            return cfg
+        if cfg is None:
+            return cls(None, enable=False)
+        return cls(cfg.get('path'), cfg.get('enable', True), cfg.get('read_only', False))
 
     def filename(self, spec, layer_name):
         return self.path / spec.seq_name / ('%05d.%d.%s.pth' % (spec.frame0_id, spec.obj_id, layer_name))
 
     def load(self, spec, layer_name, device=None):
-        f = self.filename(spec, layer_name)
-        if not f.exists():
+        if not self.enable:
             return None
+        f = self.filename(spec, layer_name)
         try:
-            return torch.load(f, map_location=device)
-        except Exception as e:                            # a torn file from an interrupted run: refit instead of failing
-            print('Could not read %s: %s' % (f, e))
+            return torch.load(f, map_location=device) if f.exists() else None
+        except Exception as e:                       # interrupted writer: refit instead of failing the epoch
+            print('target-model cache: unreadable %s (%s), refitting' % (f, e))
             return None
 
     def save(self, spec, layer_name, state_dict):
+        if not self.enable or self.read_only:
+            return
         f = self.filename(spec, layer_name)
-        f.parent.mkdir(exist_ok=True, parents=True)
+        f.parent.mkdir(parents=True, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in state_dict.items()}, f)
 
 
-class TargetObject:
-    """Training flavour of the tracker's TargetObject (reference :11-33): fitted once, then frozen."""
+class _FrozenTarget:
+    """One slot of the bank (``tmodels[i]`` of the reference's trainer): a Discriminator whose weights stay fixed after the fit."""
 
-    def __init__(self, disc_params, **kwargs):
+    def __init__(self, disc_params):
         self.discriminator = Discriminator(**disc_params)
-        for key, val in kwargs.items():
-            setattr(self, key, val)
-
-    def initialize(self, ft, mask):
-        self.discriminator.init(ft[self.discriminator.layer], mask)
-
-    def initialize_pretrained(self, state_dict):
-        d = self.discriminator
-        d.load_state_dict({k: v.to(d.project.weight.device) for k, v in state_dict.items()})
-        for p in d.parameters():
-            p.requires_grad_(False)
-        d.eval()
-        d._invalidate()                                    # the transposed projection cached for the GEMM is stale
 
     def get_state_dict(self):
         return self.discriminator.state_dict()
 
-    def classify(self, ft):
-        return self.discriminator.apply(ft)
+    def load(self, state_dict):
+        d = self.discriminator
+        d.load_state_dict({k: v.to(d.project.weight.device) for k, v in state_dict.items()})
+        d._invalidate()                                # the GEMM-layout copy of the projection is stale
+        d.eval()
+
+
+class TargetModelBank:
+
+    def __init__(self, disc_params, size):
+        self.slots = [_FrozenTarget(disc_params) for _ in range(size)]
+        self.layer = disc_params['layer']
+
+    @torch.no_grad()
+    def fit_or_load(self, images, labels, specs, cache, augment, extractor, device):
+        """Frame 0 of every sample: target model from the cache, else fitted here (and stored).  Returns the number of cache hits."""
+        hits = 0
+        for slot, image, label, spec in zip(self.slots, images, labels, specs):
+            stored = cache.load(spec, self.layer, device)
+            if stored is not None:
+                slot.load(stored)
+                hits += 1
+                continue
+            stack, masks = augment(image.to(device), label.to(device))
+            feats = extractor.no_grad_forward(stack, output_layers=[self.layer], chunk_size=4)
+            slot.discriminator.init(feats[self.layer], masks)
+            cache.save(spec, self.layer, slot.get_state_dict())
+        return hits
+
+    @torch.no_grad()
+    def scores(self, layer_features):
+        """(B,Cin,h,w) -> (B,1,h,w): sample i scored by target model i."""
+        return torch.cat([slot.discriminator.apply(layer_features[i:i + 1]) for i, slot in enumerate(self.slots[:layer_features.shape[0]])])
+
+
+def mask_iou(pred, gt):
+    """IoU of the thresholded maps per sample; two empty masks count as a perfect match."""
+    p, g = pred > 0.5, gt > 0.5
+    inter = (p & g).flatten(-2).sum(-1).float()
+    union = (p | g).flatten(-2).sum(-1).float()
+    return torch.where(union > 0, inter / union.clamp(min=1), torch.ones_like(union))
 
 
 class TrainerModel(nn.Module):
@@ -96,91 +138,56 @@ class TrainerModel(nn.Module):
     def __init__(self, augmenter, feature_extractor, disc_params, seg_network, batch_size=0, tmodel_cache=None, device=None):
         super().__init__()
         self.augmenter = augmenter
-        self.augment = augmenter.augment_first_frame
-        self.tmodels = [TargetObject(disc_params) for _ in range(batch_size)]
         self.feature_extractor = feature_extractor
         self.refiner = seg_network
-        if isinstance(tmodel_cache, dict):
-            tmodel_cache = TargetModelCache(tmodel_cache.get('path'), tmodel_cache.get('enable', True), tmodel_cache.get('read_only', False))
-        self.tmodel_cache = tmodel_cache if tmodel_cache is not None else TargetModelCache(None, enable=False)
         self.device = device
+        self.bank = TargetModelBank(disc_params, batch_size)
+        self.tmodel_cache = TargetModelCache.from_config(tmodel_cache)
         self.compute_loss = nn.BCELoss()
-        self.compute_accuracy = self.intersection_over_union
-        self.ft_channels = None
+        self.compute_accuracy = mask_iou
 
-    # checkpoints hold the refiner only, under the 'refiner.' prefix (reference :57-70; same keys as the inference checkpoints)
-    def load_state_dict(self, state_dict):
-        assert all(k.startswith('refiner.') for k in state_dict)
-        self.refiner.load_state_dict({k[len('refiner.'):]: v for k, v in state_dict.items()})
+    @property
+    def tmodels(self):
+        return self.bank.slots
 
-    def state_dict(self):
-        return self.refiner.state_dict(prefix='refiner.')
-
-    @staticmethod
-    def intersection_over_union(pred, gt):
-        pred, gt = (pred > 0.5).float(), (gt > 0.5).float()
-        i = (pred * gt).sum(dim=(-2, -1))
-        u = ((pred + gt) > 0.5).float().sum(dim=(-2, -1))
-        iou = i / u
-        iou[torch.isinf(iou)] = 0.0
-        iou[torch.isnan(iou)] = 1.0                        # both empty
-        return iou
-
-    # ---- the cache (reference :168-183) -----------------------------------------------------------------------------
     def tmodel_filename(self, spec, layer_name):
         return self.tmodel_cache.filename(spec, layer_name)
 
-    def load_target_model(self, spec, layer_name):
-        return self.tmodel_cache.load(spec, layer_name, self.device)
+    # checkpoints hold the refiner only, keyed like the inference checkpoints ('refiner.*')
+    def state_dict(self):
+        return self.refiner.state_dict(prefix='refiner.')
 
-    def save_target_model(self, spec, layer_name, state_dict):
-        self.tmodel_cache.save(spec, layer_name, state_dict)
+    def load_state_dict(self, state_dict):
+        stray = [k for k in state_dict if not k.startswith('refiner.')]
+        if stray:
+            raise KeyError('trainer checkpoints hold refiner weights only, got %s' % stray[:3])
+        self.refiner.load_state_dict({k[len('refiner.'):]: v for k, v in state_dict.items()})
 
-    # ---- one training sample set (reference :92-166) ----------------------------------------------------------------------
+    def _predict(self, image):
+        """sigmoid(refiner(score, taps)) for a batch of frames: trunk and target models frozen on the HIP path, the refiner with autograd."""
+        with torch.no_grad():
+            taps = self.feature_extractor(image)
+            scores = self.bank.scores(taps[self.bank.layer])
+            taps = {k: v.clone() for k, v in taps.items()}        # (the extractor may reuse its output buffers)
+        with torch.enable_grad():
+            logits = self.refiner.forward_torch(scores, taps, image.shape)
+            return torch.sigmoid(interpolate(logits, image.shape[-2:]))
+
     def forward(self, images, labels, meta):
-        """images / labels: lists over the frames of the samples, each (B,3,H,W) uint8 / (B,1,H,W); meta: encoded SampleSpecs.
-        Fits (or loads) the B target models on frame 0, then accumulates the BCE gradients of the refiner over the other frames."""
+        """images / labels: per frame of the sample set a (B,3,H,W) uint8 / (B,1,H,W) batch; meta: encoded SampleSpecs.  Gradients of the
+        BCE loss accumulate in the refiner's parameters (one backward per frame); the caller steps the optimiser."""
         specs = SampleSpec.from_encoded(meta)
-        losses, acc_sum, n = AverageMeter(), 0.0, 0
-        cache_hits = self._initialize(images[0], labels[0], specs)
-        for i in range(1, len(images)):
-            s = self._forward(images[i].to(self.device))
-            y = labels[i].to(self.device).float()
-            acc = self.compute_accuracy(s.detach(), y)
+        hits = self.bank.fit_or_load(images[0], labels[0], specs, self.tmodel_cache, self.augmenter.augment_first_frame,
+                                     self.feature_extractor, self.device)
+        loss_sum, acc_sum, n = 0.0, 0.0, 0
+        for image, label in zip(images[1:], labels[1:]):
+            pred = self._predict(image.to(self.device))
+            target = label.to(self.device).float()
             with torch.enable_grad():
-                loss = self.compute_loss(s, y)
+                loss = self.compute_loss(pred, target)
             loss.backward()
-            losses.update(loss.item())
-            acc_sum += float(acc.mean())
+            loss_sum += float(loss)
+            acc_sum += float(self.compute_accuracy(pred.detach(), target).mean())
             n += 1
-        return {'stats/loss': losses.avg, 'stats/accuracy': acc_sum / max(n, 1), 'stats/fcache_hits': cache_hits}
-
-    @torch.no_grad()
-    def _initialize(self, first_image, first_labels, specs):
-        L = self.tmodels[0].discriminator.layer
-        hits = 0
-        for i in range(first_image.shape[0]):
-            cache = self.tmodel_cache
-            sd = self.load_target_model(specs[i], L) if cache.enable else None
-            if sd is None:
-                im, lb = self.augment(first_image[i].to(self.device), first_labels[i].to(self.device))
-                ft = self.feature_extractor.no_grad_forward(im, output_layers=[L], chunk_size=4)
-                self.tmodels[i].initialize(ft, lb)
-                if cache.enable and not cache.read_only:
-                    self.save_target_model(specs[i], L, self.tmodels[i].get_state_dict())
-            else:
-                if self.ft_channels is None:
-                    self.ft_channels = self.feature_extractor.get_out_channels()[L]
-                self.tmodels[i].initialize_pretrained(sd)
-                hits += 1
-        return hits
-
-    def _forward(self, image):
-        with torch.no_grad():                              # trunk and target models are frozen: HIP inference path
-            features = self.feature_extractor(image)
-            ft = features[self.tmodels[0].discriminator.layer]
-            scores = torch.cat([t.classify(ft[i:i + 1]) for i, t in zip(range(image.shape[0]), self.tmodels)])
-            features = {k: v.clone() for k, v in features.items()}
-        with torch.enable_grad():                          # PyTorch definition of the refiner: autograd for its weights
-            y = self.refiner.forward_torch(scores, features, image.shape)
-            return torch.sigmoid(interpolate(y, image.shape[-2:]))
+        n = max(n, 1)
+        return {'stats/loss': loss_sum / n, 'stats/accuracy': acc_sum / n, 'stats/fcache_hits': hits}

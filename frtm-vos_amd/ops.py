@@ -73,10 +73,17 @@ def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=N
     return out
 
 
-def filter_scores(X, f, out=None, accumulate=False, n=None):
-    """(N,C,h,w) x (1,C,3,3) -> (N,1,h,w)."""
+def filter_scores(X, f, out=None, accumulate=False, n=None, interleave=None):
+    """(N,C,h,w) x (1,C,3,3) -> (N,1,h,w).
+    ``interleave`` = (batch, k, groups): write map i to batch[i * groups + k] instead (batch: (N * groups, 1, h, w) dense) -- the
+    frame-major (frame, object) score batch of a tracking window, filled object by object without a torch.stack afterwards."""
     N = X.shape[0] if n is None else n
     C, h, w = X.shape[1:]
+    if interleave is not None:
+        batch, k, groups = interleave
+        assert batch.is_contiguous() and batch.shape[0] == N * groups and tuple(batch.shape[-2:]) == (h, w)
+        H.call('frtm_filter_scores_pitched', H.ptr(X), H.ptr(f), N, C, h, w, batch.data_ptr() + 4 * k * h * w, groups * h * w, int(accumulate))
+        return batch
     if out is None:
         out = torch.empty(N, 1, h, w, device=X.device)
     H.call('frtm_filter_scores', H.ptr(X), H.ptr(f), N, C, h, w, H.ptr(out), int(accumulate))
@@ -120,3 +127,16 @@ def count_above(masks, thr=0.5):
     cnt = torch.empty(m.shape[0], dtype=torch.int32, device=masks.device)
     H.call('frtm_count_above', H.ptr(m), m.shape[0], m.shape[1], float(thr), H.ptr(cnt))
     return cnt
+
+
+def track_merge(logits, frames, n_obj, masks, labels=None, lut=None, single_object=False, counts=None, thr=0.5):
+    """The tail of Tracker.track for a window in one pass (frtm_track_merge): refiner logits (frames * n_obj, 1, H, W), frame-major ->
+    sigmoid -> merge -> ``masks`` (frames, n_obj + 1, H, W); optional ``labels`` (frames, 1, H, W) uint8 through ``lut`` (n_obj + 1
+    device bytes) and ``counts`` (frames, n_obj + 1) int32 = pixels above ``thr`` per plane."""
+    Hh, Ww = masks.shape[-2:]
+    assert logits.is_contiguous() and masks.is_contiguous() and logits.shape[0] == frames * n_obj and masks.numel() == frames * (n_obj + 1) * Hh * Ww
+    assert labels is None or (labels.is_contiguous() and labels.dtype == torch.uint8 and lut is not None and lut.dtype == torch.uint8)
+    assert counts is None or (counts.is_contiguous() and counts.dtype == torch.int32 and counts.numel() == frames * (n_obj + 1))
+    H.call('frtm_track_merge', H.ptr(logits), frames, n_obj, Hh * Ww, H.ptr(masks), None if labels is None else labels.data_ptr(),
+           None if lut is None else lut.data_ptr(), int(bool(single_object)), None if counts is None else counts.data_ptr(), float(thr))
+    return masks

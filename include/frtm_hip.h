@@ -297,6 +297,8 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
                           int stop_after_layer, frtm_stream_t stream);
 /* FLOPs (2*MAC over all convs) of the last forward() call. */
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
+/* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */
+double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb);
 /* Number of convolutions (k_conv_igemm launches) of the last forward() call. */
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb);
 /* Concurrency of forward(): a batch of B frames is split into min(lanes, B) sub-batches that run on the caller's stream
@@ -370,6 +372,10 @@ int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream
  * ------------------------------------------------------------------------------------------ */
 int frtm_warp_affine(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd,
                      const float* fwd6_host, int mode, frtm_stream_t stream);
+/* The uint8 entry point of the reference's extension (nppig.cpp:99-100, nppiWarpAffine_8u_C1R): uint8 planes in, uint8 planes out;
+ * nearest copies, bilinear / bicubic round the float interpolant to nearest and saturate. */
+int frtm_warp_affine_u8(const unsigned char* src, int C, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* fwd6_host,
+                        int mode, frtm_stream_t stream);
 /* n <= 32 nearest-neighbour warps of ONE mask plane (nonzero = set) in one launch: dst (n,Hd,Wd) uint8 {0,1}, count_dev int32[n] =
  * set pixels per warp.  fwd6_host: n forward 2x3 transforms (host memory).  The augmenter's candidate test (reference
  * model/augmenter.py:454-471 verify_frame looks at the candidates' label pixel counts only). */

@@ -294,6 +294,28 @@ def test_bench_launches_its_own_ranks_gloo(tmp_path):
     assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
 
 
+def test_bench_sharded_mode_cuts_the_dataset_over_the_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2 --sequences 11` (BASELINE config 4's shape: one dataset sharded over the ranks, strong scaling): the two
+    ranks take disjoint, length-balanced shares that cover the dataset; rank 0 reports the SUM of frames over the max wall time."""
+    import importlib.util
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--launch-check',
+                          '--sequences', '11', '--report-dir', str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    specs = bench.dataset_specs(11, (480, 854))
+    total = sum(L for _, L, _, _ in specs)
+    assert line['scaling'] == 'strong' and line['n_gpus'] == 2 and line['frames_total'] == total == line['frames_from_rank_reports']
+    r0, r1 = (json.load(open(tmp_path / ('rank_%d.json' % r))) for r in range(2))
+    assert sorted(r0['sequence_ids'] + r1['sequence_ids']) == list(range(11)) and not set(r0['sequence_ids']) & set(r1['sequence_ids'])
+    cost = lambda ids: sum(specs[i][1] * specs[i][2] for i in ids)
+    assert abs(cost(r0['sequence_ids']) - cost(r1['sequence_ids'])) <= max(L * k for _, L, k, _ in specs)      # longest-first greedy bound
+
+
 def test_length_balanced_sharding_and_rank_reports(tmp_path):
     from frtm_vos_amd.shard import aggregate_reports, shard_indices, write_rank_report
     costs = [100, 10, 10, 10, 90, 10, 10, 60]
@@ -534,3 +556,29 @@ def test_trunk_batch_schedule():
         sz = Tracker.batch_sizes(folded, n, 16)
         assert sum(sz) == n and all(1 <= v <= 19 for v in sz) and (len(sz) < 2 or sz[-1] > 3)
     assert Tracker.batch_sizes(even, 63, 16) == [16, 16, 16, 15]
+
+
+def test_warp_ref_against_grid_sample():
+    """oracle/warp_ref.py (the checker of the HIP warp kernels; convention of lib/image.py:38-59 / lib/_npp/nppig.cpp:48-104: forward
+    transform, pixel centres at integer coordinates, zeros outside) against an independent implementation of the same interpolants,
+    F.grid_sample(align_corners=True, padding_mode='zeros'): nearest, bilinear, bicubic (a = -0.75), rotation x scale x skew x flip x
+    shift, border pixels included."""
+    from oracle.warp_ref import augmenter_like_transforms, grid_sample_warp, warp_affine_ref
+    g = torch.Generator().manual_seed(0)
+    src = torch.rand(2, 40, 50, generator=g, dtype=torch.float64) * 255
+    for Tm in augmenter_like_transforms((40, 50), 6, seed=1):
+        for mode in ('nearest', 'bilinear', 'bicubic'):
+            a, b = warp_affine_ref(src, Tm, (44, 61), mode), grid_sample_warp(src, Tm, (44, 61), mode)
+            if mode == 'nearest':      # grid_sample rounds half to even, the warp half up: only exact .5 coordinates may differ
+                assert float(((a - b).abs() > 1e-9).float().mean()) < 1e-3
+            else:
+                assert float((a - b).abs().max()) < 1e-9, mode
+    # identity / integer shift: exact copies
+    eye = np.eye(3, dtype=np.float32)
+    sh = np.array([[1, 0, 3], [0, 1, -2], [0, 0, 1]], dtype=np.float32)
+    for mode in ('nearest', 'bilinear', 'bicubic'):
+        assert float((warp_affine_ref(src, eye, (40, 50), mode) - src).abs().max()) < 1e-9
+        out = warp_affine_ref(src, sh, (40, 50), mode)
+        assert float((out[:, :38, 3:] - src[:, 2:, :47]).abs().max()) < 1e-9 and float(out[:, 38:].abs().max()) == 0
+    u8 = (src[0]).to(torch.uint8)
+    assert torch.equal(warp_affine_ref(u8, eye, (40, 50), 'bilinear'), u8)

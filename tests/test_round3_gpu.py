@@ -108,6 +108,9 @@ def test_device_guard_on_wide_maps_equals_the_host_decision(shape):
     N, c, h, w, Hh, Ww = shape
     mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 9, True)
     mem2, opt2, wv2, _ = _filter_problem(N, c, h, w, Hh, Ww, 9, True)
+    opt.problem.initialize()
+    opt._alloc()
+    opt2._alloc()
     assert opt._persistent_plan() is None and opt.can_guard()
     few, many = torch.tensor([3], dtype=torch.int32, device=DEV), torch.tensor([5000], dtype=torch.int32, device=DEV)
     for guard, solved in ((many, True), (few, False), (many, True)):
@@ -119,3 +122,196 @@ def test_device_guard_on_wide_maps_equals_the_host_decision(shape):
         if not solved:
             assert torch.equal(wv, before[0]) and torch.equal(opt._buf, before[1]) and torch.equal(opt._state, before[2])
     assert opt.persistent_counts() == (2, 1)
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 15])
+def test_track_merge_equals_the_step_by_step_tail(n):
+    """ops.track_merge (sigmoid + merge + pixel counts + label decoding of a tracking window as ONE kernel) against the separate steps it
+    replaces -- torch.sigmoid, plane copies, the merge kernel (pinned to the reference's merge by G6), count_above, and the reference's
+    label decoding (tracker.py:143-150: one object: masks[1] > 0.5; several: the merge applied to the merged masks, arg-max) -- and the
+    merge itself against the CPU oracle."""
+    from oracle import cpu_ref as O
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(40 + n)
+    W, Hh, Ww = 3, 50, 67                                            # odd sizes: scalar tails
+    logits = (4 * torch.randn(W * n, 1, Hh, Ww, generator=g)).to(DEV)
+    lut = torch.tensor([0] + [(7 * k + 3) % 250 + 1 for k in range(n)], dtype=torch.uint8, device=DEV)
+    masks = torch.empty(W, n + 1, Hh, Ww, device=DEV)
+    labels = torch.empty(W, 1, Hh, Ww, dtype=torch.uint8, device=DEV)
+    counts = torch.empty(W, n + 1, dtype=torch.int32, device=DEV)
+    ops.track_merge(logits, W, n, masks, labels, lut, n == 1, counts)
+    ref = torch.zeros(W, n + 1, Hh, Ww, device=DEV)
+    ref[:, 1:] = torch.sigmoid(logits).view(W, n, Hh, Ww)
+    raw = ref.clone()
+    ops.merge_masks_(ref)
+    assert float((masks - ref).abs().max()) < 5e-7                    # (expf of the two sigmoid forms may differ in the last bit)
+    same = (masks > 0) == (ref > 0)
+    assert float(same.float().mean()) > 0.9999
+    cnt = ops.count_above(ref.view(W * (n + 1), Hh, Ww)).view(W, n + 1)
+    assert int((counts - cnt).abs().max()) <= 2
+    if n == 1:
+        lab = lut[(ref[:, 1:2] > 0.5).long()]
+    else:
+        lab = lut[ops.merge_masks_(ref.clone()).argmax(dim=1, keepdim=True)]
+    assert float((labels == lab).float().mean()) > 0.9999
+    cpu = torch.stack([O.merge_masks(raw[f].cpu()) for f in range(W)])
+    assert float((masks.cpu() - cpu).abs().max()) < 1e-6
+
+
+def test_scores_written_into_the_frame_major_batch():
+    """ops.filter_scores(interleave=(batch, k, groups)): object k's maps land at batch[f * groups + k] -- what torch.stack(dim=1) of the
+    per-object results gave."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for (W, c, h, w) in ((8, 96, 30, 54), (1, 96, 30, 54), (3, 16, 45, 80), (2, 96, 68, 120)):
+        n = 3
+        feats = [torch.relu(torch.randn(W, c, h, w, generator=g)).to(DEV) for _ in range(n)]
+        filt = [(torch.randn(1, c, 3, 3, generator=g) / 30).to(DEV) for _ in range(n)]
+        batch = torch.full((W * n, 1, h, w), float('nan'), device=DEV)
+        for k in range(n):
+            ops.filter_scores(feats[k], filt[k], interleave=(batch, k, n))
+        ref = torch.stack([ops.filter_scores(feats[k], filt[k]) for k in range(n)], dim=1).reshape(W * n, 1, h, w)
+        assert torch.equal(batch, ref)
+
+
+def test_fused_window_tail_equals_the_step_by_step_tracker():
+    """Tracker.run_sequence with the fused merge kernel (default) vs fuse_merge = False: same label images (up to last-bit differences of
+    the sigmoid at the 0.5 threshold) and the same memory / filter state, 1 and 3 objects, a late object included."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence, make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    torch.set_grad_enabled(False)
+
+    def refiner(chans):
+        torch.manual_seed(1)
+        return make_score_following_refiner(SegNetwork(1, 64, chans, True).eval())
+    for n_obj, late in ((1, None), (3, None), (2, 5)):
+        outs = []
+        for fuse in (True, False):
+            params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18')
+            params.refiner_factory = refiner
+            params.disc_params.update(memory_size=12, init_iters=(3, 5), update_iters=(3,))
+            trk = params.get_model().eval()
+            trk.fuse_merge = fuse
+            seq = SyntheticSequence('f', 19, (128, 160), n_obj, seed=31, late_object_at=late)
+            seq.preload(DEV)
+            torch.manual_seed(5)
+            labels, _ = trk.run_sequence(seq)
+            filt = [t.discriminator.filter.weight.detach().clone() for t in trk.targets.values()]
+            outs.append((torch.stack([l.reshape(128, 160) for l in labels]).cpu(), filt))
+        agree = float((outs[0][0] == outs[1][0]).float().mean())
+        assert agree > 0.9995, (n_obj, late, agree)
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert float((a - b).abs().max() / b.abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize('mode', ['nearest', 'bilinear', 'bicubic'])
+def test_warp_affine_against_the_oracle(mode):
+    """k_warp_affine (float32 and uint8 entry points) against oracle/warp_ref.py on rotation x scale x skew x flip x shift transforms,
+    source and destination of different sizes, border pixels included.  The kernel computes source coordinates in float32 (the oracle
+    in float64): a coordinate error of ~1e-4 pixels moves an interpolated value by at most that times the local gradient, and flips a
+    nearest-neighbour pick only within 1e-4 of a half-integer coordinate."""
+    import numpy as np
+    from oracle.warp_ref import augmenter_like_transforms, warp_affine_ref
+    from frtm_vos_amd.lib.image import warp_affine
+    g = torch.Generator().manual_seed(7)
+    src = torch.rand(3, 120, 214, generator=g) * 255
+    lo = torch.nn.functional.avg_pool2d(src[None], 5, 1, 2)[0]          # smooth version: bounded gradients (<= ~40 per pixel)
+    for Tm in augmenter_like_transforms((120, 214), 8, seed=3):
+        for img in (src, lo):
+            out = warp_affine(img.to(DEV), Tm, (100, 230), mode).cpu().double()
+            ref = warp_affine_ref(img, Tm, (100, 230), mode)
+            d = (out - ref).abs()
+            if mode == 'nearest':
+                assert float((d > 0).float().mean()) < 2e-3
+            elif img is lo:
+                assert float(d.max()) < 2e-2 and float(d.mean()) < 1e-3, (mode, float(d.max()))
+            else:
+                assert float(d.max()) < 0.25 and float(d.mean()) < 2e-3, (mode, float(d.max()))      # |gradient| up to 255 per pixel
+        u8 = lo.to(torch.uint8)
+        out8 = warp_affine(u8.to(DEV), Tm, (100, 230), mode)
+        assert out8.dtype == torch.uint8
+        ref8 = warp_affine_ref(u8, Tm, (100, 230), mode)
+        d8 = (out8.cpu().int() - ref8.int()).abs()
+        assert int(d8.max()) <= (0 if mode != 'nearest' else 255) + 1 and float((d8 > 0).float().mean()) < 5e-3, (mode, int(d8.max()))
+
+
+def test_warp_mask_batch_against_the_oracle():
+    """The augmenter's candidate test (19 nearest-neighbour label warps + pixel counts in one launch, reference augmenter.py:454-471) vs
+    the oracle's nearest warp of the same mask under each transform."""
+    from oracle.warp_ref import augmenter_like_transforms, warp_affine_ref
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    mask = torch.zeros(1, 120, 214)
+    mask[0, 30:80, 60:150] = 1
+    mask[0, 50:60, 90:110] = 0
+    Ts = augmenter_like_transforms((120, 214), 19, seed=11)
+    labs, counts = ImageAugmenter._warp_masks(mask.to(DEV), Ts, (120, 214))
+    counts = counts.tolist() if torch.is_tensor(counts) else list(counts)
+    for k, Tm in enumerate(Ts):
+        ref = warp_affine_ref(mask, Tm, (120, 214), 'nearest')[0] > 0
+        got = labs[k].reshape(120, 214).cpu() > 0
+        assert float((ref != got).float().mean()) < 2e-3
+        assert abs(int(counts[k]) - int(ref.sum())) <= 0.002 * 120 * 214 + 2
+
+
+def test_g13_fork_solver_on_the_hip_path(golden):
+    """The solver configuration of the reference's YouTube-VOS fork (Fletcher-Reeves, CG state reset at every run; fixture G13 recorded
+    from ytvos_validation/optimizer.py + discriminator.py) on the HIP operators, persistent and multi-kernel form."""
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    T = torch.from_numpy
+    g = golden('g13_ytvos')
+    c, h, w, Hh, Ww, cap = [int(v) for v in g['fr_dims']]
+    for persistent in (True, False):
+        mem = Memory(cap, (c, h, w), (1, Hh, Ww), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
+        mem.samples.copy_(T(g['fr_samples0']))
+        mem.weights.copy_(T(g['fr_sw0']))
+        mem._build_normals(T(g['fr_labels0'][:7]).to(DEV), T(g['fr_pw0'][:7]).to(DEV), 7, None, 0)
+        mem.current_size = 7
+        mem._slot[:1].fill_(6)
+        mem._have_prev = True
+        wv = torch.nn.Parameter(T(g['fr_w0']).clone().to(DEV), requires_grad=False)
+        opt = GaussNewtonCG(DiscriminatorLoss(mem, (1e-2,), (1e-2,), wv), TensorList([wv]), fletcher_reeves=True, standard_alpha=True,
+                            direction_forget_factor=0)
+        opt.persistent = persistent
+        opt.run((10,))
+        errs = [float((wv.cpu() - T(g['fr_filters'][0])).abs().max() / T(g['fr_filters'][0]).abs().max())]
+        for t in range(3):
+            mem.update(T(g['fr_ins_x'][t:t + 1]).to(DEV), T(g['fr_ins_y'][t:t + 1]).to(DEV))
+            assert float((mem.weights.cpu() - T(g['fr_sw'][t + 1])).abs().max()) < 1e-6
+            opt.run((10,))
+            ref = T(g['fr_filters'][t + 1])
+            errs.append(float((wv.cpu() - ref).abs().max() / ref.abs().max()))
+        print('g13 on the HIP path (%s):' % ('persistent' if persistent else 'multi-kernel'), ['%.1e' % e for e in errs])
+        assert errs[0] < 5e-2 and max(errs[1:]) < 1e-3, (persistent, errs)
+
+
+def test_g13_sequence_level_merge_of_the_fork(golden):
+    """Tracker._ytvos_labels (run_sequence(..., ytvos_merge=True)) against labels recorded from the fork's own run_sequence
+    (ytvos_validation/tracker.py:84-116: raw masks kept, ground truth re-inserted on every object's first frame, one merge over the
+    sequence, arg-max through the id table): 2 objects, 3 objects with a late start, 1 object.  Bit-exact label images."""
+    import types
+    from frtm_vos_amd.model.tracker import Tracker
+    T = torch.from_numpy
+    g = golden('g13_ytvos')
+    for tag in ('two', 'late', 'one'):
+        raw, ids, first = T(g['merge_%s_raw' % tag]), [int(v) for v in g['merge_%s_ids' % tag]], [int(v) for v in g['merge_%s_first' % tag]]
+        gt, want = T(g['merge_%s_gt' % tag]), T(g['merge_%s_out' % tag])
+        T_, n, Hh, Ww = raw.shape
+        trk = Tracker.__new__(Tracker)
+        torch.nn.Module.__init__(trk)
+        trk.device = DEV
+        trk.targets = {oid: types.SimpleNamespace(object_id=oid, index=i + 1, start_frame=first[i], discriminator=None,
+                                                  start_mask=(gt[i] == oid).to(torch.uint8).reshape(1, Hh, Ww).to(DEV)) for i, oid in enumerate(ids)}
+        trk._raw_log = []
+        for t in range(1, T_):                                      # frame 0 is never tracked
+            planes = torch.zeros(n + 1, Hh, Ww, device=DEV)
+            planes[1:] = raw[t].to(DEV)
+            trk._raw_log.append((t, planes))
+        seq = types.SimpleNamespace(obj_ids=ids)
+        lut = torch.tensor([0] + ids, dtype=torch.uint8, device=DEV)
+        labels = trk._ytvos_labels(seq, [torch.zeros(1, Hh, Ww)] * T_, lut)
+        got = torch.stack([l.reshape(1, Hh, Ww) for l in labels]).cpu()
+        assert torch.equal(got, want), (tag, float((got != want).float().mean()))
