@@ -368,21 +368,28 @@ def dataset_specs(n_seq, size=(480, 854), seed=2017):
     return [('d%03d' % i, rng.randint(34, 104), objs[i], 500 + i) for i in range(n_seq)]
 
 
-def run_dataset_shard(tracker, specs, size, dev):
-    """The reference's run_dataset loop (model/tracker.py:82-99) over this rank's sequences: per-sequence frames/s as run_sequence reports it
-    (initialize() included), total frames, total seconds, and the update-work counters summed over the sequences."""
+def build_sequences(specs, size):
+    """The synthetic frames of a dataset, generated on the host BEFORE any clock starts (a real dataset lies on disk decoded by the
+    loader; generating textures is not part of the metric)."""
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    return [SyntheticSequence(name, L, size, n_obj, seed=seed) for name, L, n_obj, seed in specs]
+
+
+def run_dataset_shard(tracker, seqs, dev):
+    """The reference's run_dataset loop (model/tracker.py:82-99) over this rank's sequences: sequence.preload(device) + run_sequence per
+    sequence.  Returns the per-sequence frames/s as run_sequence reports them (initialize() included, preload not: tracker.py:130,159-161),
+    total frames, total seconds of the loop (preloads included) and the update-work counters summed over the sequences."""
     fps, frames, agg = [], 0, {}
     t0 = time.time()
-    for name, L, n_obj, seed in specs:
-        seq = SyntheticSequence(name, L, size, n_obj, seed=seed)
-        seq.preload(dev)                                # (like the reference's sequence.preload(device), tracker.py:91: inside the dataset loop)
+    for seq in seqs:
+        seq.preload(dev)                                # (the reference's sequence.preload(device), tracker.py:91: inside the dataset loop)
         out, f = tracker.run_sequence(seq)
         c = path_counters(tracker, seq, len(out))
         for k, v in c.items():
             agg[k] = (agg.get(k, True) and v) if isinstance(v, bool) else agg.get(k, 0) + v
         fps.append(f)
         frames += len(out)
+        seq.release()
     torch.cuda.synchronize()
     return fps, frames, time.time() - t0, agg
 
@@ -592,14 +599,18 @@ def main():
     dev_allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     if args.debug_allocs:
         torch.cuda.memory._record_memory_history(enabled='all', context='alloc', stacks='python')
-    t0 = time.time()
-    shard = None
+    shard, shard_seqs = None, None
     if args.sequences > 0:
         # sharded mode (BASELINE config 4's shape): the dataset is cut over the ranks by cost = frames x objects, longest first
         from frtm_vos_amd.shard import shard_indices
         specs = dataset_specs(args.sequences, size)
         mine = shard_indices(len(specs), rank, world, costs=[L * k for _, L, k, _ in specs])
-        seq_fps, n_shard, _, shard_counters = run_dataset_shard(tracker, [specs[i] for i in mine], size, dev)
+        shard_seqs = build_sequences([specs[i] for i in mine], size)
+        if dist is not None:
+            dist.barrier()
+    t0 = time.time()
+    if shard_seqs is not None:
+        seq_fps, n_shard, _, shard_counters = run_dataset_shard(tracker, shard_seqs, dev)
         shard = dict(sequences=len(mine), sequence_ids=mine, mean_of_per_sequence_fps=sum(seq_fps) / max(len(seq_fps), 1))
         outputs = []
     else:
@@ -745,11 +756,11 @@ def main():
             # the headline above is ONE sequence; this is the dataset-level figure the reference's run_dataset prints (mean of the per-
             # sequence frames/s, model/tracker.py:94,101) over 30 dv2017-like sequences through the same tracker, first-use costs of new
             # shapes included, with the same counters of the update work
-            fps_l, fr, sec, cnt = run_dataset_shard(tracker, dataset_specs(30, size), size, dev)
+            fps_l, fr, sec, cnt = run_dataset_shard(tracker, build_sequences(dataset_specs(30, size), size), dev)
             out['dataset_sim'] = {'sequences': len(fps_l), 'frames': fr, 'mean_of_per_sequence_fps': round(sum(fps_l) / len(fps_l), 1),
                                   'total_fps': round(fr / sec, 1), 'min_sequence_fps': round(min(fps_l), 1), 'max_sequence_fps': round(max(fps_l), 1),
                                   'path_counters': cnt,
-                                  'note': '30 synthetic dv2017val-like sequences (1-5 objects, mean 2.4; 34-104 frames; 480x854), frames pre-loaded per sequence inside the loop like the reference'}
+                                  'note': '30 synthetic dv2017val-like sequences (1-5 objects, mean 2.4; 34-104 frames; 480x854); total_fps = frames / wall of the loop incl. the host->device preload of every sequence (pageable memory) and the counter read-backs; mean_of_per_sequence_fps is what the reference prints'}
             _phase('dataset leg done')
         if not args.no_cg_roofline:
             out['roofline_cg'] = cg_roofline(dev, size)

@@ -31,6 +31,7 @@ SIGNATURES = {
     'frtm_stencil': (I, [P, P, P, P, I, I, I, P, P]),
     'frtm_filter_wgrad': (I, [P, P, I, I, I, I, I, P, P]),
     'frtm_filter_wgrad_parts': (I, [I, I]),
+    'frtm_filter_wgrad_parts_hw': (I, [I, I, I]),
     'frtm_filter_wgrad_stencil': (I, [P, P, P, P, P, I, I, I, I, P, P]),
     'frtm_filter_igrad': (I, [P, P, I, I, I, I, P, I, P]),
     'frtm_vec_reduce_slabs': (I, [P, I, I, I, F, P, F, P, P]),

@@ -1062,6 +1062,17 @@ int frtm_filter_wgrad_parts(int N, int C) {
   return max(1, min(8, 256 / max(blocks, 1)));
 }
 
+// The same with the map size taken into account: on large maps (720p: 3600, 1080p: 8160 pixels) a wave that walks a whole map for its 4
+// channels is a long chain of 4 KB load groups, and C/16 x N blocks (320 for the raw features of a first-frame fit) put about one wave
+// on every SIMD; cutting the pixels into parts keeps several waves per SIMD streaming (1080p, 5 x 1024 channels: 47 -> us per call,
+// profiles/r03_config5_*).  Each part re-stages the t map in LDS (34 KB at 1080p, from L2).
+int frtm_filter_wgrad_parts_hw(int N, int C, int hw) {
+  const int blocks = ceil_div(C, 4 * WG_CH) * N;
+  if (hw < 3000) return frtm_filter_wgrad_parts(N, C);
+  const int per_min = 1536;                                   // pixels per part at least (24 trips of 64 lanes)
+  return max(1, min(min(8, hw / per_min), ceil_div(1536, max(blocks, 1))));
+}
+
 int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, int parts, float* partial, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && t && partial && N > 0 && C > 0 && parts >= 1 && parts <= 64, "frtm_filter_wgrad: bad argument");
   const size_t lds = (size_t)(h + 2) * (w + 2) * sizeof(float);

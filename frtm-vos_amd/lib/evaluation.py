@@ -16,18 +16,8 @@ def evaluate_sequence(pred_labels, gt_labels, obj_ids, measure='J', skip_first_l
     return out
 
 
-def evaluate_dataset(dset, results_path=None, measure='J', to_file=True):
-    """Two call forms:
-      evaluate_dataset(dset, results_path, measure='J', to_file=True)   the reference's (lib/evaluation.py:9-85; driver:
-          evaluate.py:159-165): ``dset`` yields sequences with .name / .annos / .obj_ids / .start_frames / .merge_objects, the
-          tracker's PNGs are read from results_path/<sequence>/<frame>.png, per-sequence lines and the final
-          "<measure>: mean, recall, decay" line go to stdout and results_path/evaluation-<measure>.txt.  Returns the summary dict.
-      evaluate_dataset(results, measure)   in-memory: iterable of (name, pred_labels, gt_labels, obj_ids)."""
-    if results_path is not None and not isinstance(results_path, str) or hasattr(dset, 'name'):
-        return _evaluate_dataset_files(dset, results_path, measure, to_file)
-    if isinstance(results_path, str) and results_path in ('J', 'F'):
-        measure = results_path
-    results = dset
+def evaluate_results(results, measure='J'):
+    """In-memory form: ``results`` = iterable of (name, pred_labels, gt_labels, obj_ids); returns dict(measure, mean, per_sequence)."""
     per_seq, all_means = {}, []
     for name, pred, gt, ids in results:
         vals = evaluate_sequence(pred, gt, ids, measure)
@@ -36,6 +26,25 @@ def evaluate_dataset(dset, results_path=None, measure='J', to_file=True):
         all_means.extend(s[0] for s in stats.values())
     m = float(np.nanmean(all_means)) if all_means else float('nan')
     return dict(measure=measure, mean=m, per_sequence=per_seq)
+
+
+def evaluate_dataset(dset, results_path=None, measure='J', to_file=True):
+    """The reference's call (lib/evaluation.py:9-85; driver: evaluate.py:159-165): ``dset`` yields sequences with .name / .annos /
+    .obj_ids / .start_frames / .merge_objects, the tracker's PNGs are read from ``results_path``/<sequence>/<frame>.png (a Path or a
+    str), per-sequence lines and the final "<measure>: mean, recall, decay" line go to stdout and results_path/evaluation-<measure>.txt.
+    Returns the summary dict.  Results held in memory go through ``evaluate_results``; for backward compatibility
+    ``evaluate_dataset(results)`` / ``evaluate_dataset(results, 'J')`` with a list of tuples still dispatches there -- decided by the
+    TYPE of the first argument, never by what results_path looks like (round-2 ADVICE)."""
+    in_memory = isinstance(dset, (list, tuple)) and (len(dset) == 0 or isinstance(dset[0], (list, tuple)))
+    if in_memory:
+        if isinstance(results_path, str) and results_path in ('J', 'F'):
+            measure = results_path
+        elif results_path is not None:
+            raise TypeError('evaluate_dataset(results, ...): in-memory results take no results_path (got %r)' % (results_path,))
+        return evaluate_results(dset, measure)
+    if results_path is None:
+        raise TypeError('evaluate_dataset(dset, results_path, measure): results_path (directory of the PNGs) is required for a dataset object')
+    return _evaluate_dataset_files(dset, results_path, measure, to_file)
 
 
 def j_and_f(pred_labels, gt_labels, obj_ids):

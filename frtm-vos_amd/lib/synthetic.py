@@ -52,15 +52,22 @@ class SyntheticSequence:
         self.images = frames
         self.gt = labels
         self.device = device
+        self._host = None
 
     def preload(self, device):
+        if torch.device(device).type != 'cpu' and self._host is None:
+            self._host = (self.images, self.gt)                 # the host copies stay: release() only drops the device copies
         self.images = [im.to(device) for im in self.images]
         self.gt = [lb.to(device) for lb in self.gt]
         self.device = device
 
     def release(self):
-        """Counterpart of FileSequence.release: frames go back to host memory."""
-        self.preload('cpu')
+        """Counterpart of FileSequence.release: the device copies are dropped, the frames are host tensors again (no copy back)."""
+        if self._host is not None:
+            self.images, self.gt = self._host
+            self._host, self.device = None, 'cpu'
+        else:
+            self.preload('cpu')
 
     def __len__(self):
         return len(self.images)

@@ -89,7 +89,11 @@ class DiscriminatorLoss(MinimizationProblem):
             self._xt_for = None
             self.Kp = torch.empty(C * 9, device=dev)                 # composed 3x3 kernel over the raw features
             self.partialX = torch.empty(cap * 8, C * 9, device=dev)  # per-sample slabs of the raw features' 3x3 weight gradient
-            self.CS = 8                                              # channel groups of the composed score pass over the raw features
+            # channel groups of the composed score pass over the raw features: enough blocks to fill the chip (480p: 10 row blocks x 5
+            # samples -> 8 groups), but not more -- every group is one more partial map, and a wave should walk as many channels as it
+            # can (720p: 3 groups, 1080p: 2)
+            row_blocks = ((h + 2) // 3) * ((w + 63) // 64)
+            self.CS = max(1, min(8, round(450.0 / max(1, row_blocks * 5))))
             self._sp_all = torch.empty((self.CS + 1) * cap * self.hw, device=dev)   # their partial score maps (+ one for the filter-direction term)
 
     def rebind(self, filter_regs, precond, filter_weight, project_weight=None):
@@ -134,7 +138,7 @@ class DiscriminatorLoss(MinimizationProblem):
                H.ptr(self.s), self.N, self.h, self.w, H.ptr(self.t))
 
     def _filter_grad(self, feats, lam2, pvec, sign, out):
-        parts = H.lib().frtm_filter_wgrad_parts(self.N, self.c)
+        parts = H.lib().frtm_filter_wgrad_parts_hw(self.N, self.c, self.hw)
         H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
         H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N * parts, self.c * 9, self.c * 9, lam2, pvec, sign, out)
 
@@ -145,7 +149,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return None
         ops.filter_scores(self.mem.samples, p, out=self.s, n=self.N)
         self._stencil(False)          # separate 4.6 us kernel: fusing it into the weight-gradient kernel measured slower (+8 us)
-        parts = H.lib().frtm_filter_wgrad_parts(self.N, self.c)
+        parts = H.lib().frtm_filter_wgrad_parts_hw(self.N, self.c, self.hw)
         H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
         return self.partial, self.N * parts, self.c * 9, self.filter_regs[0] ** 2
 
@@ -179,8 +183,8 @@ class DiscriminatorLoss(MinimizationProblem):
         """The two 3x3 weight gradients against t (raw features: Cin x 9 slabs, projected features: c x 9 slabs), then q = sign *
         [ expand(raw slabs) through w2 + lam1 p1 | projected slabs + lam2 p2 ] and the partials of <p,q> (and <p,r>)."""
         N, c = self.N, self.c
-        px = H.lib().frtm_filter_wgrad_parts(N, self.Cin)
-        pz = H.lib().frtm_filter_wgrad_parts(N, c)
+        px = H.lib().frtm_filter_wgrad_parts_hw(N, self.Cin, self.hw)
+        pz = H.lib().frtm_filter_wgrad_parts_hw(N, c, self.hw)
         H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), N, self.Cin, self.h, self.w, px, H.ptr(self.partialX))
         H.call('frtm_filter_wgrad', H.ptr(self.Z), H.ptr(self.t), N, c, self.h, self.w, pz, H.ptr(self.partial))
         H.call('frtm_joint_q_pq_composed', H.ptr(self.partialX), N * px, self.Cin, c, H.ptr(self.w2.data), self.filter_regs[0] ** 2,
@@ -271,7 +275,7 @@ class DiscriminatorLoss(MinimizationProblem):
         """stencil + weight-gradient slabs + input gradient (one launch), the K = N*h*w GEMM, then q / <p,q> (one launch)."""
         m, N, c = self.mem, self.N, self.c
         n1 = self.Cin * c
-        parts = H.lib().frtm_filter_wgrad_parts(N, c)
+        parts = H.lib().frtm_filter_wgrad_parts_hw(N, c, self.hw)
         H.call('frtm_joint_mid', H.ptr(self.s), H.ptr(m.normal_B), H.ptr(m.normal_c) if with_c else None, H.ptr(m.weights), H.ptr(self.Z),
                H.ptr(self.w2.data), N, c, self.h, self.w, parts, H.ptr(self.partial), H.ptr(self.D))
         ops.conv2d(self.Xt, self.D, c, out=self.g1, out_transposed=True, shape=(1, N * self.hw, 1, self.Cin), w_pitch=c, ws=self.ws)

@@ -12,7 +12,7 @@ full-resolution tensor.  Sample weights live on the device and the replacement i
 comes back to the host (``frtm_memory_next_slot``): no ``.item()`` sync (reference memory.py:80-81).
 
 ``keep_hires=True`` additionally stores ``labels`` / ``pixel_weights`` like the reference
-(debugging / API completeness; not read by the solver); without it the two attributes are allocated on first access.
+(debugging / API completeness; not read by the solver); without it reading the two attributes raises.
 """
 import torch
 
@@ -64,18 +64,20 @@ class Memory:
 
     @property
     def labels(self):
-        """Full-resolution label maps like the reference's Memory.labels (memory.py:15).  The solver only needs their
-        low-resolution normal form, so without ``keep_hires=True`` the buffers do not exist until somebody asks: the first access
-        allocates them and switches recording on -- samples stored BEFORE that moment read as zeros (their maps were never kept)."""
+        """Full-resolution label maps like the reference's Memory.labels (memory.py:15).  The solver only needs their low-resolution
+        normal form, so they exist only in a memory constructed with ``keep_hires=True`` (Discriminator(..., keep_hires=True)).
+        Reading the attribute never changes the memory's state (round-2 ADVICE: a debug read used to switch recording on, which
+        silently took the window-insert path away and re-allocated the memory on recycle)."""
         if self._labels is None:
-            self._alloc_hires()
+            raise AttributeError('Memory.labels: the full-resolution maps are not recorded (only their low-resolution normal equations '
+                                 'normal_B / normal_c are); construct the memory with keep_hires=True to keep them')
         return self._labels
 
     @property
     def pixel_weights(self):
-        """Full-resolution pixel-weight maps (reference memory.py:16); allocated lazily like ``labels``."""
+        """Full-resolution pixel-weight maps (reference memory.py:16); like ``labels`` only with keep_hires=True."""
         if self._pixel_weights is None:
-            self._alloc_hires()
+            raise AttributeError('Memory.pixel_weights: not recorded; construct the memory with keep_hires=True')
         return self._pixel_weights
 
     @classmethod

@@ -100,6 +100,8 @@ int frtm_stencil(const float* B, const float* c, const float* sw, const float* s
 int frtm_filter_wgrad(const float* X, const float* t, int N, int C, int h, int w, int parts,
                       float* partial, frtm_stream_t stream);
 int frtm_filter_wgrad_parts(int N, int C);
+/* ... with the number of pixels of a map taken into account (large maps are cut into more parts). */
+int frtm_filter_wgrad_parts_hw(int N, int C, int hw);
 
 /* The same with the stencil fused in: t = sw * (B s - c) is formed inside the kernel from the scores s (c may be NULL). */
 int frtm_filter_wgrad_stencil(const float* X, const float* s, const float* B, const float* c, const float* sw,

@@ -250,7 +250,7 @@ def test_reference_signature_of_discriminator_loss_and_aliasing(golden):
         DiscriminatorLoss(xr, y[:5], (1e-2,), (1e-2,), sw5, torch.nn.Conv2d(16, 1, 3, padding=1).to(DEV), pw[:5])     # bias
 
 
-def test_memory_hires_maps_are_lazy_and_refiner_never_falls_back_silently():
+def test_memory_hires_maps_need_keep_hires_and_refiner_never_falls_back_silently():
     from frtm_vos_amd.model.memory import Memory
     from frtm_vos_amd.model.seg_network import SegNetwork
     m = Memory(6, (4, 6, 9), (1, 48, 70), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
@@ -258,8 +258,12 @@ def test_memory_hires_maps_are_lazy_and_refiner_never_falls_back_silently():
     lab = torch.zeros(3, 1, 48, 70, device=DEV)
     lab[:, :, 10:30, 20:50] = 1
     m.initialize(torch.zeros(3, 4, 6, 9, device=DEV), lab)
-    assert m.labels.shape == (6, 1, 48, 70) and m.keep_hires            # first access allocates and switches recording on
-    assert float(m.labels.abs().max()) == 0.0                            # earlier samples were never kept at full resolution
+    with pytest.raises(AttributeError, match='keep_hires'):              # a read must not change the memory's state (round-2 ADVICE)
+        m.labels
+    assert m.keep_hires is False and m._labels is None and m.matches(6, (4, 6, 9), (1, 48, 70))
+    m = Memory(6, (4, 6, 9), (1, 48, 70), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1), keep_hires=True)
+    m.initialize(torch.zeros(3, 4, 6, 9, device=DEV), lab)
+    assert m.labels.shape == (6, 1, 48, 70) and float(m.labels[:3].max()) == 1.0
     m.update(torch.ones(1, 4, 6, 9, device=DEV), lab[:1] * 0.9)
     assert abs(float(m.labels[3].max()) - 0.9) < 1e-6 and float(m.pixel_weights[3].min()) > 0
     chans = {'layer5': 32, 'layer4': 16, 'layer3': 8, 'layer2': 8}
