@@ -32,6 +32,20 @@ def _bicubic_phase(d):
     return torch.where(x < 1, near, torch.where(x < 2, far, torch.zeros_like(x)))
 
 
+_SIDE = {}
+
+
+def _shared_side_stream(dev):
+    """ONE side stream per device for the refiners of a process.  torch.cuda.Stream() hands out the 32 streams of its pool round-robin;
+    refiners that each took the next one left hipGraphs behind that had been captured across ever different stream pairs, and the HIP
+    runtime crashed (segfault inside hipGraphLaunch) at the 161st refiner of a process that also destroyed earlier ones
+    (tools/graph_stress.py).  Refiner graphs of one process never run concurrently, so they can share the side stream."""
+    key = torch.device(dev).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 class PyrUpBicubic2d(nn.Module):
     """2x polyphase bicubic up-sampling with replicate border (reference seg_network.py:75-126),
     applied separably: rows then columns, even/odd phase interleaved."""
@@ -204,7 +218,7 @@ class SegNetwork(nn.Module):
             # ONE side stream carries all deep levels (two parallel graph branches).  A stream per level measured slower
             # and bimodal on MI355X (1.25-1.31 ms vs 1.22 ms serial; this form 1.15 ms, stable).
             dev = next(self.parameters()).device
-            self._side = [torch.cuda.Stream(device=dev)] * (len(self.ft_channels) - 1)
+            self._side = [_shared_side_stream(dev)] * (len(self.ft_channels) - 1)
         return self._side
 
     def _forward_graphed(self, scores, features, image_size):
@@ -241,7 +255,7 @@ class SegNetwork(nn.Module):
             # concurrently and each output is consumed before the next replay, so the pool is as large as the largest graph
             with H.capture(g, pool=self._pool):
                 out = self._forward_hip(static_scores, features, image_size, self._side if self.parallel_levels else None)
-            entry = (g, static_scores, out, [features[L] for L in self.ft_channels])
+            entry = (g, static_scores, out, [features[L] for L in self.ft_channels] + list(self._capture_events))
         self._graphs[key] = entry                                            # (re-)insert as most recently used
         g, static_scores, out, _keepalive = entry
         static_scores.copy_(scores)
@@ -350,8 +364,19 @@ class SegNetwork(nn.Module):
         levels = list(self.ft_channels)
         cur = torch.cuda.current_stream()
         keep, br = [], {}
+        # Fork / join through events that LIVE AS LONG AS THE CAPTURED GRAPH (the caller keeps self._capture_events with the graph):
+        # stream.wait_stream() makes a temporary event and destroys it right away, and a hipGraph captured across such an event crashed
+        # a later capture / replay in processes that create and destroy many refiners (segfault inside hipGraphLaunch; reproducer:
+        # tools/graph_stress.py, deterministic at its 161st network with parallel levels, never without them).
+        self._capture_events = []
+
+        def order(waiter, waited):
+            ev = torch.cuda.Event()
+            ev.record(waited)
+            waiter.wait_event(ev)
+            self._capture_events.append(ev)
         for st in set(side_streams or []):
-            st.wait_stream(cur)                                 # fork point: everything enqueued so far (scores, taps)
+            order(st, cur)                                      # fork point: everything enqueued so far (scores, taps)
         for i, L in enumerate(levels):
             ft = features[L].contiguous()
             st = side_streams[i] if (side_streams and i < len(side_streams)) else None
@@ -365,7 +390,7 @@ class SegNetwork(nn.Module):
             p = P[L]
             st = side_streams[i] if (side_streams and i < len(side_streams)) else None
             if st is not None:
-                cur.wait_stream(st)
+                order(cur, st)
             r, sp, _, tmp = br[L]
             keep.append(tmp)
             Hh, Ww = r.shape[-2:]

@@ -33,6 +33,21 @@ from ..lib.utils import AverageMeter
 from .discriminator import Discriminator
 
 
+_STREAMS = {}
+
+
+def _process_stream(device, role):
+    """Side streams are shared by all trackers of a process (one per device and role: 'main', 'first', 'init0'..).  A tracker that took
+    fresh streams from torch's 32-stream pool for itself left hipGraphs behind that had been captured on ever different streams, and the
+    HIP runtime crashed inside hipGraphLaunch once the pool had wrapped around a few times in a process that creates and destroys many
+    trackers / refiners (the test suite; reproducer tools/graph_stress.py).  Trackers of one process do not run concurrently (one host
+    thread drives them), so they can share."""
+    key = (torch.device(device).index, role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
 class FrameTaps(dict):
     """Backbone taps of one frame ({layer: (1,C,H,W)}) that remember the trunk batch they are a slice of, so that consecutive
     frames can be handed on as one window without copying."""
@@ -128,13 +143,13 @@ class Tracker(nn.Module):
 
     def _first_pass_stream(self):
         if self._first_stream is None:
-            self._first_stream = torch.cuda.Stream(device=self.device)
+            self._first_stream = _process_stream(self.device, 'first')
         return self._first_stream
 
     def _init_streams(self, n):
         while len(self._init_pool) < n:
             # (default priority: high-priority streams measured 2.4x SLOWER for these chains on MI355X / ROCm 7.2: 41 vs 17 ms)
-            self._init_pool.append(torch.cuda.Stream(device=self.device))
+            self._init_pool.append(_process_stream(self.device, 'init%d' % len(self._init_pool)))
         return self._init_pool[:n]
 
     def clear(self):
@@ -204,7 +219,7 @@ class Tracker(nn.Module):
         if cur is None or cur != torch.cuda.default_stream(self.device) or not self.own_stream:
             return self._run_sequence(sequence, speedrun, ytvos_merge)
         if self._main_stream is None:
-            self._main_stream = torch.cuda.Stream(device=self.device)
+            self._main_stream = _process_stream(self.device, 'main')
         self._main_stream.wait_stream(cur)
         with torch.cuda.stream(self._main_stream):
             out = self._run_sequence(sequence, speedrun, ytvos_merge)
@@ -390,7 +405,7 @@ class Tracker(nn.Module):
         if pipelined:
             side = self._first_pass_stream()
         elif persistent and self.prefetch_stream and torch.cuda.is_available():
-            side = torch.cuda.Stream(device=self.device)
+            side = _process_stream(self.device, 'prefetch')
         # trunk batches [first, last) over the tracked frames 1..; pipelined: a short first batch (it has to be through the trunk
         # before initialize()'s own pass can start)
         n_tracked = len(frames) - 1

@@ -315,3 +315,15 @@ def test_g13_sequence_level_merge_of_the_fork(golden):
         labels = trk._ytvos_labels(seq, [torch.zeros(1, Hh, Ww)] * T_, lut)
         got = torch.stack([l.reshape(1, Hh, Ww) for l in labels]).cpu()
         assert torch.equal(got, want), (tag, float((got != want).float().mean()))
+
+
+def test_many_refiners_with_parallel_graph_branches_in_one_process():
+    """tools/graph_stress.py: 200 refiners created, captured (two parallel graph branches), replayed and dropped in one process, some kept
+    alive for a while.  With a side stream of its own per refiner (torch hands out its 32 pool streams round-robin) the HIP runtime
+    segfaulted inside hipGraphLaunch at the 161st refiner, deterministically; refiners (and trackers) of a process now share their side
+    streams.  In a subprocess, so that a crash fails this test instead of the session."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'graph_stress.py'), '200', '1'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'DONE 200' in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
