@@ -45,7 +45,7 @@ SIGNATURES = {
     'frtm_joint_q_pq': (I, [P, I, F, P, I, I, I, F, P, P, F, P, P, P, P]),
     'frtm_cg_persistent_plan': (I, [I, I, I, I, P, P]),
     'frtm_cg_run_persistent': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P]),
-    'frtm_cg_run_persistent_guarded': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P, I, P, I, I, P]),
+    'frtm_cg_run_persistent_guarded': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P, I, P, I, I, P, P]),
     'frtm_guarded_copy': (I, [P, P, I, P, I, I, P, I, P]),
     'frtm_filter_scores_split': (I, [P, P, I, I, I, I, I, P, P]),
     'frtm_stencil_sum': (I, [P, P, P, P, I, I, I, I, P, P]),

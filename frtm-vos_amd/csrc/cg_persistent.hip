@@ -39,7 +39,7 @@ constexpr int NMAX = CPW * NWAVE * 9;      // 864
 
 struct Params {
   const float* X; const float* Bm; const float* cm; const float* sw;
-  float* w2; float* vec; float* state; float* slabs; float* qbuf; unsigned* bar;
+  float* w2; float* vec; float* state; float* slabs; float* qbuf; unsigned* bar; unsigned* hbar;
   int N, c, h, w, R, parts, iters, has_p, apply_dff, fr, std_alpha, parity;
   float dff, lam2, invM, step;
   const int* guard; int guard_min; unsigned* stats;     // optional device-side early-out and its counters (see the guarded entry)
@@ -70,6 +70,46 @@ __device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_fla
           __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
+      }
+    }
+    *sh_flag = ok;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+// XCD-hierarchical form of the barrier (guide: "barrier-xcd").  A flat barrier serialises 240 agent-scope atomics on ONE address and
+// has 240 pollers on it; here the workgroups of an XCD (30 of them) arrive on their XCD's counter, the LAST arriver of each XCD
+// arrives on the top counter and polls it (8 arrivals, 8 pollers), then publishes the epoch in its XCD's generation word, which the
+// other workgroups of that XCD poll.  Which XCD a workgroup runs on is read from the hardware (HW_REG_XCC_ID), never assumed: the
+// per-XCD populations are counted at kernel start, behind the first (flat) barrier.  hbar layout (unsigned words, 16-word = 64-byte
+// pitch so that no two polled words share a line): [16 x] arrivals, [128 + 16 x] generation, [256] top, [272 + x] population.
+constexpr int HB_ARR = 0, HB_GEN = 128, HB_TOP = 256, HB_POP = 272, HB_WORDS = 288;
+__device__ __forceinline__ bool hier_sync(unsigned* hbar, unsigned* abort_flag, unsigned* stats, int xcc, unsigned n_x, unsigned n_active,
+                                          unsigned epoch, long long limit, int* sh_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores of the phase have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    auto give_up = [&]() {
+      if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
+        __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const unsigned old = __hip_atomic_fetch_add(hbar + HB_ARR + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == epoch * n_x) {                      // last arriver of this XCD: speaks for it at the top level
+      __hip_atomic_fetch_add(hbar + HB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(hbar + HB_TOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * n_active) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
+      }
+      if (ok) __hip_atomic_store(hbar + HB_GEN + 16 * xcc, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(hbar + HB_GEN + 16 * xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
       }
     }
     *sh_flag = ok;
@@ -119,7 +159,7 @@ constexpr int L_S = L_C + RMAX * 64;                  // [SR][PW]
 constexpr int L_T = L_S + SR * PW;                    // [RMAX][PW]
 constexpr int L_RED = L_T + RMAX * PW;                // [NWAVE][SR][64]
 constexpr int L_SRED = L_RED + NWAVE * SR * 64;       // 32
-constexpr int L_FLAG = L_SRED + 32;                   // 1 int
+constexpr int L_FLAG = L_SRED + 32;                   // 1 int (+ 3 ints: xcc id, workgroups on this XCD, populated XCDs)
 constexpr int L_TOTAL = L_FLAG + 4;
 
 __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
@@ -191,6 +231,33 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
     vb[i] = vr[i] = vq[i] = vx[i] = 0.f;
   }
   const float swn = P.sw[n_s];
+  // ---- which XCD am I on, and how many workgroups does each XCD hold?  (registration, then ONE flat barrier) ----
+  bool hier = P.hbar != nullptr;
+  int xcc = 0; unsigned n_x = 1, n_active = 1, hepoch = 0;
+  if (hier) {
+    if (tid == 0) {
+      const int x = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);          // HW_REG_XCC_ID, bits [3:0]
+      sh_flag_p[1] = x;
+      __hip_atomic_fetch_add(P.hbar + HB_POP + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) { leave(); return; }
+    if (tid == 0) {
+      unsigned act = 0, mine = 0;
+      for (int x = 0; x < 8; ++x) {
+        const unsigned c_ = __hip_atomic_load(P.hbar + HB_POP + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        act += c_ > 0u ? 1u : 0u;
+        if (x == sh_flag_p[1]) mine = c_;
+      }
+      sh_flag_p[2] = (int)mine; sh_flag_p[3] = (int)act;
+    }
+    __syncthreads();
+    xcc = sh_flag_p[1]; n_x = (unsigned)sh_flag_p[2]; n_active = (unsigned)sh_flag_p[3];
+  }
+  auto gsync = [&]() -> bool {
+    if (hier) return hier_sync(P.hbar, abort_flag, P.stats, xcc, n_x, n_active, ++hepoch, P.spin_limit, sh_flag_p);
+    return grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p);
+  };
   __syncthreads();
   stamp();
 
@@ -275,7 +342,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
     float* slab = P.slabs + (size_t)g * NMAX;
     for (int i = tid; i < NMAX; i += NT) st_wt(slab + i, gl[i]);
     stamp();
-    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) return false;
+    if (!gsync()) return false;
     stamp();
     // distributed fixed-order sum: workgroup g owns the elements [g * epw, (g + 1) * epw), one wave per element
     const int epw = (n + G - 1) / G;
@@ -289,7 +356,7 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
       }
     }
     stamp();
-    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) return false;
+    if (!gsync()) return false;
     stamp();
     for (int i = tid; i < NMAX; i += NT) vq[i] = i < n ? ld_l2(P.qbuf + i) + P.lam2 * v[i] : 0.f;        // (gl aliases vq: its stores are long done)
     __syncthreads();
@@ -416,7 +483,7 @@ int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float*
                                    float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
                                    int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                                    float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
-                                   int count_run, int debug_abort, frtm_stream_t stream) {
+                                   int count_run, int debug_abort, unsigned* hbar, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && Bm && cm && sw && w2 && vec && state && slabs && qbuf && bar && iters >= 0, "frtm_cg_run_persistent: bad argument");
   int parts = 0, R = 0;
   const int G = frtm_cg_persistent_plan(N, c, h, w, &parts, &R);
@@ -425,7 +492,7 @@ int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float*
   P.X = X; P.Bm = Bm; P.cm = cm; P.sw = sw; P.w2 = w2; P.vec = vec; P.state = state; P.slabs = slabs; P.qbuf = qbuf; P.bar = bar;
   P.N = N; P.c = c; P.h = h; P.w = w; P.R = R; P.parts = parts; P.iters = iters; P.has_p = has_p; P.apply_dff = apply_dff;
   P.fr = fletcher_reeves; P.std_alpha = standard_alpha; P.parity = 0; P.dff = dff; P.lam2 = lam2; P.invM = invM; P.step = step;
-  P.guard = guard_count; P.guard_min = guard_min; P.stats = stats; P.count_run = count_run;
+  P.guard = guard_count; P.guard_min = guard_min; P.stats = stats; P.count_run = count_run; P.hbar = hbar;
   P.spin_limit = debug_abort ? 0LL : 400000LL;          // (debug_abort: the first workgroup to wait gives up at once -- tests of the fallback)
   static bool attr_set = false;
   if (!attr_set) {
@@ -435,6 +502,7 @@ int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float*
   // every polled word starts at zero in EVERY launch (a memset node: also when the launch is replayed from a hipGraph); bar[3] is the
   // phase-stamp switch of tools/cg_phase_times.py and is left alone
   FRTM_HIP(hipMemsetAsync(bar, 0, 3 * sizeof(unsigned), (hipStream_t)stream));
+  if (hbar) FRTM_HIP(hipMemsetAsync(hbar, 0, HB_WORDS * sizeof(unsigned), (hipStream_t)stream));
   k_cg_run_persistent<<<G, NT, L_TOTAL * 4, (hipStream_t)stream>>>(P);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
@@ -445,7 +513,7 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
                            int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                            float lam2, float invM, float step, frtm_stream_t stream) {
   return frtm_cg_run_persistent_guarded(X, Bm, cm, sw, N, c, h, w, w2, vec, state, slabs, qbuf, bar, iters, has_p, apply_dff, fletcher_reeves,
-                                        standard_alpha, dff, lam2, invM, step, nullptr, 0, nullptr, 0, 0, stream);
+                                        standard_alpha, dff, lam2, invM, step, nullptr, 0, nullptr, 0, 0, nullptr, stream);
 }
 
 }  // extern "C"

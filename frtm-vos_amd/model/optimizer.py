@@ -209,6 +209,7 @@ class GaussNewtonCG:
             H.call('frtm_guarded_copy', H.ptr(v.data), self._shadow.data_ptr() + 4 * o, v.numel(), guard.data_ptr(), guard_min, 1, None, 0)
             o += v.numel()
 
+    hierarchical_barrier = True     # persistent launches: XCD-hierarchical grid barrier (False: one flat counter)
     persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
 
     def _persistent_plan(self):
@@ -224,8 +225,9 @@ class GaussNewtonCG:
         """linearize + run_CG + apply_step of run_GN_iter in ONE launch; host-side bookkeeping as in run_CG."""
         if self._pbuf is None:
             dev = self._buf.device
-            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev))
-        slabs, qbuf, bar = self._pbuf
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
+                          torch.zeros(288, dtype=torch.int32, device=dev))
+        slabs, qbuf, bar, hbar = self._pbuf
         stats = self._stats()
         guard, guard_min = self._guard if getattr(self, '_guard', None) is not None else (None, 0)
         dff = float(self.direction_forget_factor)
@@ -237,7 +239,8 @@ class GaussNewtonCG:
                int(num_cg_iter), int(self._has_p), int(self._has_p and dff != 0), int(self.fletcher_reeves), int(self.standard_alpha),
                dff if dff != 0 else 1.0, float(a['lam2']), 1.0 / m1, float(self.step_alpha),
                None if guard is None else guard.data_ptr(), guard_min, H.ptr(stats),
-               int(guard is not None and getattr(self, '_last_of_run', True)), int(bool(self.debug_abort)))
+               int(guard is not None and getattr(self, '_last_of_run', True)), int(bool(self.debug_abort)),
+               H.ptr(hbar) if self.hierarchical_barrier else None)
         self._has_p = True
         self._persistent_launched = True
         if not torch.cuda.is_current_stream_capturing():

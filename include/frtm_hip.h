@@ -191,12 +191,13 @@ int frtm_cg_run_persistent(const float* X, const float* Bm, const float* cm, con
  * the DEVICE: guard_count (device int32, e.g. one element of frtm_count_above's output) < guard_min -> the launch returns without
  * touching anything.  stats (device unsigned[4], optional): with count_run != 0, [0] += 1 per completed launch, [1] += 1 per guarded
  * early-out; [2] += 1 per ABORTED launch (always).  debug_abort != 0 forces the time-out (tests of the caller's fallback).  The host
- * never waits for the pixel count, so a tracking loop enqueues whole sequences without a device->host read. */
+ * never waits for the pixel count, so a tracking loop enqueues whole sequences without a device->host read.
+ * hbar (device unsigned[288], optional): state of the XCD-hierarchical grid barrier (zeroed by the launch); NULL: flat barrier. */
 int frtm_cg_run_persistent_guarded(const float* X, const float* Bm, const float* cm, const float* sw, int N, int c, int h, int w,
                                    float* w2, float* vec, float* state, float* slabs, float* qbuf, unsigned* bar,
                                    int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff,
                                    float lam2, float invM, float step, const int* guard_count, int guard_min, unsigned* stats,
-                                   int count_run, int debug_abort, frtm_stream_t stream);
+                                   int count_run, int debug_abort, unsigned* hbar, frtm_stream_t stream);
 /* The same early-out for solves that run as a CHAIN of launches (maps wider than 64 columns, memories beyond the resident budget,
  * the fallback after an aborted persistent launch): the caller snapshots the solver's device state before the chain
  * (mode 0: dst <- src, n floats) and rolls it back after it when the guard says the update should not have happened
