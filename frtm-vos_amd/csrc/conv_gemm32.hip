@@ -18,6 +18,7 @@
 //    shift, residual (dwordx4 read) and ReLU are applied on the way out.
 // Exact fp32 like the 16x16x4 form (an fmaf chain per output); only the summation ORDER over k differs from k_conv_igemm (k pairs
 // (2s, 2s+1) per instruction instead of quadruples), i.e. results agree to rounding.
+#include <algorithm>
 #include <cstdlib>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
@@ -106,10 +107,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv1x1_g32(const ConvParams
   const int lk = lane >> 5, li = lane & 31;
   int cur = 0;
   for (int kc = 0; kc < nch; ++kc) {
-    if (ST == 3) { if (kc + 2 < nch) gload(kc + 2, cur >= 1 ? cur - 1 : 2); }
-    else if (kc + 1 < nch) gload(kc + 1, cur ^ 1);
-    const float* As = smem + cur * STAGE + lk * BM + wm * TM + FM * li;
-    const float* Bs = smem + cur * STAGE + GK * BM + lk * BN + wn * TN + FN * li;
+    if (!(ABL & 4)) {                                       // (ABL bit 2: no global loads after chunk 0 -- what do the loads cost the loop?)
+      if (ST == 3) { if (kc + 2 < nch) gload(kc + 2, cur >= 1 ? cur - 1 : 2); }
+      else if (kc + 1 < nch) gload(kc + 1, cur ^ 1);
+    }
+    const int rs = (ABL & 4) ? 0 : cur;
+    const float* As = smem + rs * STAGE + lk * BM + wm * TM + FM * li;
+    const float* Bs = smem + rs * STAGE + GK * BM + lk * BN + wn * TN + FN * li;
     float a[2][FM], b[2][FN];
     auto frag = [&](int s, float* af, float* bf) {
       if (FM == 2) { const f32x2 v = *(const f32x2*)(As + 2 * s * BM); af[0] = v[0]; af[1] = v[1]; }
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv1x1_g32(const ConvParams
       __builtin_amdgcn_s_waitcnt(0x0F70);                   // the next chunk's loads of this wave have landed
       cur ^= 1;
     }
-    __syncthreads();                                        // ... everybody's have, and everybody is done reading the old `cur`
+    if (!(ABL & 8)) __syncthreads();                        // ... everybody's have, and everybody is done reading the old `cur`  (ABL bit 3: no barrier)
   }
 
   // ---- epilogue: accumulators -> LDS tile (C/D layout of the 32x32 MFMA: column = lane & 31, row = 8 (r / 4) + 4 (lane >> 5) + r % 4;
@@ -189,7 +193,9 @@ template <int FM, int FN, int WGM, int WGN, int ABL = 0, int ST = 2>
 int launch_g32(const ConvParams& p, hipStream_t st) {
   using T = G32<FM, FN, WGM, WGN, ST>;
   static bool attr_set = false;
-  const size_t lds = (size_t)T::LDS_FLOATS * sizeof(float);
+  // FRTM_G32_LDS_KB (tools/g32_bench.py only): ask for more LDS than the kernel needs = fewer co-resident workgroups per CU
+  static const size_t lds_min = getenv("FRTM_G32_LDS_KB") ? (size_t)atoi(getenv("FRTM_G32_LDS_KB")) * 1024 : 0;
+  const size_t lds = std::max((size_t)T::LDS_FLOATS * sizeof(float), lds_min);
   if (!attr_set) {
     FRTM_HIP(hipFuncSetAttribute((const void*)k_conv1x1_g32<FM, FN, WGM, WGN, ABL, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -204,11 +210,36 @@ int launch_g32(const ConvParams& p, hipStream_t st) {
 // Called by frtm_conv2d for 1x1 / stride-1 / NCHW / Npix % 4 == 0 convs with the GEMM weight layout and no split-K.
 // tile: one of FRTM_TILE_G32_*.  Returns FRTM_ERR_ARG for an unknown tile.
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st) {
-  // FRTM_G32_ABLATE (tools/g32_bench.py only; the 128x128 and 64x64 tiles): bit 0 = skip the epilogue's global traffic, bit 1 = skip the MFMAs
+  // FRTM_G32_ABLATE (tools/g32_bench.py only; the 128x128 and 64x64 tiles): bit 0 = skip the epilogue's global traffic, bit 1 = skip the MFMAs,
+  // bit 2 = no global loads inside the K loop, bit 3 = no per-chunk barrier (64x64 tile only)
   static const int ablate = getenv("FRTM_G32_ABLATE") ? atoi(getenv("FRTM_G32_ABLATE")) : 0;
   if (ablate) {
-    if (tile == FRTM_TILE_G32_128x128) return ablate == 1 ? launch_g32<2, 2, 2, 2, 1>(p, st) : ablate == 2 ? launch_g32<2, 2, 2, 2, 2>(p, st) : launch_g32<2, 2, 2, 2, 3>(p, st);
-    if (tile == FRTM_TILE_G32_64x64) return ablate == 1 ? launch_g32<1, 1, 2, 2, 1>(p, st) : ablate == 2 ? launch_g32<1, 1, 2, 2, 2>(p, st) : launch_g32<1, 1, 2, 2, 3>(p, st);
+    if (tile == FRTM_TILE_G32_128x128) {
+      switch (ablate) {
+        case 1: return launch_g32<2, 2, 2, 2, 1>(p, st);
+        case 2: return launch_g32<2, 2, 2, 2, 2>(p, st);
+        case 3: return launch_g32<2, 2, 2, 2, 3>(p, st);
+        case 5: return launch_g32<2, 2, 2, 2, 5>(p, st);
+        case 13: return launch_g32<2, 2, 2, 2, 13>(p, st);
+        default: break;
+      }
+    }
+    if (tile == FRTM_TILE_G32_64x128 && ablate == 13) return launch_g32<1, 2, 2, 2, 13>(p, st);
+    if (tile == FRTM_TILE_G32_128x64 && ablate == 13) return launch_g32<2, 1, 2, 2, 13>(p, st);
+    if (tile == FRTM_TILE_G32_64x128 && ablate == 5) return launch_g32<1, 2, 2, 2, 5>(p, st);
+    if (tile == FRTM_TILE_G32_128x64 && ablate == 5) return launch_g32<2, 1, 2, 2, 5>(p, st);
+    if (tile == FRTM_TILE_G32_64x64) {
+      switch (ablate) {
+        case 1: return launch_g32<1, 1, 2, 2, 1>(p, st);
+        case 2: return launch_g32<1, 1, 2, 2, 2>(p, st);
+        case 3: return launch_g32<1, 1, 2, 2, 3>(p, st);
+        case 4: return launch_g32<1, 1, 2, 2, 4>(p, st);      // no global loads in the loop
+        case 5: return launch_g32<1, 1, 2, 2, 5>(p, st);      // ... and no epilogue traffic: LDS reads + MFMAs + barriers only
+        case 8: return launch_g32<1, 1, 2, 2, 8>(p, st);      // no per-chunk barrier
+        case 13: return launch_g32<1, 1, 2, 2, 13>(p, st);    // LDS reads + MFMAs only
+        default: break;
+      }
+    }
   }
   switch (tile) {
     case FRTM_TILE_G32_128x128: return launch_g32<2, 2, 2, 2>(p, st);

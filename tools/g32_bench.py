@@ -15,7 +15,7 @@ shapes = [(256, 1024, 30, 54), (1024, 256, 30, 54), (64, 256, 120, 214), (256, 6
 tiles = {'auto(16x16x4)': 0, 'g32 128x128': 20, 'g32 64x128': 21, 'g32 128x64': 22, 'g32 64x64': 23, 'g32 256x128 8w': 24, 'g32 128x256 8w': 25, 'g32 64x64 s3': 26, 'g32 128x128 s3': 27, 'g32 128x64 s3': 28}
 if QUICK:
     shapes = shapes[:2]
-    tiles = {k: v for k, v in tiles.items() if v in (0, 20, 23, 26)}
+    tiles = {k: v for k, v in tiles.items() if v in (20, 21, 22, 23)}
 g = torch.Generator().manual_seed(0)
 for cin, cout, h, w in shapes:
     x = torch.randn(B, cin, h, w, generator=g).to(dev)
@@ -38,9 +38,9 @@ for cin, cout, h, w in shapes:
             ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=tile, splitk=1 if tile else 0, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5 if QUICK else 30):
+        for _ in range(30):
             ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=tile, splitk=1 if tile else 0, out=out)
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / (5 if QUICK else 30) * 1e3
+        us = e0.elapsed_time(e1) / 30 * 1e3
         print('   %-16s %7.1f us  %6.1f TF   rel err %.1e' % (name, us, fl / us / 1e6, err))
