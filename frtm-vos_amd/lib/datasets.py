@@ -42,7 +42,10 @@ class FileSequence:
 
     def preload(self, device):
         """Decode every frame once and keep it on the device (reference tracker.py:88-91)."""
-        self.preloaded_images = [imread(f).to(device) for f in self.images]
+        # ONE device tensor for the whole sequence (frames are its slices): the tracker feeds consecutive frames to the trunk as a view
+        # of it, without gathering them into a batch first
+        from .synthetic import _to_device_slices
+        self.preloaded_images = _to_device_slices([imread(f) for f in self.images], device)
 
     def release(self):
         """Drop the pre-loaded frames (a dataset run keeps at most one sequence on the device)."""

@@ -7,6 +7,17 @@ import torch
 import torch.nn.functional as F
 
 
+def _to_device_slices(tensors, device):
+    """The tensors as slices of ONE tensor on `device` (frame by frame copies into it: no host-side stack of the whole sequence)."""
+    tensors = list(tensors)
+    if not tensors or len({(tuple(t.shape), t.dtype) for t in tensors}) != 1:
+        return [t.to(device) for t in tensors]
+    out = torch.empty((len(tensors),) + tuple(tensors[0].shape), dtype=tensors[0].dtype, device=device)
+    for i, t in enumerate(tensors):
+        out[i].copy_(t)
+    return list(out.unbind(0))
+
+
 class SyntheticSequence:
 
     def __init__(self, name='synth', n_frames=40, size=(480, 854), n_objects=1, seed=1, late_object_at=None,
@@ -57,8 +68,9 @@ class SyntheticSequence:
     def preload(self, device):
         if torch.device(device).type != 'cpu' and self._host is None:
             self._host = (self.images, self.gt)                 # the host copies stay: release() only drops the device copies
-        self.images = [im.to(device) for im in self.images]
-        self.gt = [lb.to(device) for lb in self.gt]
+        # (one device tensor per sequence, the frames are its slices: consecutive frames reach the trunk as a view, not as a gathered batch)
+        self.images = _to_device_slices(self.images, device)
+        self.gt = _to_device_slices(self.gt, device)
         self.device = device
 
     def release(self):

@@ -126,6 +126,7 @@ class Tracker(nn.Module):
         # draws them un-seeded when the object appears (tracker.py:174-180, before its "HACK for debugging" seeds anything), so two
         # runs of the reference never start alike; reproducible runs and parity tests against a CPU run inject them here.
         self.start_weights = None
+        self.frame_views = not os.environ.get('FRTM_NO_FRAME_VIEW')     # consecutive pre-loaded frames reach the trunk as a view (no gather)
         self.fuse_merge = True           # sigmoid + merge + pixel counts + label decoding of a window as ONE kernel (ops.track_merge)
         self._lut = None                 # run_sequence: device uint8 table mask plane -> object id (label decoding inside the merge kernel)
         self._single = False
@@ -372,6 +373,20 @@ class Tracker(nn.Module):
                 if saved[2] is not None:
                     self.refiner.use_graphs = saved[2]
 
+    def _frame_batch(self, ims):
+        """(B,3,H,W) uint8 batch of consecutive frames for the trunk.  Sequences pre-load their frames as slices of ONE device tensor
+        (lib/datasets.py, lib/synthetic.py): consecutive frames are then a view of it -- no gather kernel; anything else is stacked."""
+        base = ims[0]._base if self.frame_views else None
+        if (base is not None and base.is_cuda and base.device == torch.device(self.device) and ims[0].is_contiguous() and base.dim() == ims[0].dim() + 1
+                and all(im._base is base for im in ims)):
+            n, o0 = ims[0].numel(), ims[0].storage_offset()
+            if n > 0 and (o0 - base.storage_offset()) % n == 0 and all(im.storage_offset() == o0 + i * n for i, im in enumerate(ims)):
+                k0 = (o0 - base.storage_offset()) // n
+                view = base[k0:k0 + len(ims)]
+                if view.is_contiguous():
+                    return view
+        return torch.stack([im.to(self.device) for im in ims])
+
     def batch_sizes(self, n, fb):
         """Trunk batches for n tracked frames, fb frames each (the last one up to fb + fold_tail).  With ``balance_batches``: at most
         fb frames each, as few passes as possible, and those of similar size -- a
@@ -428,7 +443,7 @@ class Tracker(nn.Module):
                 return
             i0 = bounds[bi][0]
             idx = list(range(*bounds[bi]))
-            batch = torch.stack([frames[j][0].to(self.device) for j in idx])
+            batch = self._frame_batch([frames[j][0] for j in idx])
             st = on if on is not None else side
             if st is not None:
                 st.wait_stream(torch.cuda.current_stream())         # the input batch (and the previous use of this tap set)

@@ -36,6 +36,11 @@ for _e in reversed(_ends):
     if _i < len(_starts) and _starts[_i] - _e > 4e6 and t1 - _e < 80e6:
         t1 = _e
         break
+# Round 3: the tracking loop ends with the fused window tail (k_track_merge) and nothing after the timed sequence launches it again
+# (validation = framework reductions): its last launch marks the end of the timed region more reliably than the gap heuristic above.
+_tm = [int(r['End_Timestamp']) for r in tr if 'k_track_merge' in r['Kernel_Name'] or 'k_memory_next_slot_window' in r['Kernel_Name'] or 'k_cg_run_persistent' in r['Kernel_Name']]
+if _tm:
+    t1 = max(_tm)
 tr = [r for r in tr if int(r['Start_Timestamp']) < t1]
 win = 0.7 * b['ms_per_step'] * b['steps'] * 1e6           # the last 70 % of the timed sequence: tracked frames only
 tot, cnt = collections.Counter(), collections.Counter()
