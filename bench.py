@@ -566,6 +566,9 @@ def main():
     tracker.augment = timer.wrap('init_augment', logged_augment)
     tracker.initialize = timer.wrap('initialize_total', tracker.initialize)
     tracker.refiner.forward = timer.wrap('refiner', tracker.refiner.forward)
+    tracker.track_window = timer.wrap('track_window', tracker.track_window)          # (contains 'refiner' and 'target_update')
+    from frtm_vos_amd.model.discriminator import Discriminator as _Disc
+    _Disc.update_window = timer.wrap('target_update', _Disc.update_window)            # window memory inserts + the re-solve at a window's end
     import frtm_vos_amd.model.tracker as _TR
     _TR.TargetObject.initialize = timer.wrap('init_fit', _TR.TargetObject.initialize)
 

@@ -209,7 +209,7 @@ class GaussNewtonCG:
             H.call('frtm_guarded_copy', H.ptr(v.data), self._shadow.data_ptr() + 4 * o, v.numel(), guard.data_ptr(), guard_min, 1, None, 0)
             o += v.numel()
 
-    hierarchical_barrier = True     # persistent launches: XCD-hierarchical grid barrier (False: one flat counter)
+    hierarchical_barrier = not __import__('os').environ.get('FRTM_FLAT_BARRIER')     # persistent launches: XCD-hierarchical grid barrier (False: one flat counter)
     persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
 
     def _persistent_plan(self):

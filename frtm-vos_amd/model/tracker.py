@@ -43,6 +43,8 @@ def _process_stream(device, role):
     trackers / refiners (the test suite; reproducer tools/graph_stress.py).  Trackers of one process do not run concurrently (one host
     thread drives them), so they can share."""
     key = (torch.device(device).index, role)
+    if os.environ.get('FRTM_PRIVATE_STREAMS'):
+        return torch.cuda.Stream(device=device)
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(device=device)
     return _STREAMS[key]
@@ -127,7 +129,7 @@ class Tracker(nn.Module):
         # runs of the reference never start alike; reproducible runs and parity tests against a CPU run inject them here.
         self.start_weights = None
         self.frame_views = not os.environ.get('FRTM_NO_FRAME_VIEW')     # consecutive pre-loaded frames reach the trunk as a view (no gather)
-        self.fuse_merge = True           # sigmoid + merge + pixel counts + label decoding of a window as ONE kernel (ops.track_merge)
+        self.fuse_merge = not os.environ.get('FRTM_NO_FUSE_MERGE')    # sigmoid + merge + pixel counts + label decoding of a window as ONE kernel (ops.track_merge)
         self._lut = None                 # run_sequence: device uint8 table mask plane -> object id (label decoding inside the merge kernel)
         self._single = False
         self._window_labels = None
