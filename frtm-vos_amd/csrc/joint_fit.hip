@@ -475,6 +475,9 @@ int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const flo
                                int splits, float* partial, frtm_stream_t stream) {
   FRTM_CHECK_ARG(X && K && Z && p2 && partial && N > 0 && Cx > 0 && Cz > 0 && h > 0 && w > 0 && splits >= 1 && splits <= 64,
                  "frtm_joint_scores_composed: bad argument");
+  // (6 rows per block to cut the halo re-reads on the 720p / 1080p maps -- 467 MB fetched per launch for 167 MB of features at 1080p with
+  // several fits in flight, profiles/r03_config5_pmc_traffic.json -- measured 2.5x SLOWER: 1024-thread blocks with 8 live rows per
+  // channel drop to one block per CU; dropped)
   dim3 g(ceil_div(h, 3) * N * ceil_div(w, 64), splits + 1);
   k_scores_composed<3, 16><<<g, 1024, 0, (hipStream_t)stream>>>(X, K, Cx, Z, p2, Cz, h, w, partial);
   FRTM_LAUNCH_CHECK();

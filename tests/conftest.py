@@ -28,8 +28,13 @@ def golden():
 
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no GPU is visible, so that an unmarked
-    ``pytest tests`` still works in the build container."""
+    ``pytest tests`` still works in the build container.  Every test gets a time limit (pytest-timeout, if installed): a hung kernel
+    or a stuck rendezvous fails ONE test instead of eating the whole run."""
     import torch
+    if config.pluginmanager.hasplugin('timeout'):
+        for it in items:
+            if it.get_closest_marker('timeout') is None:
+                it.add_marker(pytest.mark.timeout(900))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason='no GPU visible')
