@@ -327,3 +327,55 @@ def test_many_refiners_with_parallel_graph_branches_in_one_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'graph_stress.py'), '200', '1'], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'DONE 200' in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_bench_sharded_mode_two_ranks_on_the_gpu():
+    """`python bench.py --gpus 2 --sequences 5` (strong scaling: ONE dataset cut over the ranks) with two real ranks sharing cuda:0 over gloo:
+    the ranks take disjoint shares that cover the 5 sequences, rank 0 reports sum of frames / max wall time, and the update work of every
+    sequence ran (counters summed over the shard).  The N = 1 value of the same dataset is within a few percent of frames / seconds of
+    its rank report."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rep = os.path.join(root, 'gpurun_out', 'bench_shard_test')
+    base = [sys.executable, os.path.join(root, 'bench.py'), '--dist-backend', 'gloo', '--share-gpu', '--sequences', '5', '--steps', '12', '--warmup', '2',
+            '--backbone', 'resnet18', '--fast', '--size', '240x432', '--report-dir', rep, '--no-cpu-baseline']
+    out = subprocess.run(base + ['--gpus', '2'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    ranks = [json.load(open(os.path.join(rep, 'rank_%d.json' % r))) for r in range(2)]
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['valid']
+    assert line['frames_total'] == sum(r['frames'] for r in ranks) and all(r['frames'] > 0 for r in ranks)
+    assert abs(line['value'] - line['frames_total'] / max(r['seconds'] for r in ranks)) / line['value'] < 0.05
+    assert all(r['memory_inserts'] + r['early_outs_fewer_than_10_px'] >= r['memory_inserts_scheduled'] for r in ranks)
+
+
+def test_fork_solver_configuration_runs_through_the_tracker():
+    """Parameters(ytvos_fork_solver=True) (Fletcher-Reeves, CG state reset at every run: what the reference's YouTube-VOS driver really runs)
+    with the fork's sequence-level merge: the tracker runs, every scheduled re-solve happens, and the labels stay close to the default
+    solver's (both fit the same least-squares problems)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence, make_score_following_refiner
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    torch.set_grad_enabled(False)
+
+    def refiner(chans):
+        torch.manual_seed(1)
+        return make_score_following_refiner(SegNetwork(1, 64, chans, True).eval())
+    outs = []
+    for fork in (False, True):
+        p = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', ytvos_fork_solver=fork)
+        p.refiner_factory = refiner
+        p.disc_params.update(memory_size=16)
+        trk = p.get_model().eval()
+        seq = SyntheticSequence('yt', 19, (128, 160), 2, seed=8, late_object_at=4)
+        seq.preload(DEV)
+        torch.manual_seed(11)
+        labels, _ = trk.run_sequence(seq, ytvos_merge=True)
+        d = [t.discriminator for t in trk.targets.values()]
+        assert all(x.fletcher_reeves == fork and (x.direction_forget_factor == 0) == fork for x in d)
+        assert all(x.update_optimizer.fletcher_reeves == fork for x in d)
+        assert [x.num_solves for x in d] == [(18 - s) // 8 for s in (0, 4)]
+        outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
+    assert float((outs[0] == outs[1]).float().mean()) > 0.97
