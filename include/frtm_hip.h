@@ -275,6 +275,7 @@ typedef struct {
 #define FRTM_TILE_G32_64x64_S3 26   /* three LDS stages (loads two chunks ahead) */
 #define FRTM_TILE_G32_128x128_S3 27
 #define FRTM_TILE_G32_128x64_S3 28
+#define FRTM_TILE_G32P_64x64 30     /* persistent workgroups: loads across tile boundaries, epilogue of a tile under the next tile's K loop */
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

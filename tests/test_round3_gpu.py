@@ -379,3 +379,44 @@ def test_fork_solver_configuration_runs_through_the_tracker():
         assert [x.num_solves for x in d] == [(18 - s) // 8 for s in (0, 4)]
         outs.append(torch.stack([l.reshape(128, 160) for l in labels]).cpu())
     assert float((outs[0] == outs[1]).float().mean()) > 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,h,w,frames', [(256, 128, 30, 54, 3), (64, 256, 23, 36, 2), (96, 64, 17, 20, 1), (512, 192, 9, 12, 5)])
+def test_opt_in_gemm_tiles_match_the_default_kernel(cin, cout, h, w, frames):
+    """The selectable 1x1 kernels (32x32x2 MFMA; its persistent form with the deferred epilogue) against an fp64-accumulated reference,
+    with every epilogue combination, on pixel counts that leave ragged last tiles (h * w % 4 == 0 is the kernels' own condition).
+    The persistent kernel sums in the same order as the plain 32x32x2 one: bit-identical."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(frames, cin, h, w, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(frames, cout, h, w, generator=g).cuda()
+    wT, ktab, layout = ops.pack_weights(wt)
+    lin = torch.einsum('oc,bchw->bohw', wt[:, :, 0, 0].double(), x.double())
+    for scale, residual, relu in [(False, False, False), (True, False, True), (True, True, True), (False, True, False)]:
+        ref = lin
+        if scale:
+            ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        if residual:
+            ref = ref + res.double()
+        if relu:
+            ref = torch.relu(ref)
+        kw = dict(scale=sc if scale else None, shift=sh if scale else None, residual=res if residual else None, relu=relu, splitk=1)
+        outs = {}
+        for tile in (0, 23, 30):                                     # planner's igemm tile, FRTM_TILE_G32_64x64, FRTM_TILE_G32P_64x64
+            out = torch.full((frames, cout, h, w), float('nan'), device='cuda')
+            ops.conv2d(x, wT, cout, tile=tile, out=out, **kw)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all(), (tile, scale, residual, relu)
+            err = float((out.double() - ref).abs().max() / ref.abs().max())
+            assert err < 5e-6, (tile, scale, residual, relu, err)
+            outs[tile] = out
+        assert torch.equal(outs[23], outs[30])
+    # the persistent tile refuses what its addressing cannot do (Cout % 64) instead of computing something else
+    wt2 = (torch.randn(96, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    wT2, _, _ = ops.pack_weights(wt2)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, wT2, 96, tile=30, splitk=1)
