@@ -70,6 +70,7 @@ SIGNATURES = {
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),
     'frtm_backbone_set_winograd': (I, [P, I]),
+    'frtm_backbone_set_winograd4': (I, [P, I]),
     'frtm_merge_masks': (I, [P, I, I, P]),
     'frtm_merge_masks_frames': (I, [P, I, I, I, P]),
     'frtm_count_above': (I, [P, I, I, F, P, P]),

@@ -13,6 +13,7 @@ struct ConvL {
   int Cout, Cin, ks, stride, pad;
   float* wT = nullptr; float* scale = nullptr; float* shift = nullptr; int* ktab = nullptr;
   float* wW = nullptr;          // 3x3 stride-1 convs: second image of the weights, Winograd F(2x2,3x3) (FRTM_WLAYOUT_WINO3X3)
+  float* wW4 = nullptr;         // ... with >= 128 channels: third image, the 36 matrices of Winograd F(4x4,3x3) (FRTM_WLAYOUT_WINO4)
   bool loaded = false;
   int layout = 0;
 };
@@ -25,6 +26,7 @@ struct Lane {
   float* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t buf_elems = 0;
   float* ws = nullptr; size_t ws_elems = 0;
+  float* ws4 = nullptr; size_t ws4_elems = 0;       // transformed input / product tensors of the F(4x4,3x3) launches
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
 };
@@ -41,6 +43,7 @@ struct frtm_backbone {
   double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (16 of 36 per 2x2 outputs)
   int last_launches = 0;
   bool use_winograd = true;
+  bool use_winograd4 = getenv("FRTM_NO_WINO4") == nullptr;     // F(4x4,3x3) in three launches where it is eligible (run_conv)
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
@@ -112,6 +115,24 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
   d.ws_elems = (int)std::min<size_t>(ln.ws_elems, 0x7fffffff);
   bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;      // algorithmic (direct-form) FLOPs
+  // Winograd F(4x4,3x3), three-launch form (conv_wino4.hip), for the wide 3x3 stride-1 convs: 2.25 multiplications per output
+  // instead of 4; eligible when the 36 products fill the chip as one GEMM launch and the 4x4 output tiles waste < 25 % on the
+  // map's edges (30x54 -> 32x56: 10.6 %).  Measured at 8 frames (tools/wino4_bench.py): 256 ch 30x54 70 vs 100 us, 512 ch 15x27
+  // 69 vs 110, 128 ch 60x107 85 vs 104; 64 ch 120x214 is slower (138 vs 108: K = 64 GEMMs, transform traffic) and stays F(2x2).
+  if (c.wW4 && bb->use_winograd && bb->use_winograd4) {
+    const int th = ceil_div(*Ho, 4), tw = ceil_div(*Wo, 4);
+    const long T = (long)B * th * tw, Tp = (T + 63) / 64 * 64;
+    if ((long)ceil_div(c.Cout, 64) * (36 * Tp / 64) >= 512 && (long)16 * th * tw * 4 <= (long)5 * (*Ho) * (*Wo)) {
+      const size_t need = (size_t)36 * (c.Cin + c.Cout) * Tp;
+      int rc = ensure(bb, &ln.ws4, &ln.ws4_elems, need);
+      if (rc) return rc;
+      d.w_layout = FRTM_WLAYOUT_WINO4;
+      d.splitk = 1;
+      d.ws_elems = (int)std::min<size_t>(ln.ws4_elems, 0x7fffffff);
+      bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * 36.0 * (double)T;
+      return frtm_conv2d(&d, in, c.wW4, nullptr, c.scale, c.shift, residual, out, ln.ws4, st);
+    }
+  }
   // Winograd for the 3x3 stride-1 convs whenever the launch has enough 8x8 output blocks to fill the chip without split-K
   if (c.wW && bb->use_winograd &&
       (long)B * ceil_div(*Ho, 8) * ceil_div(*Wo, 8) * ceil_div(c.Cout, 32) >= FRTM_WINO_MIN_BLOCKS) {
@@ -253,6 +274,7 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
   for (auto& c : bb->convs) {
     if (c.wT) (void)hipFree(c.wT);
     if (c.wW) (void)hipFree(c.wW);
+    if (c.wW4) (void)hipFree(c.wW4);
     if (c.scale) (void)hipFree(c.scale);
     if (c.shift) (void)hipFree(c.shift);
     if (c.ktab) (void)hipFree(c.ktab);
@@ -260,6 +282,7 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
   for (auto& ln : bb->lanes) {
     for (auto& b : ln.buf) if (b) (void)hipFree(b);
     if (ln.ws) (void)hipFree(ln.ws);
+    if (ln.ws4) (void)hipFree(ln.ws4);
     if (ln.done) (void)hipEventDestroy(ln.done);
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
@@ -297,6 +320,11 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
     if (!c.wW) FRTM_HIP(hipMalloc((void**)&c.wW, (size_t)FRTM_CONV_WINO_ELEMS(c.Cout, c.Cin) * sizeof(float)));
     rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, 3, FRTM_WLAYOUT_WINO3X3, c.wW, nullptr, stream);
     if (rc) return rc;
+    if (c.Cin >= 128 && c.Cin % 32 == 0 && c.Cout % 64 == 0) {
+      if (!c.wW4) FRTM_HIP(hipMalloc((void**)&c.wW4, (size_t)FRTM_CONV_WINO4_ELEMS(c.Cout, c.Cin) * sizeof(float)));
+      rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, 3, FRTM_WLAYOUT_WINO4, c.wW4, nullptr, stream);
+      if (rc) return rc;
+    }
   }
   FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
   FRTM_HIP(hipMemcpyAsync(c.shift, bn_shift, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -311,6 +339,12 @@ int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->genera
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
   FRTM_CHECK_ARG(bb, "frtm_backbone_set_winograd: null handle");
   bb->use_winograd = enable != 0;
+  return FRTM_OK;
+}
+
+int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable) {
+  FRTM_CHECK_ARG(bb, "frtm_backbone_set_winograd4: null handle");
+  bb->use_winograd4 = enable != 0;
   return FRTM_OK;
 }
 

@@ -11,6 +11,8 @@ struct ConvParams {
   int B, Cin, Hin, Win, M, Mp, Ho, Wo, K, stride, pad;
   int Npix, Ntot, relu, out_transposed, splitk, chunks_per_split, nchunks;
   unsigned in_bytes, w_bytes;
+  int w_img_stride = 0;     // != 0 (k_conv_igemm MODE 1, batched GEMM): image i multiplies with the weight matrix wT + i * w_img_stride (floats);
+                            // Npix must be a multiple of the tile's BN so that no tile straddles two images
 };
 
 constexpr int BK = 32;                 // K granularity of the packed weights / split-K bookkeeping

@@ -24,6 +24,9 @@
 // conv_wino.hip
 int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_t st);
 int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st);
+// conv_wino4.hip
+int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, hipStream_t st);
+int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, hipStream_t st);
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
 // FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   const int kc0 = blockIdx.z * p.chunks_per_split / (BK / 32);
   const int kc1 = min((p.nchunks + BK / 32 - 1) / (BK / 32), (int)((blockIdx.z + 1) * p.chunks_per_split / (BK / 32)));
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
+  const float* wbase = (MODE == 1 && p.w_img_stride) ? p.wT + (size_t)(n0 / p.Npix) * p.w_img_stride : p.wT;      // batched GEMM: one weight matrix per image
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
 
   // ---- A: weights [Kp][Mp], zero padded; rows m >= M only feed accumulators that are never stored ----
@@ -463,6 +467,22 @@ static int halo_tile_width(int Ho, int Wo) {
   return best;
 }
 
+// The 36 products of the three-launch Winograd form (conv_wino4.hip) as one MODE-1 launch: q describes them as a 1x1 conv over 36
+// "images" whose weights switch per image (q.w_img_stride); Npix is a multiple of 64, every tile below is 64 columns wide.
+int frtm_igemm_batched(const ConvParams& q, int tile, hipStream_t st) {
+  if (q.Npix % 64 || !q.w_img_stride) { frtm_set_error("frtm_igemm_batched: Npix must be a multiple of 64"); return FRTM_ERR_ARG; }
+  if (tile == 0) tile = (q.M % 64 == 0) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64;
+  switch (tile) {
+    case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(q, true, st); break;
+    case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(q, true, st); break;
+    case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(q, true, st); break;
+    case FRTM_TILE_64x64_8W: launch_tile<64, 64, 2, 4>(q, true, st); break;
+    default: frtm_set_error("frtm_igemm_batched: unknown tile %d", tile); return FRTM_ERR_ARG;
+  }
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
 extern "C" {
 
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout, float* wT, int* ktab,
@@ -471,6 +491,10 @@ int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, in
   if (layout == FRTM_WLAYOUT_WINO3X3) {
     FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd layout is for 3x3 kernels");
     return frtm_wino_pack(w_oihw, Cout, Cin, wT, (hipStream_t)stream);
+  }
+  if (layout == FRTM_WLAYOUT_WINO4) {
+    FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd F(4x4,3x3) layout is for 3x3 kernels");
+    return frtm_wino4_pack(w_oihw, Cout, Cin, wT, (hipStream_t)stream);
   }
   if (layout == FRTM_WLAYOUT_HALO3X3) {
     FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the halo layout is for 3x3 kernels");
@@ -518,6 +542,13 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
                    "frtm_conv2d: the Winograd layout needs 3x3, stride 1, pad 1, NCHW output");
     FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 3, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8)");
     return frtm_wino_launch(p, d->tile, (hipStream_t)stream);
+  }
+  if (d->w_layout == FRTM_WLAYOUT_WINO4) {
+    FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
+                   "frtm_conv2d: the Winograd F(4x4,3x3) layout needs 3x3, stride 1, pad 1, NCHW output");
+    FRTM_CHECK_ARG(d->tile == 0 || d->tile == FRTM_TILE_64x64 || d->tile == FRTM_TILE_32x64 || d->tile == FRTM_TILE_64x64_8W || d->tile == FRTM_TILE_128x64,
+                   "frtm_conv2d: Winograd F(4x4,3x3): tile selects the GEMM tile (0 auto, 64x64, 32x64, 64x64 8 waves, 128x64)");
+    return frtm_wino4_launch(p, workspace, (size_t)d->ws_elems, d->tile, (hipStream_t)stream);
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");

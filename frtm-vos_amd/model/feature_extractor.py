@@ -155,6 +155,7 @@ class ResnetFeatureExtractor:
         self.output_set = 0            # which persistent tap set to write (double buffering for the prefetch stream)
         self._lanes = 1
         self._winograd = True
+        self._winograd4 = not os.environ.get('FRTM_NO_WINO4')
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
         self.capture_after = 1         # trunk shapes are replayed as hipGraphs from their (capture_after + 1)-th use on
         self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
@@ -177,6 +178,18 @@ class ResnetFeatureExtractor:
         if self._handle is not None:
             H.call_nostream('frtm_backbone_set_winograd', self._handle, int(self._winograd))
             self._out_cache.clear()           # captured graphs hold the other kernels
+
+    @property
+    def winograd4(self):
+        """The wide 3x3 stride-1 convs (>= 128 channels) as Winograd F(4x4,3x3) in three launches (frtm_backbone_set_winograd4)."""
+        return self._winograd4
+
+    @winograd4.setter
+    def winograd4(self, on):
+        self._winograd4 = bool(on)
+        if self._handle is not None:
+            H.call_nostream('frtm_backbone_set_winograd4', self._handle, int(self._winograd4))
+            self._out_cache.clear()
 
     @lanes.setter
     def lanes(self, n):
@@ -216,6 +229,7 @@ class ResnetFeatureExtractor:
                 self._handle = h
                 H.call_nostream('frtm_backbone_set_lanes', h, self._lanes)
                 H.call_nostream('frtm_backbone_set_winograd', h, int(self._winograd))
+                H.call_nostream('frtm_backbone_set_winograd4', h, int(self._winograd4))
             pairs = self.resnet.conv_bn_pairs()
             assert L.frtm_backbone_num_convs(self._handle) == len(pairs)
             info = (ctypes.c_int * 6)()

@@ -252,6 +252,13 @@ typedef struct {
  * no split-K: meant for launches with enough output blocks, the caller keeps the HALO3X3 image for the small ones). */
 #define FRTM_WLAYOUT_WINO3X3 2
 #define FRTM_CONV_WINO_ELEMS(Cout, Cin) ((((Cin) + 7) / 8 * 128) * (((Cout) + 31) / 32 * 32))
+/* Winograd F(4x4,3x3) in three launches (conv_wino4.hip): input transform -> 36 batched [Cout x Cin] x [Cin x tiles] products (one
+   launch of the fp32 MFMA GEMM kernel) -> output transform + epilogue.  frtm_conv2d then needs a workspace of
+   FRTM_CONV_WINO4_WS_ELEMS floats; `tile` selects the GEMM tile (0 = auto).  3x3, stride 1, pad 1, NCHW only. */
+#define FRTM_WLAYOUT_WINO4 3
+#define FRTM_CONV_WINO4_ELEMS(Cout, Cin) (36 * (((Cin) + 31) / 32 * 32) * (((Cout) + 31) / 32 * 32))
+#define FRTM_CONV_WINO4_TILES(B, H, W) ((((B) * (((H) + 3) / 4) * (((W) + 3) / 4)) + 63) / 64 * 64)
+#define FRTM_CONV_WINO4_WS_ELEMS(B, Cin, Cout, H, W) ((size_t)36 * ((Cin) + (Cout)) * FRTM_CONV_WINO4_TILES(B, H, W))
 #define FRTM_WINO_MIN_BLOCKS 512   /* 8x8 output blocks x 32-channel tiles below which callers prefer HALO3X3 + split-K */
 #define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) \
   (((((Cin) * (k) * (k) + 31) / 32 * 32) > (((Cin) + 7) / 8 * 72) ? (((Cin) * (k) * (k) + 31) / 32 * 32) : (((Cin) + 7) / 8 * 72)) * (((Cout) + 31) / 32 * 32))
@@ -318,6 +325,8 @@ int frtm_backbone_generation(const frtm_backbone_t* bb);
 /* The trunk's 3x3 stride-1 convs run as Winograd F(2x2,3x3) when a launch has >= FRTM_WINO_MIN_BLOCKS output blocks
  * (default on; results differ from the direct kernels by fp32 rounding only). */
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable);
+/* Winograd F(4x4,3x3) (three-launch form, FRTM_WLAYOUT_WINO4) for the eligible 3x3 convs of a Winograd-enabled trunk; default on. */
+int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable);
 
 /* ------------------------------------------------------------------------------------------
  * Tracker.track mask merge (model/tracker.py:214-221), in place on masks (n_obj+1, H*W).
