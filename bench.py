@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')
     ap.add_argument('--no-windows', action='store_true', help='track frame by frame instead of one window per filter re-solve interval')
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convs on the direct (halo) kernels only')
+    ap.add_argument('--no-winograd4', action='store_true', help='no Winograd F(4x4,3x3): the wide 3x3 convs stay on the fused F(2x2,3x3) kernel')
     ap.add_argument('--first-pass-overlap', action='store_true', help='first trunk pass on a side stream next to the fits of initialize()')
     ap.add_argument('--no-early-first-pass', action='store_true', help='first tracking trunk pass after initialize() instead of under its augmentation')
     ap.add_argument('--refiner-serial', action='store_true', help='refiner graph without parallel pyramid-level branches')
@@ -562,6 +563,8 @@ def main():
     if args.no_winograd:
         tracker.refiner.use_winograd = False
         tracker.feature_extractor.winograd = False
+    if args.no_winograd4:
+        tracker.feature_extractor.winograd4 = False
     tracker.window_tracking = not args.no_windows
     if args.init_graph:
         from frtm_vos_amd.model.discriminator import Discriminator
@@ -577,6 +580,7 @@ def main():
     ext.pass_frames = []
     ext.pass_events = []                     # HIP events around every trunk pass, recorded on the stream the pass runs on
     ext.pass_exec_flops = []                 # executed (Winograd-aware) FLOPs of the same passes
+    ext.pass_form_flops = []                 # algorithmic FLOPs of the same passes by kernel form (direct, F(2x2,3x3), F(4x4,3x3))
     aug_log = []
     raw_augment = tracker.augment
 
@@ -613,6 +617,7 @@ def main():
     del ext.pass_events[:]
     del ext.pass_frames[:]
     del ext.pass_exec_flops[:]
+    del ext.pass_form_flops[:]
 
     if dist is not None:
         dist.barrier()
@@ -702,7 +707,9 @@ def main():
 
     exec_flops = sum(getattr(ext, 'pass_exec_flops', []) or [0.0])
     exec_ratio = (exec_flops / flops_total) if (flops_total > 0 and exec_flops > 0) else 1.0
-    wino_share = round((1.0 - exec_ratio) / (1.0 - 16.0 / 36.0), 4) if exec_ratio < 1.0 else 0.0
+    form = [sum(f[k] for f in (getattr(ext, 'pass_form_flops', []) or [[0.0, 0.0, 0.0]])) for k in range(3)]
+    wino_share = round((form[1] + form[2]) / max(sum(form), 1.0), 4)
+    wino4_share = round(form[2] / max(sum(form), 1.0), 4)
     sq_busy = None
     for cand in ('r03_sq_busy.json', 'r02_sq_busy.json'):
         sf = os.path.join(ROOT, 'profiles', cand)
@@ -733,17 +740,19 @@ def main():
                                 'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.memory,
                                 'seeded default init, no confident masks' if args.random_refiner else 'seeded default init + score-following channel',
                                 args.trunk_batch, args.trunk_lanes,
-                                ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else 'Winograd F(2x2,3x3)'),
+                                ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else ('Winograd F(2x2,3x3)' if args.no_winograd4 else 'Winograd F(4x4,3x3) from 128 channels on, F(2x2,3x3) below')),
                    'warmup_frames_run': sum(max(w, 2) for w in warm_lengths),
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
+        'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino / k_wino4_* (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
-                     # `frac` counts ALGORITHMIC (direct-form) FLOPs.  The 3x3 stride-1 convs of large launches run as Winograd F(2x2,3x3):
-                     # 16 instead of 36 multiplications per 2x2 outputs, so the MACs the matrix pipes EXECUTE are fewer.  frac_executed
+                     # `frac` counts ALGORITHMIC (direct-form) FLOPs.  The 3x3 stride-1 convs of large launches run as Winograd F(2x2,3x3)
+                     # (16 instead of 36 multiplications per 2x2 outputs) or, from 128 channels on, F(4x4,3x3) (36 instead of 144 per 4x4
+                     # outputs), so the MACs the matrix pipes EXECUTE are fewer.  frac_executed
                      # counts those (frtm_backbone_last_flops_executed); mfma_pipe_busy is the SQ counter ratio of the committed PMC pass
                      # over the same kernels (profiles/*_sq_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / active cycles, every kernel alone).
                      'achieved_executed': achieved * exec_ratio, 'frac_executed': achieved * exec_ratio / PEAK_F32_TFLOPS,
-                     'winograd_share_of_algorithmic_flops': wino_share, 'mfma_pipe_busy': sq_busy,
+                     'winograd_share_of_algorithmic_flops': wino_share, 'winograd_f4x4_share_of_algorithmic_flops': wino4_share,
+                     'mfma_pipe_busy': sq_busy,
                      # v_mfma_f32_16x16x4_f32 (the instruction of these kernels) sustains 123-139 TFLOP/s with register operands and nothing
                      # else in the loop, v_mfma_f32_32x32x2_f32 155 (tools/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt): `peak` stays the
                      # data-sheet number

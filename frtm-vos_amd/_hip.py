@@ -66,6 +66,7 @@ SIGNATURES = {
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_last_flops': (D, [P]),
     'frtm_backbone_last_flops_executed': (D, [P]),
+    'frtm_backbone_last_flops_form': (D, [P, I]),
     'frtm_backbone_last_conv_launches': (I, [P]),
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),

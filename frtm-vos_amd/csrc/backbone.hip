@@ -40,7 +40,8 @@ struct frtm_backbone {
   int nlanes = 1;
   hipEvent_t fork = nullptr;
   double last_flops = 0.0;
-  double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (16 of 36 per 2x2 outputs)
+  double last_flops_form[3] = {0.0, 0.0, 0.0};   // algorithmic FLOPs of the last pass by kernel form: direct, Winograd F(2x2,3x3), F(4x4,3x3)
+  double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (F(2x2,3x3): 16 per 2x2 outputs instead of 36; F(4x4,3x3): 36 per 4x4 tile instead of 144, partial edge tiles included)
   int last_launches = 0;
   bool use_winograd = true;
   bool use_winograd4 = getenv("FRTM_NO_WINO4") == nullptr;     // F(4x4,3x3) in three launches where it is eligible (run_conv)
@@ -130,6 +131,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       d.splitk = 1;
       d.ws_elems = (int)std::min<size_t>(ln.ws4_elems, 0x7fffffff);
       bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * 36.0 * (double)T;
+      bb->last_flops_form[2] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
       return frtm_conv2d(&d, in, c.wW4, nullptr, c.scale, c.shift, residual, out, ln.ws4, st);
     }
   }
@@ -139,9 +141,11 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
     d.w_layout = FRTM_WLAYOUT_WINO3X3;
     d.splitk = 1;
     bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks * (16.0 / 36.0);
+    bb->last_flops_form[1] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
     return frtm_conv2d(&d, in, c.wW, nullptr, c.scale, c.shift, residual, out, ln.ws, st);
   }
   bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
+  bb->last_flops_form[0] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
 }
 
@@ -334,6 +338,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
 double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb) { return bb ? bb->last_flops_exec : 0.0; }
+double frtm_backbone_last_flops_form(const frtm_backbone_t* bb, int form) { return (bb && form >= 0 && form < 3) ? bb->last_flops_form[form] : 0.0; }
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
 int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->generation : 0; }
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
@@ -369,6 +374,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   hipStream_t st = (hipStream_t)stream;
   bb->last_flops = 0.0;
   bb->last_flops_exec = 0.0;
+  bb->last_flops_form[0] = bb->last_flops_form[1] = bb->last_flops_form[2] = 0.0;
   bb->last_launches = 0;
   const int L = std::min(bb->nlanes, B);
   // the conv kernels address activations with 32-bit byte offsets: at most this many images per forward_lane call

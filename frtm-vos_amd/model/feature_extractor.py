@@ -147,6 +147,7 @@ class ResnetFeatureExtractor:
         self.device = None
         self.last_flops = 0.0
         self.last_flops_executed = 0.0
+        self.last_flops_form = [0.0, 0.0, 0.0]
         self.last_conv_launches = 0
         self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
         self._out_cache = {}
@@ -272,6 +273,8 @@ class ResnetFeatureExtractor:
                 self.pass_frames.append(B)
                 if getattr(self, 'pass_exec_flops', None) is not None:
                     self.pass_exec_flops.append(self.last_flops_executed)
+                if getattr(self, 'pass_form_flops', None) is not None:
+                    self.pass_form_flops.append(list(self.last_flops_form))
             if not capturing:
                 self._pass_done = torch.cuda.Event()
                 self._pass_done.record(cur)
@@ -321,7 +324,7 @@ class ResnetFeatureExtractor:
         if replay:
             ent['in'].copy_(x)
             ent['graph'].replay()
-            self.last_flops, self.last_conv_launches, self.last_flops_executed = ent['stats']
+            self.last_flops, self.last_conv_launches, self.last_flops_executed, self.last_flops_form = ent['stats']
         else:
             self._forward(x, ent['out'], args, stop)
         return ent['out']
@@ -333,7 +336,7 @@ class ResnetFeatureExtractor:
         g = torch.cuda.CUDAGraph()
         with H.capture(g):
             self._forward(ent['in'], ent['out'], args, stop)
-        ent['stats'] = (self.last_flops, self.last_conv_launches, self.last_flops_executed)
+        ent['stats'] = (self.last_flops, self.last_conv_launches, self.last_flops_executed, list(self.last_flops_form))
         ent['graph'], ent['gen'] = g, H.lib().frtm_backbone_generation(self._handle)
 
     def _forward(self, x, out, args, stop):
@@ -341,6 +344,7 @@ class ResnetFeatureExtractor:
         H.call('frtm_backbone_forward', self._handle, H.ptr(x), *args, *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
         self.last_flops_executed = H.lib().frtm_backbone_last_flops_executed(self._handle)    # Winograd launches at the MACs they execute
+        self.last_flops_form = [H.lib().frtm_backbone_last_flops_form(self._handle, k) for k in range(3)]   # direct, F(2x2,3x3), F(4x4,3x3)
         self.last_conv_launches = H.lib().frtm_backbone_last_conv_launches(self._handle)
 
     def get_out_channels(self):

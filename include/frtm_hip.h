@@ -310,6 +310,8 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */
 double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb);
+/* algorithmic FLOPs of the last forward by kernel form: 0 = direct kernels, 1 = Winograd F(2x2,3x3), 2 = Winograd F(4x4,3x3) */
+double frtm_backbone_last_flops_form(const frtm_backbone_t* bb, int form);
 /* Number of convolutions (k_conv_igemm launches) of the last forward() call. */
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb);
 /* Concurrency of forward(): a batch of B frames is split into min(lanes, B) sub-batches that run on the caller's stream

@@ -420,3 +420,64 @@ def test_opt_in_gemm_tiles_match_the_default_kernel(cin, cout, h, w, frames):
     wT2, _, _ = ops.pack_weights(wt2)
     with pytest.raises(RuntimeError):
         ops.conv2d(x, wT2, 96, tile=30, splitk=1)
+
+
+@pytest.mark.parametrize('B,cin,cout,h,w', [(3, 128, 64, 30, 54), (2, 160, 128, 17, 23), (1, 128, 192, 9, 13), (5, 256, 256, 15, 27), (8, 256, 256, 30, 54)])
+def test_winograd_f4x4_three_launch_form_against_an_fp64_convolution(B, cin, cout, h, w):
+    """FRTM_WLAYOUT_WINO4 (conv_wino4.hip: input transform, 36 batched products, output transform + epilogue) on maps whose height /
+    width are not multiples of the 4x4 output tile, tile counts that need padding to the GEMM's 64 columns, every epilogue
+    combination.  fp32 Winograd F(4x4,3x3) with the points 0, +-1, +-2, inf: max |err| <= 3e-5 of max |out| against an fp64 direct
+    convolution (the direct fp32 kernel: 1e-6, F(2x2,3x3): 5e-7)."""
+    import torch.nn.functional as F
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    x = torch.relu(torch.randn(B, cin, h, w, generator=g)).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).cuda()
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(B, cout, h, w, generator=g).cuda()
+    wW4, _, layout = ops.pack_weights(wt, wino4=True)
+    assert layout == 3
+    ws = ops.wino4_workspace(B, cin, cout, h, w, 'cuda')
+    lin = F.conv2d(x.double(), wt.double(), padding=1)
+    for scale, residual, relu in [(False, False, False), (True, False, True), (True, True, True), (False, True, False)]:
+        ref = lin
+        if scale:
+            ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        if residual:
+            ref = ref + res.double()
+        if relu:
+            ref = torch.relu(ref)
+        for tile in (0, 1, 2):
+            out = torch.full((B, cout, h, w), float('nan'), device='cuda')
+            ops.conv2d(x, wW4, cout, 3, 1, 1, scale=sc if scale else None, shift=sh if scale else None, residual=res if residual else None,
+                       relu=relu, splitk=1, w_layout=3, ws=ws, out=out, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            err = float((out.double() - ref).abs().max() / ref.abs().max())
+            assert err < 3e-5, (scale, residual, relu, tile, err)
+    with pytest.raises(RuntimeError):                                   # a workspace that cannot hold the transformed tensors
+        ops.conv2d(x, wW4, cout, 3, 1, 1, splitk=1, w_layout=3, ws=ws[:ws.numel() // 2])
+    with pytest.raises(RuntimeError):                                   # stride 2 is not a Winograd conv
+        ops.conv2d(x, wW4, cout, 3, 2, 1, splitk=1, w_layout=3, ws=ws)
+
+
+def test_trunk_with_and_without_winograd_f4x4():
+    """The same RN101 trunk with the wide 3x3 convs on F(4x4,3x3) (default) and on the fused F(2x2,3x3) kernel: every tap within 1e-4 of
+    its own scale (the oracle comparison of tests/test_configs_gpu.py runs with the default), and the form really switches (FLOP
+    accounting by kernel form)."""
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    torch.manual_seed(3)
+    ext = ResnetFeatureExtractor('resnet101').to(DEV)
+    img = torch.randint(0, 256, (4, 3, 480, 854), dtype=torch.uint8, device=DEV)
+    assert ext.winograd4
+    a = {k: v.clone() for k, v in ext(img).items()}
+    fa = list(ext.last_flops_form)
+    ext.winograd4 = False
+    b = {k: v.clone() for k, v in ext(img).items()}
+    fb = list(ext.last_flops_form)
+    assert fa[2] > 0 and fb[2] == 0 and abs(sum(fa) - sum(fb)) < 1e-6 * sum(fa)
+    assert abs(sum(fa) - ext.last_flops) < 1e-6 * sum(fa)
+    for k in a:
+        err = float((a[k] - b[k]).abs().max() / b[k].abs().max())
+        assert err < 1e-4, (k, err)
