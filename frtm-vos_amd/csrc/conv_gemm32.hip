@@ -55,7 +55,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv1x1_g32(const ConvParams
   tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, n_tile);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
+  const float* wbase = p.w_img_stride ? p.wT + (size_t)(n0 / p.Npix) * p.w_img_stride : p.wT;       // batched GEMM: one weight matrix per image
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
 
   // ---- per-thread global offsets of its 16-byte units: unit u = i * NT + tid; LDS image = unit order (lane-linear per wave instruction)

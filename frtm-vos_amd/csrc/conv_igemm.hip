@@ -477,6 +477,15 @@ int frtm_igemm_batched(const ConvParams& q, int tile, hipStream_t st) {
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(q, true, st); break;
     case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(q, true, st); break;
     case FRTM_TILE_64x64_8W: launch_tile<64, 64, 2, 4>(q, true, st); break;
+    case FRTM_TILE_64x128_8W:
+      if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 64x128 tile needs a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
+      launch_tile<64, 128, 2, 4>(q, true, st); break;
+    case FRTM_TILE_G32_64x64: case FRTM_TILE_G32_128x64: case FRTM_TILE_G32_64x64_S3: {
+      if (q.Mp % 4 || ((size_t)q.wT) % 16 || ((size_t)q.in) % 16) { frtm_set_error("frtm_igemm_batched: G32 tiles need 16-byte aligned operands"); return FRTM_ERR_ARG; }
+      int rc = frtm_g32_launch(q, tile, st);
+      if (rc) return rc;
+      break;
+    }
     default: frtm_set_error("frtm_igemm_batched: unknown tile %d", tile); return FRTM_ERR_ARG;
   }
   FRTM_LAUNCH_CHECK();
@@ -546,8 +555,6 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if (d->w_layout == FRTM_WLAYOUT_WINO4) {
     FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
                    "frtm_conv2d: the Winograd F(4x4,3x3) layout needs 3x3, stride 1, pad 1, NCHW output");
-    FRTM_CHECK_ARG(d->tile == 0 || d->tile == FRTM_TILE_64x64 || d->tile == FRTM_TILE_32x64 || d->tile == FRTM_TILE_64x64_8W || d->tile == FRTM_TILE_128x64,
-                   "frtm_conv2d: Winograd F(4x4,3x3): tile selects the GEMM tile (0 auto, 64x64, 32x64, 64x64 8 waves, 128x64)");
     return frtm_wino4_launch(p, workspace, (size_t)d->ws_elems, d->tile, (hipStream_t)stream);
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);

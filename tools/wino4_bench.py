@@ -22,7 +22,7 @@ for cin, cout, h, w in shapes:
     print('%d -> %d @ %dx%d x %d frames (%.2f GFLOP direct)' % (cin, cout, h, w, B, fl / 1e9))
     ws4 = ops.wino4_workspace(B, cin, cout, h, w, dev)
     cases = [('halo direct', dict(halo=True), 1, 0), ('wino F(2,3) fused', dict(wino=True), 2, 0)]
-    cases += [('wino F(4,3) ' + n, dict(wino4=True), 3, t) for n, t in (('auto', 0), ('64x64 4w', 1), ('32x64', 2), ('128x64', 3), ('64x64 8w', 4))]
+    cases += [('wino F(4,3) ' + n, dict(wino4=True), 3, t) for n, t in (('auto', 0), ('64x64 4w', 1), ('32x64', 2), ('128x64', 3), ('64x64 8w', 4), ('64x128 8w', 7), ('g32 64x64', 23), ('g32 128x64', 22), ('g32 64x64 s3', 26))]
     packs = {}
     for name, kw, lay, tile in cases:
         if lay not in packs:
