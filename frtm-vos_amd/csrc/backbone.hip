@@ -123,7 +123,8 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
   if (c.wW4 && bb->use_winograd && bb->use_winograd4) {
     const int th = ceil_div(*Ho, 4), tw = ceil_div(*Wo, 4);
     const long T = (long)B * th * tw, Tp = (T + 63) / 64 * 64;
-    if ((long)ceil_div(c.Cout, 64) * (36 * Tp / 64) >= 512 && (long)16 * th * tw * 4 <= (long)5 * (*Ho) * (*Wo)) {
+    if ((long)ceil_div(c.Cout, 64) * (36 * Tp / 64) >= 512 && (long)16 * th * tw * 4 <= (long)5 * (*Ho) * (*Wo) &&
+        (size_t)36 * std::max(c.Cin, c.Cout) * Tp * 4 < 0x7fffffffull) {       // (32-bit buffer offsets of the transformed tensors; else F(2x2))
       const size_t need = (size_t)36 * (c.Cin + c.Cout) * Tp;
       int rc = ensure(bb, &ln.ws4, &ln.ws4_elems, need);
       if (rc) return rc;
