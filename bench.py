@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument('--init-lanes', type=int, default=4, help='concurrent streams for the target-model fits of objects starting together')
     ap.add_argument('--no-windows', action='store_true', help='track frame by frame instead of one window per filter re-solve interval')
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convs on the direct (halo) kernels only')
+    ap.add_argument('--no-prefetch', action='store_true', help='dataset legs (--sequences, dataset_sim): preload each sequence before it is tracked instead of during the previous one')
     ap.add_argument('--no-winograd4', action='store_true', help='no Winograd F(4x4,3x3): the wide 3x3 convs stay on the fused F(2x2,3x3) kernel')
     ap.add_argument('--first-pass-overlap', action='store_true', help='first trunk pass on a side stream next to the fits of initialize()')
     ap.add_argument('--no-early-first-pass', action='store_true', help='first tracking trunk pass after initialize() instead of under its augmentation')
@@ -397,21 +398,22 @@ def build_sequences(specs, size):
     return [SyntheticSequence(name, L, size, n_obj, seed=seed) for name, L, n_obj, seed in specs]
 
 
-def run_dataset_shard(tracker, seqs, dev):
+def run_dataset_shard(tracker, seqs, dev, prefetch=True):
     """The reference's run_dataset loop (model/tracker.py:82-99) over this rank's sequences: sequence.preload(device) + run_sequence per
     sequence.  Returns the per-sequence frames/s as run_sequence reports them (initialize() included, preload not: tracker.py:130,159-161),
     total frames, total seconds of the loop (preloads included) and the update-work counters summed over the sequences."""
+    from frtm_vos_amd.lib.datasets import SequencePrefetcher
     fps, frames, agg = [], 0, {}
     t0 = time.time()
-    for seq in seqs:
-        seq.preload(dev)                                # (the reference's sequence.preload(device), tracker.py:91: inside the dataset loop)
+    # (the reference's sequence.preload(device), tracker.py:91, inside the dataset loop -- here for the NEXT sequence on a copy stream while
+    # this one is tracked, exactly as Tracker.run_dataset does it; --no-prefetch: one after the other)
+    for seq in SequencePrefetcher(seqs, dev, enabled=prefetch):
         out, f = tracker.run_sequence(seq)
         c = path_counters(tracker, seq, len(out))
         for k, v in c.items():
             agg[k] = (agg.get(k, True) and v) if isinstance(v, bool) else agg.get(k, 0) + v
         fps.append(f)
         frames += len(out)
-        seq.release()
     torch.cuda.synchronize()
     return fps, frames, time.time() - t0, agg
 
@@ -639,7 +641,7 @@ def main():
             dist.barrier()
     t0 = time.time()
     if shard_seqs is not None:
-        seq_fps, n_shard, _, shard_counters = run_dataset_shard(tracker, shard_seqs, dev)
+        seq_fps, n_shard, _, shard_counters = run_dataset_shard(tracker, shard_seqs, dev, prefetch=not args.no_prefetch)
         shard = dict(sequences=len(mine), sequence_ids=mine, mean_of_per_sequence_fps=sum(seq_fps) / max(len(seq_fps), 1))
         outputs = []
     else:
@@ -789,11 +791,11 @@ def main():
             # the headline above is ONE sequence; this is the dataset-level figure the reference's run_dataset prints (mean of the per-
             # sequence frames/s, model/tracker.py:94,101) over 30 dv2017-like sequences through the same tracker, first-use costs of new
             # shapes included, with the same counters of the update work
-            fps_l, fr, sec, cnt = run_dataset_shard(tracker, build_sequences(dataset_specs(30, size), size), dev)
+            fps_l, fr, sec, cnt = run_dataset_shard(tracker, build_sequences(dataset_specs(30, size), size), dev, prefetch=not args.no_prefetch)
             out['dataset_sim'] = {'sequences': len(fps_l), 'frames': fr, 'mean_of_per_sequence_fps': round(sum(fps_l) / len(fps_l), 1),
                                   'total_fps': round(fr / sec, 1), 'min_sequence_fps': round(min(fps_l), 1), 'max_sequence_fps': round(max(fps_l), 1),
                                   'path_counters': cnt,
-                                  'note': '30 synthetic dv2017val-like sequences (1-5 objects, mean 2.4; 34-104 frames; 480x854); total_fps = frames / wall of the loop incl. the host->device preload of every sequence (pageable memory) and the counter read-backs; mean_of_per_sequence_fps is what the reference prints'}
+                                  'note': '30 synthetic dv2017val-like sequences (1-5 objects, mean 2.4; 34-104 frames; 480x854); total_fps = frames / wall of the loop incl. the host->device preload of every sequence (pageable memory; %s) and the counter read-backs; mean_of_per_sequence_fps is what the reference prints' % ('one after the other' if args.no_prefetch else 'the next sequence on a copy stream while this one is tracked, lib/datasets.py: SequencePrefetcher')}
             _phase('dataset leg done')
         if not args.no_cg_roofline:
             out['roofline_cg'] = cg_roofline(dev, size)

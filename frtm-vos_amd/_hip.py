@@ -214,6 +214,12 @@ def require_gpu(t, what):
 _capture_stream = None
 
 
+# 'thread_local': only the capturing thread's own unsafe calls invalidate a capture.  The dataset loop's prefetch thread (lib/datasets.py:
+# SequencePrefetcher) allocates and copies the next sequence on its own stream while this thread may be capturing a window / trunk
+# graph; under 'global' (torch's default) its hipMalloc / pageable hipMemcpy ended the capture with hipErrorStreamCaptureInvalidated.
+CAPTURE_ERROR_MODE = 'thread_local'
+
+
 class capture:
     """``with capture(graph, pool=None):`` -- stream capture into a torch.cuda.CUDAGraph, like ``torch.cuda.graph`` but
 
@@ -246,9 +252,9 @@ class capture:
             self._ctx = torch.cuda.stream(_capture_stream)
             self._ctx.__enter__()
             if self.pool is not None:
-                self.graph.capture_begin(self.pool, capture_error_mode='global')
+                self.graph.capture_begin(self.pool, capture_error_mode=CAPTURE_ERROR_MODE)
             else:
-                self.graph.capture_begin(capture_error_mode='global')
+                self.graph.capture_begin(capture_error_mode=CAPTURE_ERROR_MODE)
         except BaseException:
             if self._ctx is not None:
                 self._ctx.__exit__(None, None, None)

@@ -73,6 +73,74 @@ class FileSequence:
         return '%s: %s, %d frames' % (self.dset_name, self.name, len(self.images))
 
 
+class SequencePrefetcher:
+    """Iterates over sequences with ``sequence.preload(device)`` of the NEXT one running on a copy stream, in a worker thread, while the
+    caller tracks the current one (the reference preloads and tracks one after the other, model/tracker.py:88-99): decoding and the
+    host -> device transfer of a sequence (30-110 frames, 40-170 MB at 480p) overlap with the previous sequence's tracking instead
+    of adding to the dataset's wall clock.  The yielded sequence is resident (its copy has completed for the caller's current stream);
+    the one before it is released when the loop comes back.  At most two sequences are on the device at a time.
+
+        for sequence in SequencePrefetcher(dataset, device):
+            tracker.run_sequence(sequence)
+    """
+
+    def __init__(self, sequences, device, enabled=True):
+        self.sequences, self.device = sequences, torch.device(device)
+        self.enabled = bool(enabled) and self.device.type == 'cuda'
+        self._stream = None
+
+    def _start(self, seq):
+        import threading
+        box = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self._stream):
+                    seq.preload(self.device)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                box['event'] = ev
+            except BaseException as e:                      # re-raised in the consumer
+                box['error'] = e
+        th = threading.Thread(target=work, name='frtm-prefetch', daemon=True)
+        th.start()
+        return th, box
+
+    def __iter__(self):
+        if not self.enabled:
+            for seq in self.sequences:
+                seq.preload(self.device)
+                try:
+                    yield seq
+                finally:
+                    if hasattr(seq, 'release'):
+                        seq.release()
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        it = iter(self.sequences)
+        cur = next(it, None)
+        pending = self._start(cur) if cur is not None else None
+        while cur is not None:
+            th, box = pending
+            th.join()
+            if 'error' in box:
+                raise box['error']
+            torch.cuda.current_stream(self.device).wait_event(box['event'])
+            nxt = next(it, None)
+            pending = self._start(nxt) if nxt is not None else None      # overlaps with whatever the caller does with `cur`
+            try:
+                yield cur
+            finally:
+                # the caller's work on `cur` must have left the GPU before its frames go back to the allocator (they were allocated
+                # on the copy stream, which would reuse them for the sequence after next)
+                torch.cuda.current_stream(self.device).synchronize()
+                if hasattr(cur, 'release'):
+                    cur.release()
+            cur = nxt
+
+
 def _select(all_seqs, sequences, restart):
     seqs = list(all_seqs)
     if sequences is not None:

@@ -102,6 +102,7 @@ class Tracker(nn.Module):
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
+        self.prefetch_sequences = True   # run_dataset: the next sequence is decoded / copied to the device while this one is tracked
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
         self.pipeline_passes = False     # two tap sets, passes one ahead on a side stream, a short pass before and a pass beside
                                          # initialize()'s fits (supersedes early_first_pass / overlap_first_pass / prefetch_stream)
@@ -170,13 +171,18 @@ class Tracker(nn.Module):
         out_path.mkdir(exist_ok=True, parents=True)
         dset_fps = AverageMeter()
         print('Evaluating', dataset.name)
-        restarted = False
-        for sequence in dataset:
-            if restart is not None and not restarted:
-                if sequence.name != restart:
-                    continue
-                restarted = True
-            sequence.preload(self.device)
+        from ..lib.datasets import SequencePrefetcher
+
+        def todo():
+            restarted = False
+            for sequence in dataset:
+                if restart is not None and not restarted:
+                    if sequence.name != restart:
+                        continue
+                    restarted = True
+                yield sequence
+        # sequence.preload(device) of the reference (:91) -- for the NEXT sequence, on a copy stream, while this one is tracked
+        for sequence in SequencePrefetcher(todo(), self.device, enabled=self.prefetch_sequences):
             self.clear()
             outputs, seq_fps = self.run_sequence(sequence, speedrun)
             dset_fps.update(seq_fps)

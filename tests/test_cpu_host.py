@@ -582,3 +582,28 @@ def test_warp_ref_against_grid_sample():
         assert float((out[:, :38, 3:] - src[:, 2:, :47]).abs().max()) < 1e-9 and float(out[:, 38:].abs().max()) == 0
     u8 = (src[0]).to(torch.uint8)
     assert torch.equal(warp_affine_ref(u8, eye, (40, 50), 'bilinear'), u8)
+
+
+def test_sequence_prefetcher_order_and_release_on_the_cpu():
+    """lib/datasets.py: SequencePrefetcher on a CPU device degrades to preload -> yield -> release, one sequence at a time, in order,
+    also when the consumer stops early."""
+    from frtm_vos_amd.lib.datasets import SequencePrefetcher
+    log = []
+
+    class Seq:
+        def __init__(self, k):
+            self.k = k
+
+        def preload(self, device):
+            log.append(('preload', self.k, str(device)))
+
+        def release(self):
+            log.append(('release', self.k))
+
+    got = [s.k for s in SequencePrefetcher((Seq(k) for k in range(3)), 'cpu')]
+    assert got == [0, 1, 2]
+    assert log == [('preload', 0, 'cpu'), ('release', 0), ('preload', 1, 'cpu'), ('release', 1), ('preload', 2, 'cpu'), ('release', 2)]
+    del log[:]
+    for s in SequencePrefetcher([Seq(0), Seq(1)], 'cpu'):
+        break
+    assert log == [('preload', 0, 'cpu'), ('release', 0)]

@@ -481,3 +481,42 @@ def test_trunk_with_and_without_winograd_f4x4():
     for k in a:
         err = float((a[k] - b[k]).abs().max() / b[k].abs().max())
         assert err < 1e-4, (k, err)
+
+
+def test_prefetched_dataset_loop_equals_the_sequential_one():
+    """SequencePrefetcher (the next sequence is copied to the device on a copy stream, in a worker thread, while the current one is
+    tracked): same label images as preload -> track -> release one after the other, every sequence released, errors of the worker
+    re-raised in the loop."""
+    from frtm_vos_amd.lib.datasets import SequencePrefetcher
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from test_north_star_gpu import _hip_tracker
+    import oracle.make_golden_jf as JF
+    torch.set_grad_enabled(False)
+    trk = _hip_tracker('resnet18', JF.refiner_for('resnet18'), fast=True)
+    size = (128, 160)
+
+    def seqs():
+        return [SyntheticSequence('pf%d' % k, 9 + 4 * k, size, 1 + k % 2, seed=70 + k) for k in range(4)]
+
+    def run(prefetch):
+        out = []
+        ss = seqs()
+        for s in SequencePrefetcher(ss, DEV, enabled=prefetch):
+            assert s.images[0].is_cuda
+            trk.start_weights = lambda oid, k=len(out): JF.start_weights(900 + k, oid, cin=256)
+            labels, _ = trk.run_sequence(s)
+            out.append(torch.stack([l.reshape(size) for l in labels]).cpu())
+        assert all(not s.images[0].is_cuda for s in ss)              # every sequence went back to the host
+        return out
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+    class Broken(SyntheticSequence):
+        def preload(self, device):
+            raise OSError('frame missing')
+
+    with pytest.raises(OSError):
+        for s in SequencePrefetcher([seqs()[0], Broken('bad', 5, size, 1, seed=1)], DEV):
+            pass
