@@ -102,6 +102,8 @@ class Tracker(nn.Module):
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
+        self.hold_gc = not os.environ.get('FRTM_NO_HOLD_GC')   # no cyclic garbage collection while a sequence is being enqueued (_run_sequence)
+        self._gc_frozen = False
         self.prefetch_sequences = True   # run_dataset: the next sequence is decoded / copied to the device while this one is tracked
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
         self.pipeline_passes = False     # two tap sets, passes one ahead on a side stream, a short pass before and a pass beside
@@ -239,6 +241,29 @@ class Tracker(nn.Module):
         return out
 
     def _run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
+        """_run_sequence_loop with the interpreter's cyclic garbage collector held off (``hold_gc``): the host enqueues a sequence's
+        few thousand launches AHEAD of the GPU (a 20-frame sequence: 17 ms of host work for 46 ms of GPU work), and a generation-2
+        collection of a PyTorch process (1.7e5 tracked objects here) stops it for 40-50 ms -- whenever one fell into a short sequence
+        the GPU ran dry and that sequence came out at 270-330 instead of 420 frames/s (the sporadic "slow runs" of rounds 2 and 3,
+        every GPU stage timer normal).  Reference counting still frees everything that is not a cycle; cycles wait for the end of the
+        sequence.  The first sequence of a tracker also moves the long-lived objects (modules, weights, graphs) into the permanent
+        generation (gc.freeze), so that collections between sequences only look at young objects."""
+        import gc
+        if not self.hold_gc:
+            return self._run_sequence_loop(sequence, speedrun, ytvos_merge)
+        if not self._gc_frozen:
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._run_sequence_loop(sequence, speedrun, ytvos_merge)
+        finally:
+            if was:
+                gc.enable()
+
+    def _run_sequence_loop(self, sequence, speedrun=False, ytvos_merge=False):
         """The loop of run_sequence on the current stream.
 
         ``ytvos_merge``: label decoding of the reference's YouTube-VOS validation fork instead (ytvos_validation/tracker.py:84-116):
