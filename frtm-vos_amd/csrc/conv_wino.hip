@@ -252,7 +252,10 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
     variant = a2 <= a3 ? 2 : 3;
     const long a = variant == 2 ? a2 : a3;
     const long blocks2 = (long)p.B * (a / 128) * mt;
-    if (mt > 1 || a * 100 > a1 * 115 || blocks2 < 512) variant = 1;     // measured: the 32-tile forms only pay for a single M tile
+    // measured (tools/wino2_tiles.py, round 3): one M tile -- always worth it from 512 blocks on; two M tiles (64 output channels: the
+    // refiner's convs and layer1) -- 7-12 % ahead on the large maps (16 x 64->64 @ 120x214: 199 vs 210 us, @ 60x107: 62-64 vs 67),
+    // behind on the small ones (@ 30x54: 20.7 vs 19.5); more M tiles: the 8x8 form
+    if (mt > 2 || a * 100 > a1 * 115 || blocks2 < (mt == 1 ? 512 : 1024)) variant = 1;
   }
   if (variant == 2) {
     k_conv3x3_wino<2, 0, 3><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);

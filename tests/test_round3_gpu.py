@@ -520,3 +520,33 @@ def test_prefetched_dataset_loop_equals_the_sequential_one():
     with pytest.raises(OSError):
         for s in SequencePrefetcher([seqs()[0], Broken('bad', 5, size, 1, seed=1)], DEV):
             pass
+
+
+def test_the_garbage_collector_is_held_off_during_a_sequence_and_restored_after():
+    """Tracker.hold_gc: no cyclic collection while a sequence is enqueued (a generation-2 pass of the process takes as long as a whole
+    20-frame sequence); the collector's state is the caller's again afterwards, also when the sequence raises."""
+    import gc
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from test_north_star_gpu import _hip_tracker
+    import oracle.make_golden_jf as JF
+    torch.set_grad_enabled(False)
+    trk = _hip_tracker('resnet18', JF.refiner_for('resnet18'), fast=True)
+    seen = []
+    inner = trk._run_sequence_loop
+    trk._run_sequence_loop = lambda *a, **k: (seen.append(gc.isenabled()), inner(*a, **k))[1]
+    seq = SyntheticSequence('gc', 6, (128, 160), 1, seed=3)
+    seq.preload(DEV)
+    assert gc.isenabled()
+    trk.run_sequence(seq)
+    assert seen == [False] and gc.isenabled() and trk._gc_frozen
+    trk.hold_gc = False
+    trk.run_sequence(seq)
+    assert seen == [False, True] and gc.isenabled()
+    trk.hold_gc = True
+
+    def boom(*a, **k):
+        raise RuntimeError('x')
+    trk._run_sequence_loop = boom
+    with pytest.raises(RuntimeError):
+        trk.run_sequence(seq)
+    assert gc.isenabled()
