@@ -480,6 +480,13 @@ int frtm_igemm_batched(const ConvParams& q, int tile, hipStream_t st) {
     case FRTM_TILE_64x128_8W:
       if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 64x128 tile needs a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
       launch_tile<64, 128, 2, 4>(q, true, st); break;
+    case FRTM_TILE_128x128_8W: case FRTM_TILE_128x128_16W:
+      if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 128x128 tiles need a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
+      if (tile == FRTM_TILE_128x128_8W) launch_tile<128, 128, 2, 4>(q, true, st); else launch_tile<128, 128, 4, 4>(q, true, st);
+      break;
+    case FRTM_TILE_G32_128x128:
+      if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 128x128 tiles need a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
+      // fall through
     case FRTM_TILE_G32_64x64: case FRTM_TILE_G32_128x64: case FRTM_TILE_G32_64x64_S3: {
       if (q.Mp % 4 || ((size_t)q.wT) % 16 || ((size_t)q.in) % 16) { frtm_set_error("frtm_igemm_batched: G32 tiles need 16-byte aligned operands"); return FRTM_ERR_ARG; }
       int rc = frtm_g32_launch(q, tile, st);

@@ -10,7 +10,7 @@ from frtm_vos_amd import ops
 
 dev = 'cuda:0'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-shapes = [(256, 256, 30, 54), (128, 128, 60, 107), (512, 512, 15, 27), (64, 64, 120, 214)]
+shapes = [(256, 256, 30, 54), (128, 128, 60, 107), (512, 512, 15, 27), (64, 64, 120, 214)][:int(os.environ.get('W4_SHAPES', '4'))]
 g = torch.Generator().manual_seed(0)
 for cin, cout, h, w in shapes:
     x = torch.relu(torch.randn(B, cin, h, w, generator=g)).to(dev)
@@ -22,7 +22,7 @@ for cin, cout, h, w in shapes:
     print('%d -> %d @ %dx%d x %d frames (%.2f GFLOP direct)' % (cin, cout, h, w, B, fl / 1e9))
     ws4 = ops.wino4_workspace(B, cin, cout, h, w, dev)
     cases = [('halo direct', dict(halo=True), 1, 0), ('wino F(2,3) fused', dict(wino=True), 2, 0)]
-    cases += [('wino F(4,3) ' + n, dict(wino4=True), 3, t) for n, t in (('auto', 0), ('64x64 4w', 1), ('32x64', 2), ('128x64', 3), ('64x64 8w', 4), ('64x128 8w', 7), ('g32 64x64', 23), ('g32 128x64', 22), ('g32 64x64 s3', 26))]
+    cases += [('wino F(4,3) ' + n, dict(wino4=True), 3, t) for n, t in (('auto', 0), ('64x64 4w', 1), ('32x64', 2), ('128x64', 3), ('64x64 8w', 4), ('64x128 8w', 7), ('g32 64x64', 23), ('g32 128x64', 22), ('g32 64x64 s3', 26), ('128x128 8w', 8), ('128x128 16w', 9), ('g32 128x128', 20))]
     packs = {}
     for name, kw, lay, tile in cases:
         if lay not in packs:
