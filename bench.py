@@ -709,9 +709,10 @@ def main():
 
     exec_flops = sum(getattr(ext, 'pass_exec_flops', []) or [0.0])
     exec_ratio = (exec_flops / flops_total) if (flops_total > 0 and exec_flops > 0) else 1.0
-    form = [sum(f[k] for f in (getattr(ext, 'pass_form_flops', []) or [[0.0, 0.0, 0.0]])) for k in range(3)]
-    wino_share = round((form[1] + form[2]) / max(sum(form), 1.0), 4)
+    form = [sum(f[k] for f in (getattr(ext, 'pass_form_flops', []) or [[0.0, 0.0, 0.0, 0.0]])) for k in range(4)]
+    wino_share = round((form[1] + form[2] + form[3]) / max(sum(form), 1.0), 4)
     wino4_share = round(form[2] / max(sum(form), 1.0), 4)
+    wino6_share = round(form[3] / max(sum(form), 1.0), 4)
     sq_busy = None
     for cand in ('r03_sq_busy.json', 'r02_sq_busy.json'):
         sf = os.path.join(ROOT, 'profiles', cand)
@@ -742,18 +743,19 @@ def main():
                                 'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.memory,
                                 'seeded default init, no confident masks' if args.random_refiner else 'seeded default init + score-following channel',
                                 args.trunk_batch, args.trunk_lanes,
-                                ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else ('Winograd F(2x2,3x3)' if args.no_winograd4 else 'Winograd F(4x4,3x3) from 128 channels on, F(2x2,3x3) below')),
+                                ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else ('Winograd F(2x2,3x3)' if args.no_winograd4 else 'Winograd F(6x6,3x3) / F(4x4,3x3) from 128 channels on, F(2x2,3x3) below')),
                    'warmup_frames_run': sum(max(w, 2) for w in warm_lengths),
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino / k_wino4_* (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
                      # `frac` counts ALGORITHMIC (direct-form) FLOPs.  The 3x3 stride-1 convs of large launches run as Winograd F(2x2,3x3)
-                     # (16 instead of 36 multiplications per 2x2 outputs) or, from 128 channels on, F(4x4,3x3) (36 instead of 144 per 4x4
-                     # outputs), so the MACs the matrix pipes EXECUTE are fewer.  frac_executed
+                     # (16 instead of 36 multiplications per 2x2 outputs) or, from 128 channels on, F(4x4,3x3) / F(6x6,3x3) (36 instead of 144 per 4x4
+                     # outputs, 64 instead of 324 per 6x6), so the MACs the matrix pipes EXECUTE are fewer.  frac_executed
                      # counts those (frtm_backbone_last_flops_executed); mfma_pipe_busy is the SQ counter ratio of the committed PMC pass
                      # over the same kernels (profiles/*_sq_busy.json: SQ_VALU_MFMA_BUSY_CYCLES / active cycles, every kernel alone).
                      'achieved_executed': achieved * exec_ratio, 'frac_executed': achieved * exec_ratio / PEAK_F32_TFLOPS,
                      'winograd_share_of_algorithmic_flops': wino_share, 'winograd_f4x4_share_of_algorithmic_flops': wino4_share,
+                     'winograd_f6x6_share_of_algorithmic_flops': wino6_share,
                      'mfma_pipe_busy': sq_busy,
                      # v_mfma_f32_16x16x4_f32 (the instruction of these kernels) sustains 123-139 TFLOP/s with register operands and nothing
                      # else in the loop, v_mfma_f32_32x32x2_f32 155 (tools/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt): `peak` stays the

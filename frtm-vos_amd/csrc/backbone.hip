@@ -14,6 +14,7 @@ struct ConvL {
   float* wT = nullptr; float* scale = nullptr; float* shift = nullptr; int* ktab = nullptr;
   float* wW = nullptr;          // 3x3 stride-1 convs: second image of the weights, Winograd F(2x2,3x3) (FRTM_WLAYOUT_WINO3X3)
   float* wW4 = nullptr;         // ... with >= 128 channels: third image, the 36 matrices of Winograd F(4x4,3x3) (FRTM_WLAYOUT_WINO4)
+  float* wW6 = nullptr;         // ... and the 64 matrices of F(6x6,3x3) (FRTM_WLAYOUT_WINO6)
   bool loaded = false;
   int layout = 0;
 };
@@ -40,11 +41,12 @@ struct frtm_backbone {
   int nlanes = 1;
   hipEvent_t fork = nullptr;
   double last_flops = 0.0;
-  double last_flops_form[3] = {0.0, 0.0, 0.0};   // algorithmic FLOPs of the last pass by kernel form: direct, Winograd F(2x2,3x3), F(4x4,3x3)
+  double last_flops_form[4] = {0.0, 0.0, 0.0, 0.0};   // algorithmic FLOPs of the last pass by kernel form: direct, Winograd F(2x2,3x3), F(4x4,3x3), F(6x6,3x3)
   double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (F(2x2,3x3): 16 per 2x2 outputs instead of 36; F(4x4,3x3): 36 per 4x4 tile instead of 144, partial edge tiles included)
   int last_launches = 0;
   bool use_winograd = true;
-  bool use_winograd4 = getenv("FRTM_NO_WINO4") == nullptr;     // F(4x4,3x3) in three launches where it is eligible (run_conv)
+  // three-launch Winograd where it is eligible (run_conv): 0 = off, 1 = F(4x4,3x3) only, 2 = F(4x4,3x3) or F(6x6,3x3), whichever has fewer products
+  int use_winograd4 = getenv("FRTM_NO_WINO4") ? 0 : getenv("FRTM_NO_WINO6") ? 1 : 2;
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
@@ -116,24 +118,33 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
   d.ws_elems = (int)std::min<size_t>(ln.ws_elems, 0x7fffffff);
   bb->last_launches += 1;
   bb->last_flops += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;      // algorithmic (direct-form) FLOPs
-  // Winograd F(4x4,3x3), three-launch form (conv_wino4.hip), for the wide 3x3 stride-1 convs: 2.25 multiplications per output
-  // instead of 4; eligible when the 36 products fill the chip as one GEMM launch and the 4x4 output tiles waste < 25 % on the
-  // map's edges (30x54 -> 32x56: 10.6 %).  Measured at 8 frames (tools/wino4_bench.py): 256 ch 30x54 70 vs 100 us, 512 ch 15x27
-  // 69 vs 110, 128 ch 60x107 85 vs 104; 64 ch 120x214 is slower (138 vs 108: K = 64 GEMMs, transform traffic) and stays F(2x2).
+  // Winograd F(4x4,3x3) / F(6x6,3x3), three-launch form (conv_wino4.hip), for the wide 3x3 stride-1 convs: 2.25 / 1.78 multiplications
+  // per output instead of 4; eligible when the products fill the chip as one GEMM launch and the output tiles waste < 25 % on the
+  // map's edges; of the two, the form with fewer products = (m+2)^2 x padded tile count (30x54: 6x6 tiles fit exactly, 64 x 384 against
+  // 36 x 896 at 8 frames).  Measured at 8 frames (tools/wino4_bench.py): 256 ch 30x54 62 (F6) / 69 (F4) vs 100 us fused F(2x2), 512 ch
+  // 15x27 58 / 68 vs 105, 128 ch 60x107 76 / 85 vs 101; 64 ch 120x214 is slower (128 / 145 vs 108: K = 64 GEMMs, transform traffic).
   if (c.wW4 && bb->use_winograd && bb->use_winograd4) {
-    const int th = ceil_div(*Ho, 4), tw = ceil_div(*Wo, 4);
-    const long T = (long)B * th * tw, Tp = (T + 63) / 64 * 64;
-    if ((long)ceil_div(c.Cout, 64) * (36 * Tp / 64) >= 512 && (long)16 * th * tw * 4 <= (long)5 * (*Ho) * (*Wo) &&
-        (size_t)36 * std::max(c.Cin, c.Cout) * Tp * 4 < 0x7fffffffull) {       // (32-bit buffer offsets of the transformed tensors; else F(2x2))
-      const size_t need = (size_t)36 * (c.Cin + c.Cout) * Tp;
+    int best_m = 0; long best_cost = 0, best_T = 0, best_Tp = 0;
+    for (int m : {6, 4}) {
+      if (m == 6 && (bb->use_winograd4 < 2 || !c.wW6)) continue;
+      const int th = ceil_div(*Ho, m), tw = ceil_div(*Wo, m), NP = (m + 2) * (m + 2);
+      const long T = (long)B * th * tw, Tp = (T + 63) / 64 * 64;
+      if ((long)ceil_div(c.Cout, 64) * (NP * Tp / 64) < 512 || (long)m * m * th * tw * 4 > (long)5 * (*Ho) * (*Wo) ||
+          (size_t)NP * std::max(c.Cin, c.Cout) * Tp * 4 >= 0x7fffffffull)       // (32-bit buffer offsets of the transformed tensors)
+        continue;
+      if (!best_m || NP * Tp < best_cost) { best_m = m; best_cost = NP * Tp; best_T = T; best_Tp = Tp; }
+    }
+    if (best_m) {
+      const int NP = (best_m + 2) * (best_m + 2);
+      const size_t need = (size_t)NP * (c.Cin + c.Cout) * best_Tp;
       int rc = ensure(bb, &ln.ws4, &ln.ws4_elems, need);
       if (rc) return rc;
-      d.w_layout = FRTM_WLAYOUT_WINO4;
+      d.w_layout = best_m == 6 ? FRTM_WLAYOUT_WINO6 : FRTM_WLAYOUT_WINO4;
       d.splitk = 1;
       d.ws_elems = (int)std::min<size_t>(ln.ws4_elems, 0x7fffffff);
-      bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * 36.0 * (double)T;
-      bb->last_flops_form[2] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
-      return frtm_conv2d(&d, in, c.wW4, nullptr, c.scale, c.shift, residual, out, ln.ws4, st);
+      bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * NP * (double)best_T;
+      bb->last_flops_form[best_m == 6 ? 3 : 2] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
+      return frtm_conv2d(&d, in, best_m == 6 ? c.wW6 : c.wW4, nullptr, c.scale, c.shift, residual, out, ln.ws4, st);
     }
   }
   // Winograd for the 3x3 stride-1 convs whenever the launch has enough 8x8 output blocks to fill the chip without split-K
@@ -280,6 +291,7 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
     if (c.wT) (void)hipFree(c.wT);
     if (c.wW) (void)hipFree(c.wW);
     if (c.wW4) (void)hipFree(c.wW4);
+    if (c.wW6) (void)hipFree(c.wW6);
     if (c.scale) (void)hipFree(c.scale);
     if (c.shift) (void)hipFree(c.shift);
     if (c.ktab) (void)hipFree(c.ktab);
@@ -329,6 +341,9 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
       if (!c.wW4) FRTM_HIP(hipMalloc((void**)&c.wW4, (size_t)FRTM_CONV_WINO4_ELEMS(c.Cout, c.Cin) * sizeof(float)));
       rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, 3, FRTM_WLAYOUT_WINO4, c.wW4, nullptr, stream);
       if (rc) return rc;
+      if (!c.wW6) FRTM_HIP(hipMalloc((void**)&c.wW6, (size_t)FRTM_CONV_WINO6_ELEMS(c.Cout, c.Cin) * sizeof(float)));
+      rc = frtm_conv_pack_weights(w_oihw, c.Cout, c.Cin, 3, FRTM_WLAYOUT_WINO6, c.wW6, nullptr, stream);
+      if (rc) return rc;
     }
   }
   FRTM_HIP(hipMemcpyAsync(c.scale, bn_scale, c.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -339,7 +354,7 @@ int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, co
 
 double frtm_backbone_last_flops(const frtm_backbone_t* bb) { return bb ? bb->last_flops : 0.0; }
 double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb) { return bb ? bb->last_flops_exec : 0.0; }
-double frtm_backbone_last_flops_form(const frtm_backbone_t* bb, int form) { return (bb && form >= 0 && form < 3) ? bb->last_flops_form[form] : 0.0; }
+double frtm_backbone_last_flops_form(const frtm_backbone_t* bb, int form) { return (bb && form >= 0 && form < 4) ? bb->last_flops_form[form] : 0.0; }
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb) { return bb ? bb->last_launches : 0; }
 int frtm_backbone_generation(const frtm_backbone_t* bb) { return bb ? bb->generation : 0; }
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
@@ -350,7 +365,7 @@ int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable) {
 
 int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable) {
   FRTM_CHECK_ARG(bb, "frtm_backbone_set_winograd4: null handle");
-  bb->use_winograd4 = enable != 0;
+  bb->use_winograd4 = enable < 0 ? 0 : enable > 2 ? 2 : enable;
   return FRTM_OK;
 }
 
@@ -375,7 +390,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
   hipStream_t st = (hipStream_t)stream;
   bb->last_flops = 0.0;
   bb->last_flops_exec = 0.0;
-  bb->last_flops_form[0] = bb->last_flops_form[1] = bb->last_flops_form[2] = 0.0;
+  bb->last_flops_form[0] = bb->last_flops_form[1] = bb->last_flops_form[2] = bb->last_flops_form[3] = 0.0;
   bb->last_launches = 0;
   const int L = std::min(bb->nlanes, B);
   // the conv kernels address activations with 32-bit byte offsets: at most this many images per forward_lane call

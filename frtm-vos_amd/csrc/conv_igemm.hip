@@ -25,8 +25,8 @@
 int frtm_wino_pack(const float* w_oihw, int Cout, int Cin, float* wT, hipStream_t st);
 int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st);
 // conv_wino4.hip
-int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, hipStream_t st);
-int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, hipStream_t st);
+int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, int m, hipStream_t st);
+int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, int m, hipStream_t st);
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
 // FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
@@ -508,9 +508,9 @@ int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, in
     FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd layout is for 3x3 kernels");
     return frtm_wino_pack(w_oihw, Cout, Cin, wT, (hipStream_t)stream);
   }
-  if (layout == FRTM_WLAYOUT_WINO4) {
-    FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd F(4x4,3x3) layout is for 3x3 kernels");
-    return frtm_wino4_pack(w_oihw, Cout, Cin, wT, (hipStream_t)stream);
+  if (layout == FRTM_WLAYOUT_WINO4 || layout == FRTM_WLAYOUT_WINO6) {
+    FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the Winograd F(4x4,3x3) / F(6x6,3x3) layouts are for 3x3 kernels");
+    return frtm_wino4_pack(w_oihw, Cout, Cin, wT, layout == FRTM_WLAYOUT_WINO6 ? 6 : 4, (hipStream_t)stream);
   }
   if (layout == FRTM_WLAYOUT_HALO3X3) {
     FRTM_CHECK_ARG(ksize == 3, "frtm_conv_pack_weights: the halo layout is for 3x3 kernels");
@@ -559,10 +559,10 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 3, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8)");
     return frtm_wino_launch(p, d->tile, (hipStream_t)stream);
   }
-  if (d->w_layout == FRTM_WLAYOUT_WINO4) {
+  if (d->w_layout == FRTM_WLAYOUT_WINO4 || d->w_layout == FRTM_WLAYOUT_WINO6) {
     FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
-                   "frtm_conv2d: the Winograd F(4x4,3x3) layout needs 3x3, stride 1, pad 1, NCHW output");
-    return frtm_wino4_launch(p, workspace, (size_t)d->ws_elems, d->tile, (hipStream_t)stream);
+                   "frtm_conv2d: the Winograd F(4x4,3x3) / F(6x6,3x3) layouts need 3x3, stride 1, pad 1, NCHW output");
+    return frtm_wino4_launch(p, workspace, (size_t)d->ws_elems, d->tile, d->w_layout == FRTM_WLAYOUT_WINO6 ? 6 : 4, (hipStream_t)stream);
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");

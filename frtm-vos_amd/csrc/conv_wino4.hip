@@ -53,6 +53,146 @@ __global__ __launch_bounds__(256) void k_wino4_weights(const float* __restrict__
   }
 }
 
+// F(6x6,3x3): points 0, +-1, +-2, +-1/2, inf.  rows of G: (1,0,0) (-2/9,-2/9,-2/9) (-2/9,2/9,-2/9) (1/90,1/45,2/45) (1/90,-1/45,2/45)
+// (32/45,16/45,8/45) (32/45,-16/45,8/45) (0,0,1)
+__device__ __forceinline__ void g8(const double g0, const double g1, const double g2, double* u) {
+  u[0] = g0;
+  u[1] = -2.0 * (g0 + g1 + g2) / 9.0;
+  u[2] = -2.0 * (g0 - g1 + g2) / 9.0;
+  u[3] = g0 / 90.0 + g1 / 45.0 + 2.0 * g2 / 45.0;
+  u[4] = g0 / 90.0 - g1 / 45.0 + 2.0 * g2 / 45.0;
+  u[5] = 32.0 * g0 / 45.0 + 16.0 * g1 / 45.0 + 8.0 * g2 / 45.0;
+  u[6] = 32.0 * g0 / 45.0 - 16.0 * g1 / 45.0 + 8.0 * g2 / 45.0;
+  u[7] = g2;
+}
+
+__global__ __launch_bounds__(256) void k_wino6_weights(const float* __restrict__ w, int Cout, int Cin, int Kp, int Mp, float* __restrict__ U) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * Cin) return;
+  const int co = i / Cin, ci = i - co * Cin;
+  double t[8][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    double u[8];
+    g8((double)w[(size_t)i * 9 + b], (double)w[(size_t)i * 9 + 3 + b], (double)w[(size_t)i * 9 + 6 + b], u);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) t[a][b] = u[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    double u[8];
+    g8(t[a][0], t[a][1], t[a][2], u);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) U[((size_t)(a * 8 + b) * Kp + ci) * Mp + co] = (float)u[b];
+  }
+}
+
+// one dimension of B^T d B, F(6x6,3x3)
+__device__ __forceinline__ void bt8(const float* d, float* o) {
+  o[0] = d[0] - d[6] + (d[4] - d[2]) * 5.25f;
+  const float t1 = d[2] + d[6] - d[4] * 4.25f, t2 = d[1] + d[5] - d[3] * 4.25f;
+  o[1] = t1 + t2;
+  o[2] = t1 - t2;
+  const float t3 = d[6] + d[2] * 0.25f - d[4] * 1.25f, t4 = d[1] * 0.5f - d[3] * 2.5f + d[5] * 2.f;
+  o[3] = t3 + t4;
+  o[4] = t3 - t4;
+  const float t5 = d[6] + (d[2] - d[4] * 1.25f) * 4.f, t6 = d[1] * 2.f - d[3] * 2.5f + d[5] * 0.5f;
+  o[5] = t5 + t6;
+  o[6] = t5 - t6;
+  o[7] = d[7] - d[1] + (d[3] - d[5]) * 5.25f;
+}
+
+// one dimension of A^T m A, F(6x6,3x3)
+__device__ __forceinline__ void at6(const float* m, float* o) {
+  const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+  o[0] = m[0] + s12 + s34 + s56;
+  o[1] = d12 + 2.f * d34 + 0.5f * d56;
+  o[2] = s12 + 4.f * s34 + 0.25f * s56;
+  o[3] = d12 + 8.f * d34 + 0.125f * d56;
+  o[4] = s12 + 16.f * s34 + 0.0625f * s56;
+  o[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
+}
+
+// ---- the F(6x6,3x3) transforms: as k_wino4_input / k_wino4_output with 8x8 patches, 64 planes and 6x6 output tiles ----
+__global__ __launch_bounds__(256) void k_wino6_input(const float* __restrict__ in, int C, int H, int W, int th, int tw, int T, int Tp,
+                                                      float* __restrict__ V) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= Tp) return;
+  const size_t plane = (size_t)C * Tp;
+  float* vp = V + (size_t)c * Tp + t;
+  if (t >= T) {
+#pragma unroll
+    for (int xi = 0; xi < 64; ++xi) vp[xi * plane] = 0.f;
+    return;
+  }
+  const int tx = t % tw, r = t / tw, ty = r % th, b = r / th;
+  const float* ip = in + ((size_t)b * C + c) * H * W;
+  const int y0 = 6 * ty - 1, x0 = 6 * tx - 1;
+  float m[8][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                       // columns: B^T d  (a column of the patch at a time: 8 loads, 8 results)
+    const int x = x0 + j;
+    const bool xok = (unsigned)x < (unsigned)W;
+    float d[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int y = y0 + i;
+      d[i] = (xok && (unsigned)y < (unsigned)H) ? ip[(size_t)y * W + x] : 0.f;
+    }
+    bt8(d, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                       // rows: (.) B
+    float o[8];
+    bt8(m[i], o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vp[(size_t)(i * 8 + j) * plane] = o[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wino6_output(const float* __restrict__ Mb, int C, int H, int W, int th, int tw, int T, int Tp,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ residual, int relu, float* __restrict__ out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= T) return;
+  const size_t plane = (size_t)C * Tp;
+  const float* mp = Mb + (size_t)c * Tp + t;
+  float y[6][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                       // columns: A^T M
+    float mm[8], o[6];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm[i] = mp[(size_t)(i * 8 + j) * plane];
+    at6(mm, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i][j] = o[i];
+  }
+  const int tx = t % tw, r = t / tw, ty = r % th, b = r / th;
+  const float sa = scale ? scale[c] : 1.f, sb = scale ? shift[c] : 0.f;
+  const size_t base = ((size_t)b * C + c) * H * W;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int yy = 6 * ty + i;
+    if (yy >= H) break;
+    float o[6];
+    at6(y[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int xx = 6 * tx + j;
+      if (xx >= W) break;
+      const size_t idx = base + (size_t)yy * W + xx;
+      float v = o[j] * sa + sb;
+      if (residual) v += residual[idx];
+      if (relu) v = fmaxf(v, 0.f);
+      out[idx] = v;
+    }
+  }
+}
+
 // one dimension of B^T d B
 __device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5, float* o) {
   const float a = d4 - 4.f * d2, b = d3 - 4.f * d1, c = d4 - d2, e = 2.f * (d3 - d1);
@@ -160,39 +300,44 @@ __global__ __launch_bounds__(256) void k_wino4_output(const float* __restrict__ 
 
 }  // namespace
 
-int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, hipStream_t st) {
-  const int Kp = (Cin + 31) / 32 * 32, Mp = (Cout + 31) / 32 * 32;
-  FRTM_HIP(hipMemsetAsync(U, 0, (size_t)36 * Kp * Mp * sizeof(float), st));
-  k_wino4_weights<<<ceil_div(Cout * Cin, 256), 256, 0, st>>>(w_oihw, Cout, Cin, Kp, Mp, U);
+// m = 4: F(4x4,3x3), 36 matrices; m = 6: F(6x6,3x3), 64 matrices
+int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, int m, hipStream_t st) {
+  const int Kp = (Cin + 31) / 32 * 32, Mp = (Cout + 31) / 32 * 32, NP = (m + 2) * (m + 2);
+  FRTM_HIP(hipMemsetAsync(U, 0, (size_t)NP * Kp * Mp * sizeof(float), st));
+  if (m == 6) k_wino6_weights<<<ceil_div(Cout * Cin, 256), 256, 0, st>>>(w_oihw, Cout, Cin, Kp, Mp, U);
+  else k_wino4_weights<<<ceil_div(Cout * Cin, 256), 256, 0, st>>>(w_oihw, Cout, Cin, Kp, Mp, U);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
 
-// p: the conv's own parameters (in / out / scale / shift / residual / relu filled in by frtm_conv2d); U from frtm_wino4_pack;
-// ws: at least FRTM_CONV_WINO4_WS_ELEMS(B, Cin, Cout, H, W) floats.
-int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, hipStream_t st) {
-  const int H = p.Hin, W = p.Win, th = ceil_div(H, 4), tw = ceil_div(W, 4);
+// p: the conv's own parameters (in / out / scale / shift / residual / relu filled in by frtm_conv2d); U from frtm_wino4_pack(m);
+// ws: at least FRTM_CONV_WINO4_WS_ELEMS / FRTM_CONV_WINO6_WS_ELEMS(B, Cin, Cout, H, W) floats.
+int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, int m, hipStream_t st) {
+  const int NP = (m + 2) * (m + 2);
+  const int H = p.Hin, W = p.Win, th = ceil_div(H, m), tw = ceil_div(W, m);
   const int T = p.B * th * tw, Tp = (T + 63) / 64 * 64;
   const int Kp = (p.Cin + 31) / 32 * 32;
-  const size_t need = (size_t)36 * (p.Cin + p.M) * Tp;
-  FRTM_CHECK_ARG(ws && ws_elems >= need, "frtm_conv2d: the Winograd F(4x4,3x3) layout needs a workspace of %zu floats (got %zu)", need, ws_elems);
-  FRTM_CHECK_ARG((size_t)36 * std::max(p.Cin, p.M) * Tp * 4 < 0x7fffffffull, "frtm_conv2d: Winograd F(4x4,3x3): transformed tensor beyond 32-bit buffer offsets");
+  const size_t need = (size_t)NP * (p.Cin + p.M) * Tp;
+  FRTM_CHECK_ARG(ws && ws_elems >= need, "frtm_conv2d: the Winograd F(%dx%d,3x3) layout needs a workspace of %zu floats (got %zu)", m, m, need, ws_elems);
+  FRTM_CHECK_ARG((size_t)NP * std::max(p.Cin, p.M) * Tp * 4 < 0x7fffffffull, "frtm_conv2d: Winograd F(%dx%d,3x3): transformed tensor beyond 32-bit buffer offsets", m, m);
   float* V = ws;
-  float* Mb = ws + (size_t)36 * p.Cin * Tp;
+  float* Mb = ws + (size_t)NP * p.Cin * Tp;
   dim3 g(ceil_div(Tp, 256), p.Cin);
-  k_wino4_input<<<g, 256, 0, st>>>(p.in, p.Cin, H, W, th, tw, T, Tp, V);
+  if (m == 6) k_wino6_input<<<g, 256, 0, st>>>(p.in, p.Cin, H, W, th, tw, T, Tp, V);
+  else k_wino4_input<<<g, 256, 0, st>>>(p.in, p.Cin, H, W, th, tw, T, Tp, V);
   FRTM_LAUNCH_CHECK();
   ConvParams q = {};
   q.in = V; q.wT = p.wT; q.out = Mb;
-  q.B = 36; q.Cin = p.Cin; q.Hin = 1; q.Win = Tp; q.M = p.M; q.Mp = p.Mp; q.Ho = 1; q.Wo = Tp; q.K = p.Cin; q.stride = 1; q.pad = 0;
-  q.Npix = Tp; q.Ntot = 36 * Tp; q.splitk = 1; q.nchunks = Kp / 32; q.chunks_per_split = q.nchunks;
-  q.in_bytes = (unsigned)((size_t)36 * p.Cin * Tp * 4);
+  q.B = NP; q.Cin = p.Cin; q.Hin = 1; q.Win = Tp; q.M = p.M; q.Mp = p.Mp; q.Ho = 1; q.Wo = Tp; q.K = p.Cin; q.stride = 1; q.pad = 0;
+  q.Npix = Tp; q.Ntot = NP * Tp; q.splitk = 1; q.nchunks = Kp / 32; q.chunks_per_split = q.nchunks;
+  q.in_bytes = (unsigned)((size_t)NP * p.Cin * Tp * 4);
   q.w_bytes = (unsigned)((size_t)Kp * p.Mp * 4);
   q.w_img_stride = Kp * p.Mp;
   int rc = frtm_igemm_batched(q, tile, st);
   if (rc) return rc;
   dim3 go(ceil_div(T, 256), p.M);
-  k_wino4_output<<<go, 256, 0, st>>>(Mb, p.M, H, W, th, tw, T, Tp, p.scale, p.shift, p.residual, p.relu, p.out);
+  if (m == 6) k_wino6_output<<<go, 256, 0, st>>>(Mb, p.M, H, W, th, tw, T, Tp, p.scale, p.shift, p.residual, p.relu, p.out);
+  else k_wino4_output<<<go, 256, 0, st>>>(Mb, p.M, H, W, th, tw, T, Tp, p.scale, p.shift, p.residual, p.relu, p.out);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }

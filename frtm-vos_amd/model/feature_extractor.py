@@ -147,7 +147,7 @@ class ResnetFeatureExtractor:
         self.device = None
         self.last_flops = 0.0
         self.last_flops_executed = 0.0
-        self.last_flops_form = [0.0, 0.0, 0.0]
+        self.last_flops_form = [0.0, 0.0, 0.0, 0.0]
         self.last_conv_launches = 0
         self.reuse_outputs = False     # True: tap tensors are persistent per (batch, size) and overwritten by the next call
         self._out_cache = {}
@@ -157,6 +157,7 @@ class ResnetFeatureExtractor:
         self._lanes = 1
         self._winograd = True
         self._winograd4 = not os.environ.get('FRTM_NO_WINO4')
+        self._winograd6 = not os.environ.get('FRTM_NO_WINO6')
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
         self.capture_after = 1         # trunk shapes are replayed as hipGraphs from their (capture_after + 1)-th use on
         self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
@@ -185,11 +186,26 @@ class ResnetFeatureExtractor:
         """The wide 3x3 stride-1 convs (>= 128 channels) as Winograd F(4x4,3x3) in three launches (frtm_backbone_set_winograd4)."""
         return self._winograd4
 
+    def _wino_mode(self):
+        return 0 if not self._winograd4 else 2 if self._winograd6 else 1
+
     @winograd4.setter
     def winograd4(self, on):
         self._winograd4 = bool(on)
         if self._handle is not None:
-            H.call_nostream('frtm_backbone_set_winograd4', self._handle, int(self._winograd4))
+            H.call_nostream('frtm_backbone_set_winograd4', self._handle, self._wino_mode())
+            self._out_cache.clear()
+
+    @property
+    def winograd6(self):
+        """With winograd4: F(6x6,3x3) instead of F(4x4,3x3) wherever it needs fewer products (30x54 maps: 6x6 tiles fit exactly)."""
+        return self._winograd6
+
+    @winograd6.setter
+    def winograd6(self, on):
+        self._winograd6 = bool(on)
+        if self._handle is not None:
+            H.call_nostream('frtm_backbone_set_winograd4', self._handle, self._wino_mode())
             self._out_cache.clear()
 
     @lanes.setter
@@ -230,7 +246,7 @@ class ResnetFeatureExtractor:
                 self._handle = h
                 H.call_nostream('frtm_backbone_set_lanes', h, self._lanes)
                 H.call_nostream('frtm_backbone_set_winograd', h, int(self._winograd))
-                H.call_nostream('frtm_backbone_set_winograd4', h, int(self._winograd4))
+                H.call_nostream('frtm_backbone_set_winograd4', h, self._wino_mode())
             pairs = self.resnet.conv_bn_pairs()
             assert L.frtm_backbone_num_convs(self._handle) == len(pairs)
             info = (ctypes.c_int * 6)()
@@ -344,7 +360,7 @@ class ResnetFeatureExtractor:
         H.call('frtm_backbone_forward', self._handle, H.ptr(x), *args, *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
         self.last_flops_executed = H.lib().frtm_backbone_last_flops_executed(self._handle)    # Winograd launches at the MACs they execute
-        self.last_flops_form = [H.lib().frtm_backbone_last_flops_form(self._handle, k) for k in range(3)]   # direct, F(2x2,3x3), F(4x4,3x3)
+        self.last_flops_form = [H.lib().frtm_backbone_last_flops_form(self._handle, k) for k in range(4)]   # direct, F(2x2,3x3), F(4x4,3x3), F(6x6,3x3)
         self.last_conv_launches = H.lib().frtm_backbone_last_conv_launches(self._handle)
 
     def get_out_channels(self):

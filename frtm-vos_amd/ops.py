@@ -36,25 +36,27 @@ def padded_cols(M):
     return (M + 31) // 32 * 32
 
 
-def pack_weights(w_oihw, halo=None, wino=False, wino4=False):
+def pack_weights(w_oihw, halo=None, wino=False, wino4=False, wino6=False):
     """(Cout,Cin,k,k) -> packed GEMM weights (+ ktab for k > 1).  3x3 kernels default to the halo layout
     (valid for pad-1 convs of stride 1 or 2); wino=True: Winograd F(2x2,3x3) image (stride 1, pad 1); wino4=True: the 36 transformed
-    weight matrices of Winograd F(4x4,3x3) (FRTM_WLAYOUT_WINO4; conv2d then needs ``ws`` = wino4_workspace(...)).
+    weight matrices of Winograd F(4x4,3x3) (FRTM_WLAYOUT_WINO4; conv2d then needs ``ws`` = wino4_workspace(...)); wino6=True: the 64 of
+    F(6x6,3x3) (FRTM_WLAYOUT_WINO6, ``ws`` = wino4_workspace(..., m=6)).
     Returns (wT, ktab, layout)."""
     w = w_oihw.detach().float().contiguous()
     Cout, Cin, k, _ = w.shape
-    layout = 3 if wino4 else 2 if wino else (1 if (halo if halo is not None else k == 3) else 0)
-    rows = 36 * padded_rows(Cin) if layout == 3 else max(padded_rows(Cin * k * k), (Cin + 7) // 8 * 72) if layout != 2 else (Cin + 7) // 8 * 128
+    layout = 4 if wino6 else 3 if wino4 else 2 if wino else (1 if (halo if halo is not None else k == 3) else 0)
+    rows = 64 * padded_rows(Cin) if layout == 4 else 36 * padded_rows(Cin) if layout == 3 else max(padded_rows(Cin * k * k), (Cin + 7) // 8 * 72) if layout != 2 else (Cin + 7) // 8 * 128
     wT = torch.zeros(rows, padded_cols(Cout), device=w.device)
     ktab = torch.empty(Cin * k * k * 3, device=w.device, dtype=torch.int32) if (k > 1 and layout == 0) else None
     H.call('frtm_conv_pack_weights', H.ptr(w), Cout, Cin, k, layout, H.ptr(wT), H.ptr(ktab))
     return wT, ktab, layout
 
 
-def wino4_workspace(B, Cin, Cout, Hh, Ww, device):
-    """Scratch of a FRTM_WLAYOUT_WINO4 launch: the transformed input and product tensors (FRTM_CONV_WINO4_WS_ELEMS)."""
-    tiles = (B * ((Hh + 3) // 4) * ((Ww + 3) // 4) + 63) // 64 * 64
-    return torch.empty(36 * (Cin + Cout) * tiles, device=device)
+def wino4_workspace(B, Cin, Cout, Hh, Ww, device, m=4):
+    """Scratch of a FRTM_WLAYOUT_WINO4 (m = 4) / WINO6 (m = 6) launch: the transformed input and product tensors
+    (FRTM_CONV_WINO4_WS_ELEMS / FRTM_CONV_WINO6_WS_ELEMS)."""
+    tiles = (B * ((Hh + m - 1) // m) * ((Ww + m - 1) // m) + 63) // 64 * 64
+    return torch.empty((m + 2) ** 2 * (Cin + Cout) * tiles, device=device)
 
 
 def conv2d(x, wT, Cout, ksize=1, stride=1, pad=0, ktab=None, scale=None, shift=None, residual=None, relu=False,

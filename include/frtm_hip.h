@@ -259,6 +259,13 @@ typedef struct {
 #define FRTM_CONV_WINO4_ELEMS(Cout, Cin) (36 * (((Cin) + 31) / 32 * 32) * (((Cout) + 31) / 32 * 32))
 #define FRTM_CONV_WINO4_TILES(B, H, W) ((((B) * (((H) + 3) / 4) * (((W) + 3) / 4)) + 63) / 64 * 64)
 #define FRTM_CONV_WINO4_WS_ELEMS(B, Cin, Cout, H, W) ((size_t)36 * ((Cin) + (Cout)) * FRTM_CONV_WINO4_TILES(B, H, W))
+/* ... and F(6x6,3x3) (points 0, +-1, +-2, +-1/2, inf; 64 products per 6x6 outputs = 1.78 multiplications per output; fp32 error of the
+   same order as F(4x4): 2e-5 of the output range at 256 channels).  Fewer products AND smaller transformed tensors than F(4x4)
+   whenever the map divides well into 6x6 tiles (30x54: no edge waste). */
+#define FRTM_WLAYOUT_WINO6 4
+#define FRTM_CONV_WINO6_ELEMS(Cout, Cin) (64 * (((Cin) + 31) / 32 * 32) * (((Cout) + 31) / 32 * 32))
+#define FRTM_CONV_WINO6_TILES(B, H, W) ((((B) * (((H) + 5) / 6) * (((W) + 5) / 6)) + 63) / 64 * 64)
+#define FRTM_CONV_WINO6_WS_ELEMS(B, Cin, Cout, H, W) ((size_t)64 * ((Cin) + (Cout)) * FRTM_CONV_WINO6_TILES(B, H, W))
 #define FRTM_WINO_MIN_BLOCKS 512   /* 8x8 output blocks x 32-channel tiles below which callers prefer HALO3X3 + split-K */
 #define FRTM_CONV_PACKED_ELEMS(Cout, Cin, k) \
   (((((Cin) * (k) * (k) + 31) / 32 * 32) > (((Cin) + 7) / 8 * 72) ? (((Cin) * (k) * (k) + 31) / 32 * 32) : (((Cin) + 7) / 8 * 72)) * (((Cout) + 31) / 32 * 32))
@@ -310,7 +317,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */
 double frtm_backbone_last_flops_executed(const frtm_backbone_t* bb);
-/* algorithmic FLOPs of the last forward by kernel form: 0 = direct kernels, 1 = Winograd F(2x2,3x3), 2 = Winograd F(4x4,3x3) */
+/* algorithmic FLOPs of the last forward by kernel form: 0 = direct kernels, 1 = Winograd F(2x2,3x3), 2 = F(4x4,3x3), 3 = F(6x6,3x3) */
 double frtm_backbone_last_flops_form(const frtm_backbone_t* bb, int form);
 /* Number of convolutions (k_conv_igemm launches) of the last forward() call. */
 int frtm_backbone_last_conv_launches(const frtm_backbone_t* bb);
@@ -327,7 +334,8 @@ int frtm_backbone_generation(const frtm_backbone_t* bb);
 /* The trunk's 3x3 stride-1 convs run as Winograd F(2x2,3x3) when a launch has >= FRTM_WINO_MIN_BLOCKS output blocks
  * (default on; results differ from the direct kernels by fp32 rounding only). */
 int frtm_backbone_set_winograd(frtm_backbone_t* bb, int enable);
-/* Winograd F(4x4,3x3) (three-launch form, FRTM_WLAYOUT_WINO4) for the eligible 3x3 convs of a Winograd-enabled trunk; default on. */
+/* Three-launch Winograd (FRTM_WLAYOUT_WINO4 / WINO6) for the eligible 3x3 convs of a Winograd-enabled trunk: 0 = off, 1 = F(4x4,3x3)
+   only, 2 (default) = F(4x4,3x3) or F(6x6,3x3), whichever needs fewer products for the map at hand. */
 int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable);
 
 /* ------------------------------------------------------------------------------------------

@@ -422,10 +422,11 @@ def test_opt_in_gemm_tiles_match_the_default_kernel(cin, cout, h, w, frames):
         ops.conv2d(x, wT2, 96, tile=30, splitk=1)
 
 
+@pytest.mark.parametrize('m', [4, 6])
 @pytest.mark.parametrize('B,cin,cout,h,w', [(3, 128, 64, 30, 54), (2, 160, 128, 17, 23), (1, 128, 192, 9, 13), (5, 256, 256, 15, 27), (8, 256, 256, 30, 54)])
-def test_winograd_f4x4_three_launch_form_against_an_fp64_convolution(B, cin, cout, h, w):
-    """FRTM_WLAYOUT_WINO4 (conv_wino4.hip: input transform, 36 batched products, output transform + epilogue) on maps whose height /
-    width are not multiples of the 4x4 output tile, tile counts that need padding to the GEMM's 64 columns, every epilogue
+def test_winograd_f4x4_three_launch_form_against_an_fp64_convolution(B, cin, cout, h, w, m):
+    """FRTM_WLAYOUT_WINO4 / WINO6 (conv_wino4.hip: input transform, 36 / 64 batched products, output transform + epilogue) on maps whose
+    height / width are not multiples of the 4x4 / 6x6 output tile, tile counts that need padding to the GEMM's 64 columns, every epilogue
     combination.  fp32 Winograd F(4x4,3x3) with the points 0, +-1, +-2, inf: max |err| <= 3e-5 of max |out| against an fp64 direct
     convolution (the direct fp32 kernel: 1e-6, F(2x2,3x3): 5e-7)."""
     import torch.nn.functional as F
@@ -436,9 +437,9 @@ def test_winograd_f4x4_three_launch_form_against_an_fp64_convolution(B, cin, cou
     sc = (torch.rand(cout, generator=g) + 0.5).cuda()
     sh = torch.randn(cout, generator=g).cuda()
     res = torch.randn(B, cout, h, w, generator=g).cuda()
-    wW4, _, layout = ops.pack_weights(wt, wino4=True)
-    assert layout == 3
-    ws = ops.wino4_workspace(B, cin, cout, h, w, 'cuda')
+    wW4, _, layout = ops.pack_weights(wt, wino4=(m == 4), wino6=(m == 6))
+    assert layout == (3 if m == 4 else 4)
+    ws = ops.wino4_workspace(B, cin, cout, h, w, 'cuda', m=m)
     lin = F.conv2d(x.double(), wt.double(), padding=1)
     for scale, residual, relu in [(False, False, False), (True, False, True), (True, True, True), (False, True, False)]:
         ref = lin
@@ -451,15 +452,15 @@ def test_winograd_f4x4_three_launch_form_against_an_fp64_convolution(B, cin, cou
         for tile in (0, 1, 2):
             out = torch.full((B, cout, h, w), float('nan'), device='cuda')
             ops.conv2d(x, wW4, cout, 3, 1, 1, scale=sc if scale else None, shift=sh if scale else None, residual=res if residual else None,
-                       relu=relu, splitk=1, w_layout=3, ws=ws, out=out, tile=tile)
+                       relu=relu, splitk=1, w_layout=layout, ws=ws, out=out, tile=tile)
             torch.cuda.synchronize()
             assert torch.isfinite(out).all()
             err = float((out.double() - ref).abs().max() / ref.abs().max())
             assert err < 3e-5, (scale, residual, relu, tile, err)
     with pytest.raises(RuntimeError):                                   # a workspace that cannot hold the transformed tensors
-        ops.conv2d(x, wW4, cout, 3, 1, 1, splitk=1, w_layout=3, ws=ws[:ws.numel() // 2])
+        ops.conv2d(x, wW4, cout, 3, 1, 1, splitk=1, w_layout=layout, ws=ws[:ws.numel() // 2])
     with pytest.raises(RuntimeError):                                   # stride 2 is not a Winograd conv
-        ops.conv2d(x, wW4, cout, 3, 2, 1, splitk=1, w_layout=3, ws=ws)
+        ops.conv2d(x, wW4, cout, 3, 2, 1, splitk=1, w_layout=layout, ws=ws)
 
 
 def test_trunk_with_and_without_winograd_f4x4():
@@ -470,17 +471,22 @@ def test_trunk_with_and_without_winograd_f4x4():
     torch.manual_seed(3)
     ext = ResnetFeatureExtractor('resnet101').to(DEV)
     img = torch.randint(0, 256, (4, 3, 480, 854), dtype=torch.uint8, device=DEV)
-    assert ext.winograd4
+    assert ext.winograd4 and ext.winograd6
     a = {k: v.clone() for k, v in ext(img).items()}
-    fa = list(ext.last_flops_form)
+    fa = list(ext.last_flops_form)                                   # direct, F(2x2), F(4x4), F(6x6)
+    ext.winograd6 = False
+    a4 = {k: v.clone() for k, v in ext(img).items()}
+    f4 = list(ext.last_flops_form)
     ext.winograd4 = False
     b = {k: v.clone() for k, v in ext(img).items()}
     fb = list(ext.last_flops_form)
-    assert fa[2] > 0 and fb[2] == 0 and abs(sum(fa) - sum(fb)) < 1e-6 * sum(fa)
-    assert abs(sum(fa) - ext.last_flops) < 1e-6 * sum(fa)
+    assert fa[3] > 0 and f4[3] == 0 and f4[2] > 0 and fb[2] == 0 and fb[3] == 0
+    assert abs(fa[2] + fa[3] - f4[2]) < 1e-6 * f4[2]                 # the same convs, another form
+    assert abs(sum(fa) - sum(fb)) < 1e-6 * sum(fa) and abs(sum(fa) - ext.last_flops) < 1e-6 * sum(fa)
     for k in a:
-        err = float((a[k] - b[k]).abs().max() / b[k].abs().max())
-        assert err < 1e-4, (k, err)
+        for other in (a, a4):
+            err = float((other[k] - b[k]).abs().max() / b[k].abs().max())
+            assert err < 1e-4, (k, err)
 
 
 def test_prefetched_dataset_loop_equals_the_sequential_one():
