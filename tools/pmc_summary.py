@@ -11,7 +11,7 @@ import glob
 import json
 import sys
 
-FAMILY = ('k_conv_igemm', 'k_conv3x3_halo', 'k_conv3x3_wino', 'k_splitk_epilogue', 'k_wino4_')
+FAMILY = ('k_conv_igemm', 'k_conv3x3_halo', 'k_conv3x3_wino', 'k_splitk_epilogue', 'k_wino4_', 'k_wino6_')
 
 
 def load(d, counter):
@@ -40,7 +40,7 @@ def main():
         n = max(nf, nw)
         out['kernels'][k[:80]] = {'launches': n, 'fetch_bytes_per_launch': 2 * f * 1024 / max(nf, 1),
                                   'write_bytes_per_launch': w * 1024 / max(nw, 1)}
-        if 'k_splitk_epilogue' not in k and 'k_wino4_' not in k:      # (a launch = one conv: split-K epilogues and the two transform
+        if 'k_splitk_epilogue' not in k and 'k_wino4_' not in k and 'k_wino6_' not in k:      # (a launch = one conv: split-K epilogues and the two transform
             fam_n += n                                                # kernels of a Winograd F(4x4,3x3) conv belong to their GEMM launch)
         fam_f += 2 * f * 1024
         fam_w += w * 1024
