@@ -90,6 +90,7 @@ def parse(argv=None):
                     help='sharded (strong-scaling) mode, BASELINE config 4 shape: S dv2017-like synthetic sequences (1-5 objects, 34-104 frames) are '
                          'sharded over the ranks, length-balanced; value = sum of frames / max rank wall time')
     ap.add_argument('--no-dataset-sim', action='store_true', help='skip the dataset-level leg (30 dv2017-like sequences through the same tracker, N = 1 only)')
+    ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
     ap.add_argument('--no-pin', action='store_true', help='do not restrict every rank to its own GPU through HIP_VISIBLE_DEVICES')
     ap.add_argument('--debug-allocs', action='store_true', help='print the Python stacks of device allocations (hipMalloc) made inside the timed region')
     ap.add_argument('--report-dir', default=os.path.join(ROOT, 'gpurun_out', 'bench_ranks'), help='where every rank writes rank_<r>.json')
@@ -539,7 +540,11 @@ def main():
 
     from frtm_vos_amd.evaluate import Parameters
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
-    from frtm_vos_amd.shard import write_rank_report
+    from frtm_vos_amd.shard import write_rank_report, pin_host_threads_near_gpu
+
+    # the rank's host threads on cores of its GPU's NUMA node (this GPU's share of them): the thread that enqueues the launches must not
+    # be migrated across sockets in the middle of a 46 ms sequence (shard.py: pin_host_threads_near_gpu; --no-cpu-pin)
+    host_cpus = [] if (args.no_cpu_pin or args.share_gpu) else pin_host_threads_near_gpu(torch.device(dev).index)
 
     params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone, feature_batch=args.trunk_batch,
                         trunk_lanes=args.trunk_lanes)
@@ -778,6 +783,7 @@ def main():
         'device_mallocs_in_timed_region': mallocs,
         # wall-clock until the host had enqueued the whole sequence (run_sequence, before its final synchronise)
         'host_enqueue_ms_total': round(1e3 * getattr(tracker, 'last_enqueue_seconds', 0.0), 2),
+        'host_cpus': ('%d-%d (%d logical CPUs on the NUMA node of the GPU)' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned',
         'valid': bool(ok.item() > 0),
     }
     if shard is not None:

@@ -607,3 +607,33 @@ def test_sequence_prefetcher_order_and_release_on_the_cpu():
     for s in SequencePrefetcher([Seq(0), Seq(1)], 'cpu'):
         break
     assert log == [('preload', 0, 'cpu'), ('release', 0)]
+
+
+def test_host_cores_near_gpu_cuts_the_numa_node_among_its_gpus(tmp_path):
+    """shard.host_cores_near_gpu on a fake sysfs: two sockets (0-63,128-191 / 64-127,192-255), four GPUs per socket -> every GPU gets its
+    own 16 physical cores + their 16 SMT siblings on its own socket; unknown device -> nothing."""
+    from frtm_vos_amd.shard import host_cores_near_gpu, _parse_cpulist
+    assert _parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    drv = tmp_path / 'drivers' / 'amdgpu'
+    drv.mkdir(parents=True)
+    (tmp_path / 'drivers' / 'other').mkdir()
+    buses = [0x0a, 0x1b, 0x3c, 0x5a, 0x8d, 0xa4, 0xc7, 0xd9]
+    for i, b in enumerate(buses):
+        d = tmp_path / ('0000:%02x:00.0' % b)
+        d.mkdir()
+        (d / 'numa_node').write_text('%d\n' % (i // 4))
+        (d / 'local_cpulist').write_text('0-63,128-191\n' if i < 4 else '64-127,192-255\n')
+        (d / 'class').write_text('0x120000\n')
+        (d / 'driver').symlink_to(drv)
+    nic = tmp_path / '0000:5b:00.0'                                    # another device on the same node: not a GPU
+    nic.mkdir()
+    (nic / 'numa_node').write_text('0\n'); (nic / 'local_cpulist').write_text('0-63,128-191\n'); (nic / 'class').write_text('0x020000\n')
+    (nic / 'driver').symlink_to(tmp_path / 'drivers' / 'other')
+    seen = []
+    for i, b in enumerate(buses):
+        cpus = host_cores_near_gpu(b, sysfs=str(tmp_path))
+        base = 64 * (i // 4) + 16 * (i % 4)
+        assert cpus == list(range(base, base + 16)) + list(range(base + 128, base + 144)), (i, cpus)
+        seen += cpus
+    assert sorted(seen) == list(range(256))                            # a partition of the machine
+    assert host_cores_near_gpu(0x77, sysfs=str(tmp_path)) == []
