@@ -471,7 +471,10 @@ static int halo_tile_width(int Ho, int Wo) {
 // "images" whose weights switch per image (q.w_img_stride); Npix is a multiple of 64, every tile below is 64 columns wide.
 int frtm_igemm_batched(const ConvParams& q, int tile, hipStream_t st) {
   if (q.Npix % 64 || !q.w_img_stride) { frtm_set_error("frtm_igemm_batched: Npix must be a multiple of 64"); return FRTM_ERR_ARG; }
-  if (tile == 0) tile = (q.M % 64 == 0) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64;
+  // auto: FRTM_BATCHED_G32=1 tries the 32x32x2-MFMA kernel for the products (1-5 % ahead when timed alone, tools/wino4_bench.py)
+  static const bool g32_products = getenv("FRTM_BATCHED_G32") && atoi(getenv("FRTM_BATCHED_G32"));
+  if (tile == 0) tile = (g32_products && q.M % 64 == 0 && q.Mp % 4 == 0 && ((size_t)q.wT) % 16 == 0 && ((size_t)q.in) % 16 == 0) ? FRTM_TILE_G32_64x64
+                      : (q.M % 64 == 0) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64;
   switch (tile) {
     case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(q, true, st); break;
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(q, true, st); break;

@@ -1,12 +1,14 @@
-// Winograd F(4x4,3x3) in its THREE-LAUNCH form for the wide 3x3 stride-1 convs of the trunk (layer3: 22 x 256->256 at 30x54, layer4,
-// layer2) -- the MI355X shape of the algorithm: the transformed tensors (36 planes of [channels][tiles], 30 + 30 MB for an 8-frame
-// layer3 launch) never leave the 256 MB Infinity Cache / the L2s, so the two transform passes cost bandwidth the chip has to spare,
-// and the 36 independent [Cout x Cin] x [Cin x tiles] products run as ONE launch of the tuned fp32 MFMA GEMM kernel
-// (k_conv_igemm, MODE 1: the 36 transform positions are its "images", the weights switch per image).
-//   multiplications per output: 36 / 16 = 2.25 (direct: 9, F(2x2,3x3): 4)
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A  with the interpolation points 0, +-1, +-2, inf (Lavin & Gray 2015, the standard matrices)
-// fp32 throughout (weights transformed once in fp64 and rounded); measured error against an fp64 direct convolution: see
-// tests/test_round3_gpu.py::test_winograd_f4 (max |err| / max |out| <= 2e-5 at 256 channels).
+// Winograd F(4x4,3x3) and F(6x6,3x3) in their THREE-LAUNCH form for the wide 3x3 stride-1 convs of the trunk (layer3: 22 x 256->256 at
+// 30x54, layer4, layer2) -- the MI355X shape of the algorithm: the transformed tensors ((m+2)^2 planes of [channels][tiles]; F(6x6):
+// 25 + 25 MB for an 8-frame layer3 launch, F(4x4): 30 + 30 MB) never leave the 256 MB Infinity Cache / the L2s, so the two transform
+// passes cost bandwidth the chip has to spare, and the (m+2)^2 independent [Cout x Cin] x [Cin x tiles] products run as ONE launch of
+// the tuned fp32 MFMA GEMM kernel (k_conv_igemm, MODE 1: the transform positions are its "images", the weights switch per image).
+//   multiplications per output: F(6x6,3x3) 64 / 36 = 1.78, F(4x4,3x3) 36 / 16 = 2.25   (direct: 9, fused F(2x2,3x3): 4)
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A  with the interpolation points 0, +-1, +-2, inf (F(4x4); Lavin & Gray 2015) and
+//   0, +-1, +-2, +-1/2, inf (F(6x6)), the standard matrices
+// fp32 throughout (weights transformed once in fp64 and rounded); measured error against an fp64 direct convolution:
+// tests/test_round3_gpu.py::test_winograd_f4x4_* (max |err| / max |out|: F(4x4) 0.6-1.1e-5, F(6x6) 1.0-1.5e-5 at 128-512 channels).
+// The caller (backbone.hip: run_conv) takes the form with fewer products for the map at hand.
 // Reference call sites: the torchvision Bottleneck conv2 / BasicBlock convs behind model/feature_extractor.py:56-65.
 #include "frtm_common.h"
 #include "conv_common.h"

@@ -24,7 +24,7 @@ for cin, cout, h, w in shapes:
     cases = [('halo direct', dict(halo=True), 1, 0), ('wino F(2,3) fused', dict(wino=True), 2, 0)]
     cases += [('wino F(4,3) ' + n, dict(wino4=True), 3, t) for n, t in (('auto', 0), ('64x64 4w', 1), ('32x64', 2), ('128x64', 3), ('64x64 8w', 4), ('64x128 8w', 7), ('g32 64x64', 23), ('g32 128x64', 22), ('g32 64x64 s3', 26), ('128x128 8w', 8), ('128x128 16w', 9), ('g32 128x128', 20))]
     ws6 = ops.wino4_workspace(B, cin, cout, h, w, dev, m=6)
-    cases += [('wino F(6,3) ' + n, dict(wino6=True), 4, t) for n, t in (('auto', 0), ('64x64 8w', 4), ('g32 64x64', 23))]
+    cases += [('wino F(6,3) ' + n, dict(wino6=True), 4, t) for n, t in (('auto', 0), ('64x64 8w', 4), ('g32 64x64', 23), ('128x64', 3), ('128x128 8w', 8), ('g32 128x64', 22), ('g32 128x128', 20), ('64x128 8w', 7), ('32x64', 2))]
     packs = {}
     for name, kw, lay, tile in cases:
         if lay not in packs:
