@@ -272,3 +272,64 @@ class capture:
             if self._was_enabled:
                 gc.enable()
         return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Optional roctx ranges around the stages of a sequence (FRTM_ROCTX=1): `rocprofv3 --marker-trace --kernel-trace` then shows
+# initialize / trunk pass / tracking window / target update as named ranges above the kernels.  Off: two no-op calls per stage.
+# ------------------------------------------------------------------------------------------------------------------
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        if os.environ.get('FRTM_ROCTX'):
+            for name in ('librocprofiler-sdk-roctx.so', 'libroctx64.so'):
+                try:
+                    L = ctypes.CDLL(name)
+                    L.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    L.roctxRangePushA.restype = ctypes.c_int
+                    L.roctxRangePop.restype = ctypes.c_int
+                    _roctx = L
+                    break
+                except (OSError, AttributeError):
+                    continue
+    return _roctx
+
+
+class roctx_range:
+    """``with roctx_range('trunk pass'):`` -- a named range in rocprofv3's marker trace when FRTM_ROCTX=1, nothing otherwise."""
+
+    def __init__(self, name):
+        self.name = name
+        self._on = False
+
+    def __enter__(self):
+        L = _roctx_lib()
+        if L:
+            L.roctxRangePushA(self.name.encode())
+            self._on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self._on:
+            _roctx.roctxRangePop()
+        return False
+
+
+def roctx(name):
+    """Decorator form of roctx_range."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            if not _roctx_lib():
+                return fn(*a, **k)
+            with roctx_range(name):
+                return fn(*a, **k)
+        return wrapped
+    return deco
+

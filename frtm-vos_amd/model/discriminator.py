@@ -609,6 +609,7 @@ class Discriminator(nn.Module):
             return False
         return all((self.frame_num + f) % self.train_skipping != 0 for f in range(1, W))
 
+    @H.roctx('target model update_window')
     def update_window(self, cfts, masks, plane, counts):
         """advance() + update() for the W frames of a tracking window at once: ``cfts`` (W,c,h,w) projected features, the soft
         label of frame f is ``masks[f, plane]``, its pixel count ``counts[f, plane]`` (device int32).  Same memory and filter as the
@@ -636,6 +637,7 @@ class Discriminator(nn.Module):
         opt.run(self.update_iters)
         return True
 
+    @H.roctx('target model update')
     def update(self, train_y, num_positive=None, count_dev=None):
         """Memory insert + every ``train_skipping``-th frame a filter re-solve (reference :208-227).
         The reference's early-out "fewer than 10 pixels above 0.5" (:214) needs the pixel count:

@@ -295,6 +295,7 @@ class ResnetFeatureExtractor:
                 self._pass_done = torch.cuda.Event()
                 self._pass_done.record(cur)
 
+    @H.roctx('trunk pass')
     def _call(self, x, B, Hh, Ww, output_layers):
         want = ['layer1', 'layer2', 'layer3', 'layer4', 'layer5'] if output_layers is None else list(output_layers)
         stop = max(int(L[-1]) for L in want)       # the reference always runs resnet.layer4 (:65); skipping it is exact

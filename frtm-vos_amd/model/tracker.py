@@ -543,6 +543,7 @@ class Tracker(nn.Module):
 
     # ------------------------------------------------------------------------------------
     @torch.no_grad()
+    @H.roctx('initialize')
     def initialize(self, image, labels, new_objects):
         """Reference tracker.py:165-191."""
         self.current_masks = torch.zeros((len(self.targets) + len(new_objects) + 1, *image.shape[-2:]), device=self.device)
@@ -603,6 +604,7 @@ class Tracker(nn.Module):
         return self.current_masks
 
     @torch.no_grad()
+    @H.roctx('track_window')
     def track_window(self, images, taps):
         """track() for W consecutive frames at once (one contiguous slice of a trunk batch, same active objects, no filter
         re-solve before the last frame): one projection / score / refiner pass over W x n samples instead of W passes over n.
