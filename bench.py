@@ -505,6 +505,9 @@ def _phase(msg):
 
 
 def main():
+    if os.environ.get('FRTM_BENCH_WATCHDOG'):          # debugging aid: dump every thread's Python stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['FRTM_BENCH_WATCHDOG']), exit=True)
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))

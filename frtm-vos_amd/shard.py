@@ -125,5 +125,9 @@ def pin_host_threads_near_gpu(device=0):
     cpus = [c for c in cpus if c in allowed]
     if len(cpus) >= 2:
         os.sched_setaffinity(0, cpus)
+        # torch's intra-op (OpenMP) pool is sized for the whole machine and its workers inherit this mask when they are started: 256
+        # spinning threads on 32 CPUs turned the host-side generation of a synthetic sequence from milliseconds into minutes.  Size
+        # the pool for the cores the rank owns (one thread per physical core).
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus) // 2)))
         return cpus
     return []
