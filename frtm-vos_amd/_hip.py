@@ -204,6 +204,15 @@ def upload(t, device):
         return st.put(t, dev)
 
 
+def normalize_device(device):
+    """torch.device with an explicit index: 'cuda' -> 'cuda:<current device>' (torch.cuda.set_device / Stream(device=) / device
+    comparisons need the index).  CPU devices pass through."""
+    d = torch.device(device)
+    if d.type == 'cuda' and d.index is None:
+        d = torch.device('cuda', torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return d
+
+
 def require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError('%s: tensor is on %s; the FRTM hot path runs on the GPU only (no CPU fallback)' % (what, t.device))

@@ -422,7 +422,19 @@ __global__ __launch_bounds__(NT) void k_cg_run_persistent(const Params P) {
     __syncthreads();
   }
   // ---- write back (one workgroup): x += step * delta and the carried solver state ----
+  // COMMIT XOR ABORT: another workgroup may time out in the very barrier this one has just passed.  Workgroup 0 therefore
+  // claims the launch's abort word with an atomic exchange BEFORE it writes: old value 0 -> the launch is committed (word = 2: a later
+  // give-up finds it non-zero and does not count an abort), old value 1 -> somebody gave up first, the abort is already counted and
+  // NOTHING is written.  stats[3] counts the committed launches, so the host can tell how many Gauss-Newton iterations of a run()
+  // really happened and re-runs only the missed ones.
   if (g == 0) {
+    if (tid == 0) {
+      const unsigned was = __hip_atomic_exchange(abort_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh_flag = (was == 0u) ? 1 : 0;
+      if (was == 0u && P.stats) __hip_atomic_fetch_add(P.stats + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sh_flag) { leave(); return; }
     for (int i = tid; i < n; i += NT) {
       P.w2[i] = vw[i] + P.step * vx[i];
       P.vec[0 * n + i] = vb[i];

@@ -381,6 +381,7 @@ static int launch_g32p(const ConvParams& p, hipStream_t st) {
 
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st) {
   if (tile == FRTM_TILE_G32P_64x64) return launch_g32p(p, st);
+#ifdef FRTM_DEBUG_ABLATE    // (the deliberately-wrong ablation variants are not part of the shipped library; FRTM_BUILD_ABLATE=1 python frtm-vos_amd/build.py)
   // FRTM_G32_ABLATE (tools/g32_bench.py only; the 128x128 and 64x64 tiles): bit 0 = skip the epilogue's global traffic, bit 1 = skip the MFMAs,
   // bit 2 = no global loads inside the K loop, bit 3 = no per-chunk barrier (64x64 tile only)
   static const int ablate = getenv("FRTM_G32_ABLATE") ? atoi(getenv("FRTM_G32_ABLATE")) : 0;
@@ -412,6 +413,7 @@ int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st) {
       }
     }
   }
+#endif
   switch (tile) {
     case FRTM_TILE_G32_128x128: return launch_g32<2, 2, 2, 2>(p, st);
     case FRTM_TILE_G32_64x128: return launch_g32<1, 2, 2, 2>(p, st);

@@ -115,6 +115,8 @@ def main(argv=None):
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL); gloo for tests')
     ap.add_argument('--share-gpu', action='store_true', help='tests only: every rank uses cuda:0')
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
+    ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
+    ap.add_argument('--keep-gc', action='store_true', help="leave Python's cyclic collector alone (default: held off while a sequence is enqueued)")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -135,7 +137,18 @@ def main(argv=None):
     else:
         dset = YouTubeVOSDataset(args.yt2018, '2018', 'valid_all_frames')
     out_path = Path(args.output).expanduser().resolve() / (dset.name + '-' + Path(args.model).stem + ('_fast' if args.fast else ''))
+    # host side of the rank, as bench.py has it: its threads on cores of the GPU's NUMA node (this rank's share of them)
+    from .shard import pin_host_threads_near_gpu
+    host_cpus = [] if (args.no_cpu_pin or args.share_gpu) else pin_host_threads_near_gpu(torch.device(args.dev).index or 0)
+    if rank == 0:
+        print('host threads: %s' % (('CPUs %d-%d (%d logical) near the GPU' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned'))
     tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver).get_model()
+    if not args.keep_gc:
+        # driver-level decisions (process-global, so not the library's): long-lived objects into the permanent generation once, and no
+        # cyclic collection while a sequence's launches are being enqueued
+        from .lib.utils import freeze_long_lived_objects
+        freeze_long_lived_objects()
+        tracker.hold_gc = True
     if args.prewarm:
         tracker.prewarm(tuple(int(v) for v in args.prewarm.lower().split('x')))
 

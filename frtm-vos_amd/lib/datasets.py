@@ -85,7 +85,10 @@ class SequencePrefetcher:
     """
 
     def __init__(self, sequences, device, enabled=True):
-        self.sequences, self.device = sequences, torch.device(device)
+        d = torch.device(device)
+        if d.type == 'cuda' and d.index is None:              # 'cuda' -> the current device, with its index (set_device / Stream need one)
+            d = torch.device('cuda', torch.cuda.current_device())
+        self.sequences, self.device = sequences, d
         self.enabled = bool(enabled) and self.device.type == 'cuda'
         self._stream = None
 
@@ -95,8 +98,7 @@ class SequencePrefetcher:
 
         def work():
             try:
-                torch.cuda.set_device(self.device)
-                with torch.cuda.stream(self._stream):
+                with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
                     seq.preload(self.device)
                     ev = torch.cuda.Event()
                     ev.record(self._stream)

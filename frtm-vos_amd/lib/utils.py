@@ -83,3 +83,18 @@ class AverageMeter:
         self.sum += float(np.nansum(good))
         self.count += len(good)
         self.avg = self.sum / max(self.count, 1)
+
+
+_FROZEN = False
+
+
+def freeze_long_lived_objects():
+    """Driver-level, once per process: moves everything alive NOW (modules, weights, captured graphs) into the interpreter's permanent
+    generation so that later collections only look at young objects.  Process-global and not undone, which is why the library never
+    does it by itself: bench.py and evaluate.py call it after the tracker is built."""
+    global _FROZEN
+    if not _FROZEN:
+        import gc
+        gc.collect()
+        gc.freeze()
+        _FROZEN = True

@@ -631,10 +631,11 @@ class Discriminator(nn.Module):
         missed solve there, on the memory as it is now.  Called where a peek at the mirrored abort counter says so (every re-solve
         frame), and after the final synchronise of a sequence (Tracker.run_sequence) -- no solve is lost, at worst it runs late."""
         opt = self.update_optimizer
-        if opt is None or not opt.poll_persistent_abort():
+        missed = opt.poll_persistent_abort() if opt is not None else []
+        if not missed:
             return False
         self.num_persistent_aborts += 1
-        opt.run(self.update_iters)
+        opt.run(tuple(missed))              # only the Gauss-Newton iterations whose launch did not commit (ADVICE r3)
         return True
 
     @H.roctx('target model update')

@@ -72,7 +72,10 @@ class GaussNewtonCG:
         self._buf = None
         self._pbuf = None
         self._persistent_launched = False
-        self._gstats = None              # device int32[4]: guarded runs completed / skipped by the device-side early-out, persistent launches aborted
+        self._gstats = None              # device int32[4]: guarded runs completed / skipped by the device-side early-out, persistent launches
+                                         # aborted / persistent launches COMMITTED (wrote x and the solver state back)
+        self._launched = []              # num_cg_iter of every persistent launch since the last poll (oldest first)
+        self._committed_seen = 0
         self._shadow = None              # snapshot of the solver state around a chain-form run with a device-side guard
         self._aborts_handled = 0
         self.debug_abort = False         # tests: the next persistent launches time out at their first barrier
@@ -178,7 +181,12 @@ class GaussNewtonCG:
         chain_guard = False
         if guard is not None:
             self._guard = (guard, int(guard_min))
-            chain_guard = self._persistent_plan() is None
+            # snapshot / roll-back covers every Gauss-Newton iteration that runs as a CHAIN of launches: all of them without a resident
+            # plan, and the linearize-only entries (num_cg_iter == 0) even with one (those used to run unguarded).
+            # Host-side state is NOT rolled back on a skipped solve: step_alpha *= 1.2 (capped at 1.0 -- the update solver starts at
+            # 1.0, so nothing drifts) and _has_p = True with a zero direction on the device (p = z + 0 * beta: the same first step as
+            # has_p = False).  The reference never enters run() on such a frame (discriminator.py:214).
+            chain_guard = self._persistent_plan() is None or any(int(n) == 0 for n in num_cg_iter)
             if chain_guard:
                 self._snapshot()
         try:
@@ -243,6 +251,8 @@ class GaussNewtonCG:
                H.ptr(hbar) if self.hierarchical_barrier else None)
         self._has_p = True
         self._persistent_launched = True
+        self._launched.append(int(num_cg_iter))
+        del self._launched[:-64]          # (bounded: callers that never poll -- benchmarks -- must not grow it)
         if not torch.cuda.is_current_stream_capturing():
             self._abort_host.copy_(stats[2:3], non_blocking=True)
 
@@ -263,20 +273,28 @@ class GaussNewtonCG:
         return self._gstats is not None and self._persistent_launched and int(self._abort_host[0]) > self._aborts_handled
 
     def poll_persistent_abort(self):
-        """True if a persistent launch since the last poll gave up (its workgroups could not all become resident within the spin
-        time-out, e.g. another process holds the GPU's CUs): that launch left variable and solver state untouched, the CALLER re-runs
-        the solve (this solver is in the multi-kernel form from now on, and so is every solver created later in this process).
-        SYNCHRONISES (one 4-byte read); call it where the host waits anyway, or after peek_persistent_abort() said so."""
+        """Non-empty list if persistent launches since the last poll gave up (their workgroups could not all become resident within the
+        spin time-out, e.g. another process holds the GPU's CUs): the ``num_cg_iter`` of the Gauss-Newton iterations that did NOT
+        happen.  An aborted launch leaves variable and solver state untouched -- commit and abort exclude each other on the device
+        (cg_persistent.hip: the write-back claims the abort word) -- so the CALLER re-runs exactly these iterations
+        (``run(missed)``; this solver is in the multi-kernel form from now on, and so is every solver created later in this process).
+        Launches skipped by the device-side guard neither commit nor abort and are not missed.  Empty list (falsy): nothing to do.
+        SYNCHRONISES (one 16-byte read); call it where the host waits anyway, or after peek_persistent_abort() said so."""
         if not self._persistent_launched or self._gstats is None:
-            return False
+            return []
         self._persistent_launched = False
-        n = int(self._gstats[2].item())
+        launched, self._launched = self._launched, []
+        _, _, n, committed = self._gstats.tolist()
+        new_commits, self._committed_seen = committed - self._committed_seen, committed
         if n <= self._aborts_handled:
-            return False
-        self._aborts_handled = n
+            return []
+        new_aborts, self._aborts_handled = n - self._aborts_handled, n
         self.persistent = False
         GaussNewtonCG.abort_seen_in_process = True
-        return True
+        # the aborted launches are the ones that neither committed nor were skipped by the guard; which of the queue they were is not
+        # recorded -- with equal entries (the reference's update schedule is (10,)) it does not matter, otherwise the LAST ones are taken
+        missed = min(new_aborts, max(len(launched) - new_commits, 0)) if launched else new_aborts
+        return launched[len(launched) - missed:] if launched and missed else ([launched[-1]] * missed if launched else [])
 
     def run_GN_iter(self, num_cg_iter):
         a = self._persistent_plan() if num_cg_iter > 0 else None

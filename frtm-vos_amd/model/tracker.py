@@ -102,8 +102,9 @@ class Tracker(nn.Module):
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
-        self.hold_gc = not os.environ.get('FRTM_NO_HOLD_GC')   # no cyclic garbage collection while a sequence is being enqueued (_run_sequence)
-        self._gc_frozen = False
+        # No cyclic garbage collection while a sequence is being enqueued (_run_sequence).  A process-global side effect, so OPT-IN: the
+        # drivers (bench.py, evaluate.py) switch it on; an embedding application keeps its collector unless it sets this or FRTM_HOLD_GC=1.
+        self.hold_gc = bool(os.environ.get('FRTM_HOLD_GC')) and not os.environ.get('FRTM_NO_HOLD_GC')
         self.prefetch_sequences = True   # run_dataset: the next sequence is decoded / copied to the device while this one is tracked
         self.prefetch_stream = False     # True: next trunk batch on a side stream, overlapped with tracking (+3.5 % fps measured)
         self.pipeline_passes = False     # two tap sets, passes one ahead on a side stream, a short pass before and a pass beside
@@ -121,7 +122,7 @@ class Tracker(nn.Module):
         for m in self.refiner.parameters():
             m.requires_grad_(False)
         self.refiner.eval()
-        self.device = device
+        self.device = H.normalize_device(device)   # 'cuda' -> 'cuda:<current>': side streams, prefetcher and frame views compare devices by index
         self.first_frames = []
         self.current_frame = 0
         self.current_masks = None
@@ -246,15 +247,12 @@ class Tracker(nn.Module):
         collection of a PyTorch process (1.7e5 tracked objects here) stops it for 40-50 ms -- whenever one fell into a short sequence
         the GPU ran dry and that sequence came out at 270-330 instead of 420 frames/s (the sporadic "slow runs" of rounds 2 and 3,
         every GPU stage timer normal).  Reference counting still frees everything that is not a cycle; cycles wait for the end of the
-        sequence.  The first sequence of a tracker also moves the long-lived objects (modules, weights, graphs) into the permanent
-        generation (gc.freeze), so that collections between sequences only look at young objects."""
+        sequence.  Only this SCOPED disable / enable lives in the library, and only when ``hold_gc`` is set (off by default); moving the
+        long-lived objects into the permanent generation (gc.freeze) is the DRIVER's decision, once per process
+        (``frtm_vos_amd.lib.utils.freeze_long_lived_objects``, called by bench.py and evaluate.py)."""
         import gc
         if not self.hold_gc:
             return self._run_sequence_loop(sequence, speedrun, ytvos_merge)
-        if not self._gc_frozen:
-            gc.collect()
-            gc.freeze()
-            self._gc_frozen = True
         was = gc.isenabled()
         gc.disable()
         try:

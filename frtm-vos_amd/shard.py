@@ -110,17 +110,53 @@ def host_cores_near_gpu(pci_bus_id, pci_device_id=0, pci_domain_id=0, sysfs='/sy
     return sorted(out)
 
 
-def pin_host_threads_near_gpu(device=0):
+def rank_share_of(cpus, k, n):
+    """The k-th of n even shares of a node's CPU list (physical cores and their SMT siblings -- the kernel lists them as two ranges -- are
+    cut separately, like host_cores_near_gpu does among the GPUs of a node)."""
+    cpus = sorted(cpus)
+    half = len(cpus) // 2 if len(cpus) % 2 == 0 and len(cpus) >= 2 and cpus[len(cpus) // 2] - cpus[len(cpus) // 2 - 1] > 1 else len(cpus)
+    out = []
+    for lo in range(0, len(cpus), max(half, 1)):
+        rng = cpus[lo:lo + half]
+        per = max(1, len(rng) // n)
+        out.extend(rng[(k % n) * per:(k % n + 1) * per])
+    return sorted(out)
+
+
+def describe_gpu_numa(device=0, sysfs='/sys/bus/pci/devices'):
+    """What the box's sysfs says about this GPU's place among the host cores (printed by the multi-rank dress rehearsal): PCI address,
+    NUMA node, local CPU list, amdgpu functions on that node, and the cut host_cores_near_gpu makes of it."""
+    if not torch.cuda.is_available():
+        return {}
+    p = torch.cuda.get_device_properties(device)
+    bdf = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), getattr(p, 'pci_bus_id', 0), getattr(p, 'pci_device_id', 0))
+    d = os.path.join(sysfs, bdf)
+    out = {'pci': bdf}
+    for key in ('numa_node', 'local_cpulist'):
+        try:
+            out[key] = open(os.path.join(d, key)).read().strip()
+        except OSError:
+            out[key] = None
+    cut = host_cores_near_gpu(getattr(p, 'pci_bus_id', 0), getattr(p, 'pci_device_id', 0), getattr(p, 'pci_domain_id', 0), sysfs)
+    out['cut_for_this_gpu'] = '%d-%d (%d)' % (min(cut), max(cut), len(cut)) if cut else None
+    out['host_logical_cpus'] = os.cpu_count()
+    return out
+
+
+def pin_host_threads_near_gpu(device=0, share=None):
     """Confines the calling thread (and every thread it starts afterwards) to host cores on the NUMA node of CUDA/HIP device ``device``
     (host_cores_near_gpu).  The thread that enqueues a sequence's launches is latency-critical: measured on a two-socket MI355X node,
     20-frame sequences ran at 432-439 frames/s pinned next to the GPU and at 338-438 frames/s left to the scheduler (it migrates the
-    thread across sockets).  Returns the CPU list (empty: nothing done)."""
+    thread across sockets).  ``share=(k, n)``: only the k-th of n even shares of those cores (ranks sharing one GPU in the multi-rank
+    dress rehearsal: the host-side contention of n pinned ranks without n GPUs).  Returns the CPU list (empty: nothing done)."""
     if not hasattr(os, 'sched_setaffinity') or not torch.cuda.is_available():
         return []
     p = torch.cuda.get_device_properties(device)
     if not hasattr(p, 'pci_bus_id'):
         return []
     cpus = host_cores_near_gpu(p.pci_bus_id, getattr(p, 'pci_device_id', 0), getattr(p, 'pci_domain_id', 0))
+    if share is not None:                 # dress rehearsal of N ranks on ONE GPU: rank k takes the k-th of n shares of this GPU's cores
+        cpus = rank_share_of(cpus, share[0], share[1])
     allowed = os.sched_getaffinity(0)
     cpus = [c for c in cpus if c in allowed]
     if len(cpus) >= 2:

@@ -38,8 +38,13 @@ DISC = dict(init_iters=(5, 10, 10, 10, 10), update_iters=(10,), CG_forgetting_ra
             pixel_weighting=dict(method='hinge', tf=0.1))
 
 
-def sequence_specs(n_seq, n_frames):
-    """(name, frames, objects, seed) of the synthetic dataset: 1-3 objects, DAVIS-2017-val-like mean of 2."""
+def sequence_specs(n_seq, n_frames, spec='v1'):
+    """(name, frames, objects, seed) of the synthetic dataset.
+    v1 (round 3, G12): 1-3 objects, mean 2.  v2 (round 4, G14; BASELINE config 3's shape = dv2017val: 30 sequences, 1-5 objects,
+    mean 2.4): 32 sequences with 9 x 1, 10 x 2, 7 x 3, 3 x 4, 3 x 5 objects (77 objects), seeds disjoint from v1's."""
+    if spec == 'v2':
+        objs = (2, 1, 3, 2, 5, 1, 2, 4, 1, 3, 2, 2, 1, 3, 5, 2, 1, 3, 2, 4, 1, 2, 3, 1, 2, 5, 3, 1, 2, 4, 3, 1)
+        return [('jg%02d' % k, n_frames, objs[k % len(objs)], 500 + k) for k in range(n_seq)]
     objs = (2, 1, 3, 2, 2, 1, 3, 2, 2, 3, 1, 2, 3, 2, 1, 2)
     return [('jf%02d' % k, n_frames, objs[k % len(objs)], 300 + k) for k in range(n_seq)]
 
@@ -80,6 +85,8 @@ def main():
     ap.add_argument('--threads', type=int, default=os.cpu_count())
     ap.add_argument('--first', type=int, default=0, help='index of the first sequence to run (resume)')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--spec', default='v1', help="v1 = fixture G12 (round 3), v2 = fixture G14 (round 4: 32 x 40, 1-5 objects)")
+    ap.add_argument('--no-labels', action='store_true', help='store J / F per object only (noise-floor and arbiter runs)')
     args = ap.parse_args()
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     torch.set_num_threads(args.threads)
@@ -88,7 +95,8 @@ def main():
     refiner = refiner_for()
     out = args.out or os.path.join(ROOT, 'tests', 'golden', 'g12_jf_%s.npz' % args.dtype)
     res = dict(np.load(out)) if (args.first > 0 and os.path.exists(out)) else {}
-    specs = sequence_specs(args.sequences, args.frames)
+    specs = sequence_specs(args.sequences, args.frames, args.spec)
+    res['threads'] = np.array(args.threads)
     res['specs'] = np.array([[f, n, s] for _, f, n, s in specs])
     for k, (name, n_frames, n_obj, seed) in enumerate(specs):
         if k < args.first:
@@ -99,7 +107,8 @@ def main():
         labels = trk.run_sequence(seq)
         lab = torch.stack(labels).numpy()
         jf = jf_per_object(lab, seq)
-        res['labels_%d' % k] = lab
+        if not args.no_labels:
+            res['labels_%d' % k] = lab
         res['jf_%d' % k] = np.array(jf)
         print('%s: %d objects, %d frames, J&F per object %s, %.0f s' % (name, n_obj, n_frames, ['%.2f/%.2f' % (100 * a, 100 * b) for a, b in jf],
                                                                       time.time() - t0), flush=True)
