@@ -93,6 +93,7 @@ def parse(argv=None):
     ap.add_argument('--sequences', type=int, default=0,
                     help='sharded (strong-scaling) mode, BASELINE config 4 shape: S dv2017-like synthetic sequences (1-5 objects, 34-104 frames) are '
                          'sharded over the ranks, length-balanced; value = sum of frames / max rank wall time')
+    ap.add_argument('--shard-warm', action='store_true', help='sharded mode: run the rank\'s share once untimed first, so that the timed pass is the steady state (every shape seen, allocator warm)')
     ap.add_argument('--no-dataset-sim', action='store_true', help='skip the dataset-level leg (30 dv2017-like sequences through the same tracker, N = 1 only)')
     ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
     ap.add_argument('--no-pin', action='store_true', help='do not restrict every rank to its own GPU through HIP_VISIBLE_DEVICES')
@@ -668,6 +669,9 @@ def main():
         specs = dataset_specs(args.sequences, size)
         mine = shard_indices(len(specs), rank, world, costs=[L * k for _, L, k, _ in specs])
         shard_seqs = build_sequences([specs[i] for i in mine], size)
+        if args.shard_warm:
+            run_dataset_shard(tracker, shard_seqs, dev, prefetch=not args.no_prefetch)
+            _phase('shard warm pass done')
     # the sequences of the repeats, resident before any clock starts (repeat 0 = the sequence of rounds 1-3: seed 1 + rank)
     rep_seqs = [seq]
     for r in range(1, repeats):

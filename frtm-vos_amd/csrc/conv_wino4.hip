@@ -14,7 +14,7 @@
 #include "conv_common.h"
 #include "../../include/frtm_hip.h"
 
-int frtm_igemm_batched(const ConvParams& q, int tile, hipStream_t st);      // conv_igemm.hip
+int frtm_igemm_batched(const ConvParams& q, int tile, float* scratch, size_t scratch_elems, hipStream_t st);      // conv_igemm.hip
 
 namespace {
 
@@ -335,7 +335,8 @@ int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile,
   q.in_bytes = (unsigned)((size_t)NP * p.Cin * Tp * 4);
   q.w_bytes = (unsigned)((size_t)Kp * p.Mp * 4);
   q.w_img_stride = Kp * p.Mp;
-  int rc = frtm_igemm_batched(q, tile, st);
+  // (whatever the caller's workspace holds beyond V and M is scratch for the stream-K form of the products)
+  int rc = frtm_igemm_batched(q, tile, ws_elems > need ? ws + need : nullptr, ws_elems > need ? ws_elems - need : 0, st);
   if (rc) return rc;
   dim3 go(ceil_div(T, 256), p.M);
   if (m == 6) k_wino6_output<<<go, 256, 0, st>>>(Mb, p.M, H, W, th, tw, T, Tp, p.scale, p.shift, p.residual, p.relu, p.out);

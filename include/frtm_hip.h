@@ -290,6 +290,13 @@ typedef struct {
 #define FRTM_TILE_G32_128x128_S3 27
 #define FRTM_TILE_G32_128x64_S3 28
 #define FRTM_TILE_G32P_64x64 30     /* persistent workgroups: loads across tile boundaries, epilogue of a tile under the next tile's K loop */
+#define FRTM_TILE_SK_64x64 31       /* round 4 (csrc/conv_gemm_sk.hip): persistent STREAM-K workgroups, two per CU, 4-stage LDS-DMA ring; needs >= 512 tiles,
+                                       Cout % 64 == 0 and FRTM_CONV_SK_SCRATCH_ELEMS floats of workspace; tile = 0 (auto) takes it where eligible */
+#define FRTM_CONV_SK_SCRATCH_ELEMS (1024 * 4096 + 1024 * 2 + 64)   /* upper bound of the stream-K scratch at the END of the workspace (floats) */
+/* Stream-K GEMM (csrc/conv_gemm_sk.hip): inter-workgroup hand-off spins that ran into their 2 s time-out since the library was loaded.
+ * 0 on a healthy run; anything else means a conv result may be wrong (the caller should stop and set FRTM_SK=0).  Synchronises the
+ * device.  No reference counterpart (the reference's convs are cuDNN calls, model/feature_extractor.py:50-65). */
+int frtm_sk_timeouts(void);
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

@@ -95,6 +95,7 @@ def test_persistent_cg_commits_xor_aborts():
     from test_round2_gpu import _filter_problem
     N, c, h, w, Hh, Ww = 16, 32, 24, 40, 96, 160
     mem, opt, wv, g = _filter_problem(N, c, h, w, Hh, Ww, 5, True)
+    opt.problem.initialize()
     assert opt._persistent_plan() is not None
     w0 = wv.detach().clone()
     opt.run((4, 4))
@@ -145,3 +146,115 @@ def test_eight_ranks_share_one_gpu_dress_rehearsal(tmp_path):
     pinned = [r['host_cpus'] for r in reps]
     if all(p_ != 'not pinned' for p_ in pinned):
         assert len(set(pinned)) == 8                                          # eight different shares of the GPU's cores
+
+
+# ------------------------------------------------------------------------------------------ stream-K GEMM (csrc/conv_gemm_sk.hip)
+def _sk_case(B, cin, cout, h, w, seed, residual=True, scale=True, relu=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+    sc = (torch.rand(cout, generator=g) + 0.5).to(DEV) if scale else None
+    sh = torch.randn(cout, generator=g).to(DEV) if scale else None
+    res = torch.randn(B, cout, h, w, generator=g).to(DEV) if residual else None
+    ref = torch.einsum('oc,bchw->bohw', wt[:, :, 0, 0].double(), x.double())
+    if scale:
+        ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    return x, wt, sc, sh, res, ref
+
+
+@pytest.mark.parametrize('shape', [
+    (8, 256, 1024, 30, 54),        # the dominant trunk shape: 8 chunks per tile, 3 248 tiles (pixel tail: 12 960 = 202.5 tiles of 64)
+    (8, 1024, 256, 30, 54),        # 32 chunks per tile, 812 tiles: most tiles are cut over two or three workgroups
+    (8, 64, 256, 120, 214),        # 2 chunks per tile, 12 840 tiles
+    (4, 2048, 512, 16, 28),        # 64 chunks per tile, 224 -> not eligible (fewer than 512 tiles): must be refused when forced
+    (3, 96, 128, 60, 108),         # K = 96 = 3 chunks; 608 tiles; images of 6 480 pixels (not a multiple of 64: tiles straddle images)
+    (2, 40, 64, 128, 260),         # K = 40: a ragged last chunk (zero rows of the packed weights, out-of-bounds activation rows)
+])
+def test_stream_k_gemm_against_fp64(shape):
+    """k_gemm_sk (persistent stream-K 1x1 conv GEMM) against a float64-accumulated reference, forced (tile = FRTM_TILE_SK_64x64) and as the
+    automatic choice; equal bits on repetition (the summation order of a cut tile is fixed); bit-identical to itself under uneven load from a
+    second stream (the hand-off of partial tiles must never deliver a stale word)."""
+    from frtm_vos_amd import ops, _hip as H
+    B, cin, cout, h, w = shape
+    x, wt, sc, sh, res, ref = _sk_case(B, cin, cout, h, w, 11)
+    wT, ktab, layout = ops.pack_weights(wt)
+    ws = torch.empty(1 << 24, device=DEV)
+    ws.uniform_(-1, 1)                                     # the scratch is NOT zeroed by anybody: flags must not depend on it
+    ntiles = -(-B * h * w // 64) * (cout // 64)
+    if ntiles < 512:
+        with pytest.raises(RuntimeError):
+            ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
+        return
+    out = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
+    auto = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, ws=ws)      # tile 0: the planner takes stream-K here
+    assert torch.equal(auto, out)
+    old = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=4, splitk=1)       # k_conv_igemm 64x64 8 waves
+    assert float((old - out).abs().max() / ref.abs().max()) < 3e-6
+    side = torch.cuda.Stream()
+    noise = torch.randn(64, 1 << 20, device=DEV)
+    bad = 0
+    for it in range(60):
+        if it % 2 == 0:
+            with torch.cuda.stream(side):
+                for k in range(1 + it % 5):
+                    noise[k * 8:(k + 1) * 8].mul_(1.0000001)
+        o2 = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
+        bad += int(not torch.equal(o2, out))
+    torch.cuda.synchronize()
+    assert bad == 0, '%d of 60 repetitions differ' % bad
+    assert H.lib().frtm_sk_timeouts() == 0
+
+
+def test_stream_k_plain_epilogue_and_graph_replay():
+    """No scale / residual / ReLU (the form the batched Winograd products use), and the same launch replayed from a hipGraph: the token in
+    the flag words is frozen under replay, the consumer's reset must make every replay start from clean flags."""
+    from frtm_vos_amd import ops, _hip as H
+    x, wt, sc, sh, res, ref = _sk_case(8, 256, 256, 30, 54, 5, residual=False, scale=False, relu=False)
+    wT, ktab, layout = ops.pack_weights(wt)
+    ws = torch.empty(1 << 23, device=DEV)
+    out = ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    o2 = torch.empty_like(out)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws, out=o2)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with H.capture(g):
+        ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws, out=o2)
+    for _ in range(20):
+        o2.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o2, out)
+    assert H.lib().frtm_sk_timeouts() == 0
+
+
+@pytest.mark.parametrize('m', [4, 6])
+def test_winograd_products_on_stream_k_equal_the_tiled_kernel(m):
+    """The batched products of the three-launch Winograd forms (36 / 64 GEMMs with one weight matrix each) on the stream-K kernel -- taken
+    automatically when the workspace has the scratch behind V and M -- against the same conv with a workspace WITHOUT it (k_conv_igemm)."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, h, w = 8, 256, 30, 54
+    x = torch.randn(B, C, h, w, generator=g).to(DEV)
+    wt = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(DEV)
+    layout = 3 if m == 4 else 4
+    wT, _, _ = ops.pack_weights(wt, layout=layout)
+    th, tw = -(-h // m), -(-w // m)
+    Tp = (B * th * tw + 63) // 64 * 64
+    need = (m + 2) ** 2 * 2 * C * Tp
+    small, big = torch.empty(need, device=DEV), torch.empty(need + (1 << 22) + 4096, device=DEV)
+    a = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=small)
+    b = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=big)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    ea, eb = float((a.double() - ref).abs().max() / ref.abs().max()), float((b.double() - ref).abs().max() / ref.abs().max())
+    assert eb < 3e-5 and eb < 2 * ea + 1e-6, (ea, eb)
+    assert float((a - b).abs().max() / ref.abs().max()) < 1e-5

@@ -5,7 +5,7 @@ share of the GPU's host cores, its own pageable-memory prefetcher.  Checks and r
   * aggregate of the line == sum of the ranks' frames / max rank wall (recomputed from the files alone);
   * host enqueue time per rank under 8-way contention, torch threads, the CPUs each rank was pinned to;
   * the NUMA facts the box's sysfs reports for the GPU (the cut the pinning is made from);
-  * device mallocs inside the timed region per rank.
+  * device mallocs inside the timed region per rank (the share is run once untimed first, --shard-warm: the timed pass is the steady state).
 Writes profiles/r04_eight_ranks_one_gpu.json.   python tools/eight_ranks_one_gpu.py [--gpus 8] [--sequences 24] [--out ...]"""
 import argparse
 import json
@@ -30,7 +30,7 @@ def main():
         os.remove(os.path.join(rdir, f))
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(args.gpus), '--share-gpu', '--dist-backend', 'gloo',
            '--sequences', str(args.sequences), '--warmup', '5', '--steps', '20', '--no-cpu-baseline', '--no-cg-roofline', '--no-init-sweep',
-           '--no-dataset-sim', '--report-dir', rdir] + args.extra.split()
+           '--no-dataset-sim', '--shard-warm', '--report-dir', rdir] + args.extra.split()
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     wall = time.time() - t0
