@@ -38,23 +38,27 @@
 #include "conv_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int GK = 32;                 // chunk depth (rows of the packed weights are padded to 32)
-constexpr int BM = 64, BN = 64, NT = 256, ST = 4;
-constexpr int NA = GK * BM / 4 / NT, NB = GK * BN / 4 / NT;      // 2 + 2 LDS-DMA instructions per wave and chunk
-constexpr int NLD = NA + NB;
-constexpr int STAGE = GK * (BM + BN);                            // floats per stage (16 KB)
-constexpr int LDS_FLOATS = ST * STAGE + 4 * 64;                  // + per-wave scale / shift rows
-constexpr int SLOT_FLOATS = BM * BN;                             // one published partial tile
+// Tile: BM = 128 output channels x BN = 64 FN pixels per workgroup of 4 waves (2 x 2); a wave owns 64 x 32 FN outputs = 2 x FN blocks
+// of v_mfma_f32_32x32x2_f32 with INTERLEAVED fragments (block (im, jn) covers rows 2 i + im / columns FN j + jn, so a k-step's two A
+// operands -- and its FN B operands -- are ONE ds_read_b64 / b32 of consecutive bytes per lane, conflict free).  FN = 2 (128 x 128, four
+// independent accumulator chains per wave) is the main form; FN = 1 (128 x 64) serves the batched Winograd products, whose "images" are
+// padded to 64 columns only.  16-deep chunks: a stage is 16 (BM + BN) floats = 16 / 12 KB, FOUR stages = 64 / 48 KB: two workgroups per CU.
+constexpr int GK = 16;                 // chunk depth
+constexpr int BM = 128, NT = 256, ST = 4;
+constexpr int PD = 2, NS = GK / 2;     // LDS fragments are read PD k-steps ahead of their MFMAs
 
 struct SKArgs {
-  int ntiles, mt, cpt;            // 64x64 tiles of the launch, tiles along M, 32-deep chunks per tile
-  float* slots;                   // [G][SLOT_FLOATS]
+  int ntiles, mt, cpt;            // tiles of the launch, tiles along M, 16-deep chunks per tile
+  float* slots;                   // [G][BM * BN]
   unsigned long long* flags;      // [G]
   unsigned token;
   long long spin_limit;           // 10 ns ticks
+  int dbg;                        // FRTM_DEBUG_ABLATE builds only (tools/sk_probe.py): bit 0 = no epilogue traffic, bit 1 = no operand loads after the prologue
 };
 
 __device__ unsigned g_sk_timeouts;        // sticky: hand-off spins that ran into the time-out (read by frtm_sk_timeouts)
@@ -78,27 +82,65 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
+template <int FN>
 __global__ __launch_bounds__(NT, 2) void k_gemm_sk(const ConvParams p, const SKArgs a) {
+  constexpr int BN = 64 * FN;
+  constexpr int NA = GK * BM / 4 / NT, NB = (GK * BN / 4 + NT - 1) / NT;     // LDS-DMA instructions per wave and chunk: 2 + 2 (FN = 2) / 2 + 1
+  constexpr int NLD = 4;                                                      // counted as 4 per chunk in both forms (the model works in 4s)
+  constexpr int STAGE = GK * (BM + BN);                                       // floats per stage
+  constexpr int SLOT_FLOATS = BM * BN;
+  constexpr int NACC = 2 * FN;                                                // 32x32 blocks per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int lk = lane >> 5, li = lane & 31;
-  // ---- this workgroup's share: XCD slice x of the tiles, then an equal share of that slice's (tile, chunk) units
+  // The two workgroups of a CU run the same code at the same pace: left alone they fall into LOCK-STEP -- both in their matrix phase
+  // (sharing the pipe), then both in the bookkeeping / wait phase of a chunk (pipe idle): measured 84 us with every memory operation
+  // removed, against 47 us of pipe time.  A static priority for the second half of the grid (the second residents of the CUs under
+  // in-order dispatch) breaks the symmetry: the favoured wave runs its matrix phase alone, the other one gets the pipe while the
+  // favoured one does its bookkeeping (guide, "Static priority for the younger half").
+#ifdef FRTM_DEBUG_ABLATE
+  if (!(a.dbg & 16))
+#endif
+  if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+  // ---- this workgroup's share.  The tiles are cut into eight contiguous slices (block b works on slice b % 8 -- the XCD it runs on, as
+  // observed; only speed depends on that -- with local index j = b / 8 of Gx).  Inside a slice (Ts tiles, M tiles fastest):
+  //   * R = Ts / Gx full ROUNDS: in round r workgroup j owns tile r * Gx + j entirely.  The Gx workgroups of an XCD walk ADJACENT tiles at
+  //     the same time, so the activation tiles they share are L2 hits;
+  //   * the TAIL (Ts - R Gx < Gx tiles) is cut stream-K: its (tile, chunk) units are shared evenly, workgroup j takes the contiguous
+  //     units [Ut j / Gx, Ut (j + 1) / Gx).  A share that does not contain a tile's LAST chunk is published; the share with the last
+  //     chunk finishes the tile.
+  // The workgroup's work is a short list of SEGMENTS (tile, first chunk, end chunk), in this order: the piece it publishes FIRST, the
+  // full tiles, the piece it finishes (and has to wait for) LAST.  Two cursors walk the list chunk by chunk -- the loader three chunks
+  // ahead of the matrix pipe -- with one add and one compare per chunk.
   const int x = blockIdx.x & 7, j = blockIdx.x >> 3, Gx = gridDim.x >> 3;
   const int tA = (int)((long long)a.ntiles * x / 8), tB = (int)((long long)a.ntiles * (x + 1) / 8);
-  const long long Ux = (long long)(tB - tA) * a.cpt;
-  const int u0 = (int)(Ux * j / Gx), u1 = (int)(Ux * (j + 1) / Gx);
-  const int n = u1 - u0;
-  if (n <= 0) return;
   const int cpt = a.cpt;
-  const int t_first = u0 / cpt, c_first = u0 - t_first * cpt;
-  const int t_last = (u1 - 1) / cpt, c_last_end = u1 - t_last * cpt;
-  const bool trailing_pub = c_last_end < cpt;                                    // my last tile is finished by a later workgroup
-  const int nT = trailing_pub ? (t_last == t_first ? n : c_last_end) : 0;        // units of the piece I publish (processed FIRST)
-  const bool leading_fin = c_first > 0 && !(t_last == t_first && trailing_pub);  // my first tile was started by earlier workgroups
-  const int nL = leading_fin ? cpt - c_first : 0;                                // units of the piece I finish (processed LAST)
-  const int nMid = n - nT - nL;
-  auto unit_at = [&](int i) { return i < nT ? u1 - nT + i : (i < nT + nMid ? u0 + nL + (i - nT) : u0 + (i - nT - nMid)); };
+  const int Ts = tB - tA, R = Ts / Gx, Tt = Ts - R * Gx;
+  const long long Ut = (long long)Tt * cpt;                 // tail units of the slice
+  const int v0 = (int)(Ut * j / Gx), v1 = (int)(Ut * (j + 1) / Gx);
+  const int nt = v1 - v0;
+  int nT = 0, nL = 0, t_first = 0, c_first = 0, t_last = 0, c_last_end = 0;
+  if (nt > 0) {
+    t_first = v0 / cpt; c_first = v0 - t_first * cpt;
+    t_last = (v1 - 1) / cpt; c_last_end = v1 - t_last * cpt;
+    const bool trailing_pub = c_last_end < cpt;                                    // my last tail tile is finished by a later workgroup
+    nT = trailing_pub ? (t_last == t_first ? nt : c_last_end) : 0;                // units of the piece I publish
+    const bool leading_fin = c_first > 0 && !(t_last == t_first && trailing_pub);  // my first tail tile was started by earlier workgroups
+    nL = leading_fin ? cpt - c_first : 0;                                          // units of the piece I finish
+  }
+  const int nMidTiles = (nt - nT - nL) / cpt, t_mid0 = nt > 0 ? (v0 + nL) / cpt : 0;
+  const int has_pub = nT > 0 ? 1 : 0, has_fin = nL > 0 ? 1 : 0;
+  const int nseg = has_pub + R + nMidTiles + has_fin;
+  if (nseg <= 0) return;
+  auto seg_desc = [&](int sg, int& tile, int& c0, int& c1) {
+    int s2 = sg - has_pub;
+    if (s2 < 0) { tile = R * Gx + t_last; c0 = c_last_end - nT; c1 = c_last_end; return; }
+    if (s2 < R) { tile = s2 * Gx + j; c0 = 0; c1 = cpt; return; }
+    s2 -= R;
+    if (s2 < nMidTiles) { tile = R * Gx + t_mid0 + s2; c0 = 0; c1 = cpt; return; }
+    tile = R * Gx + t_first; c0 = c_first; c1 = cpt;
+  };
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
   const unsigned w_total = p.w_img_stride ? (unsigned)p.w_bytes * (unsigned)p.B : p.w_bytes;       // (checked < 2 GB by the launcher)
@@ -112,241 +154,332 @@ __global__ __launch_bounds__(NT, 2) void k_gemm_sk(const ConvParams p, const SKA
   const __amdgpu_buffer_rsrc_t rslot = __builtin_amdgcn_make_buffer_rsrc((void*)a.slots, 0, G * SLOT_FLOATS * 4, 0x00020000);
   const int HWin = p.Hin * p.Win;
   const unsigned row_bytes = (unsigned)p.Npix * 4u;
-  constexpr int AR = NT / (BM / 4), BR = NT / (BN / 4);
+  constexpr int AR = NT / (BM / 4), BR = NT / (BN / 4);     // k rows one pass of all threads covers: 8, and 8 (FN = 2) / 16 (FN = 1)
   const int a_k = tid / (BM / 4), b_k = tid / (BN / 4);
+  const unsigned a_kstep = (unsigned)(p.Mp * 4), b_kstep = (unsigned)(HWin * 4);       // bytes per k row of the two operands
 
-  // per-thread operand offsets of a tile (t = slice-relative tile index)
-  auto tile_offsets = [&](int t, int& m0, int& n0, unsigned& a_off, unsigned& b_base) {
-    const int lt = tA + t;
+  // ---- loader cursor: segment, chunk, and this thread's byte offsets of its first k row of chunk `kc` of the segment's tile ----
+  int pf_seg = 0, pf_kc = 0, pf_c1 = 0, pf_stage = 0;
+  unsigned pf_a = OOB, pf_b = OOB;            // OOB = this thread loads zeros
+  bool pf_valid = true;
+  auto pf_enter = [&]() {                     // position the loader on the first chunk of segment pf_seg
+    int tile, c0;
+    seg_desc(pf_seg, tile, c0, pf_c1);
+    pf_kc = c0;
+    const int lt = tA + tile;
     const int n_tile = lt / a.mt, m_tile = lt - n_tile * a.mt;                  // M tiles fastest: neighbours share the activation tile
-    m0 = m_tile * BM; n0 = n_tile * BN;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int mm = m0 + 4 * (tid % (BM / 4));
-    a_off = mm >= p.Mp ? OOB : (unsigned)mm * 4u;
-    if (p.w_img_stride && a_off != OOB) a_off += (unsigned)(n0 / p.Npix) * (unsigned)p.w_img_stride * 4u;      // batched GEMM: the image's weight matrix
+    pf_a = mm >= p.Mp ? OOB : (unsigned)mm * 4u + (unsigned)(c0 * GK + a_k) * a_kstep;
+    if (p.w_img_stride && pf_a != OOB) pf_a += (unsigned)(n0 / p.Npix) * (unsigned)p.w_img_stride * 4u;      // batched GEMM: the image's weight matrix
     const int nn = n0 + 4 * (tid % (BN / 4));
-    b_base = OOB;
-    if (nn < p.Ntot) { const int img = nn / p.Npix; b_base = (unsigned)(img * p.Cin * HWin + (nn - img * p.Npix)) * 4u; }
+    pf_b = OOB;
+    if (nn < p.Ntot) { const int img = nn / p.Npix; pf_b = (unsigned)(img * p.Cin * HWin + (nn - img * p.Npix)) * 4u + (unsigned)(c0 * GK + b_k) * b_kstep; }
   };
-  auto gload = [&](int kc, int stage, unsigned a_off, unsigned b_base) {
-    float* As = smem + stage * STAGE;
+  int issued = 0;
+  auto issue = [&]() {                        // LDS-DMA of the loader's chunk into stage pf_stage, then advance the cursor
+    float* As = smem + pf_stage * STAGE;
     float* Bs = As + GK * BM;
-    const int kb = kc * GK;
+    const int kb = pf_kc * GK;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int k = kb + a_k + i * AR;
-      const unsigned o = (a_off == OOB) ? OOB : (unsigned)k * (unsigned)(p.Mp * 4) + a_off;
+      const unsigned o = (pf_a == OOB) ? OOB : pf_a + (unsigned)(i * AR) * a_kstep;       // (weight rows beyond K are zero padding of the packing)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(As + (i * NT + wid * 64) * 4), 16, (int)o, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int k = kb + b_k + i * BR;
-      const unsigned o = (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4);
+      const unsigned o = (pf_b == OOB || k >= p.K) ? OOB : pf_b + (unsigned)(i * BR) * b_kstep;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(Bs + (i * NT + wid * 64) * 4), 16, (int)o, 0, 0, 0);
     }
-  };
-
-  // ---- software model of this wave's VMEM queue (vmcnt counts loads, LDS-DMA and stores alike and they retire in issue order on gfx9:
-  // the compiler's own wait insertion relies on the same).  `issued` = operations issued so far; mark[k % ST] = its value right after the
-  // loads of position k: "position k has landed" <=> at most issued - mark[k % ST] operations are outstanding.
-  int issued = 0;
-  int pf_tile = -1, pf_m0 = 0, pf_n0 = 0; unsigned pf_a = OOB, pf_b = OOB;
-  auto issue = [&](int ip) {
-    const int u = unit_at(ip), t = u / cpt, kc = u - t * cpt;
-    if (t != pf_tile) { pf_tile = t; tile_offsets(t, pf_m0, pf_n0, pf_a, pf_b); }
-    gload(kc, ip % ST, pf_a, pf_b);
     issued += NLD;
+    pf_stage = (pf_stage + 1) & (ST - 1);
+    if (++pf_kc < pf_c1) {
+      if (pf_a != OOB) pf_a += GK * a_kstep;
+      if (pf_b != OOB) pf_b += GK * b_kstep;
+    } else if (++pf_seg < nseg) pf_enter();
+    else pf_valid = false;
   };
-  // marks of the positions i + 1 and i + 2 relative to the loop variable (scalars, rotated every iteration: no dynamically indexed array)
-  static_assert(ST == 4, "the mark rotation below is written for four stages");
-  int mk0 = 0, mk1 = 0, mk2 = 0;
-  if (0 < n) { issue(0); mk0 = issued; }
-  if (1 < n) { issue(1); mk1 = issued; }
-  if (2 < n) { issue(2); mk2 = issued; }
-  wait_vm(issued - mk0);
+  static_assert(ST == 4, "the mark rotation and the stage masks are written for four stages");
+  // ---- software model of this wave's VMEM queue (vmcnt counts loads, LDS-DMA and stores alike and they retire in issue order on gfx9:
+  // the compiler's own wait insertion relies on the same).  `issued` = operations issued so far (a chunk's 3 or 4 LDS-DMA instructions are
+  // counted as 4, an over-count only waits longer); mk1 = its value right after the loads of the NEXT chunk: that chunk has landed <=> at
+  // most issued - mk1 operations are outstanding.
+  pf_enter();
+  int mk1 = 0, mk2 = 0;
+  issue();
+  const int mk0 = issued;
+  if (pf_valid) { issue(); } mk1 = issued;
+  if (pf_valid) { issue(); } mk2 = issued;
+  if (NB + NA == 4) wait_vm(issued - mk0); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  float* ssw = smem + ST * STAGE + wid * 64;                 // this wave's scale (0..31) / shift (32..63) rows
-  auto row_local = [&](int r) { return 8 * (r / 4) + (r % 4); };            // + 4 * lk + wm * 32
-  f32x16 acc;
-  float res[16];
-  float ssv = 0.f;
-  int cur_tile = -1, m0 = 0, n0 = 0;
-  unsigned pvoff = OOB;
+  float* ssw = smem + ST * STAGE + wid * 128;                // this wave's scale (0..63) / shift (64..127) rows
+  f32x16 acc[NACC];                                          // [im * FN + jn]
+  f32x2 res[FN == 2 ? 16 : 1];                               // FN = 2: residual pairs of block row im = 0, loaded a chunk ahead (im = 1 and FN = 1: in the epilogue)
+  float ssa = 0.f, ssb = 0.f;
+  // Operand fragments are read from LDS PD k-steps ahead of the MFMAs that consume them, ACROSS chunk boundaries.
+  f32x2 pa[PD]; float pb[PD][FN];
+  auto read_frag = [&](const float* As, const float* Bs, int s2, f32x2& fa, float* fb) {
+    fa = *(const f32x2*)(As + 2 * s2 * BM);
+    if (FN == 2) { const f32x2 v = *(const f32x2*)(Bs + 2 * s2 * BN); fb[0] = v[0]; fb[1] = v[1]; }
+    else fb[0] = Bs[2 * s2 * BN];
+  };
+  {
+    const float* As = smem + lk * BM + wm * 64 + 2 * li;
+    const float* Bs = smem + GK * BM + lk * BN + wn * 32 * FN + FN * li;
+#pragma unroll
+    for (int s2 = 0; s2 < PD; ++s2) read_frag(As, Bs, s2, pa[s2], pb[s2]);
+  }
+  // tile row of accumulator register r of block im: wm * 64 + 2 * (8 (r / 4) + r % 4) + 8 lk + im
+  auto row_r = [&](int r) { return 2 * (8 * (r / 4) + (r % 4)); };
 
-  for (int i = 0; i < n; ++i) {
-    const int u = unit_at(i), t = u / cpt, kc = u - t * cpt;
-    const bool seg_start = (i == 0) || (i == nT) || (i == nT + nMid) || kc == 0;
-    const bool seg_end = (kc == cpt - 1) || (i == nT - 1);
-    const bool publish = i < nT;
-    if (t != cur_tile) {
-      cur_tile = t;
-      const int lt = tA + t, n_tile = lt / a.mt;
-      m0 = (lt - n_tile * a.mt) * BM; n0 = n_tile * BN;
-      // this lane's pixel of the tile and its half-wave's 4-row step as ONE buffer offset (rows follow as wave-uniform SGPR offsets)
-      const unsigned pn = (unsigned)(n0 + wn * 32 + li);
-      pvoff = OOB;
-      if ((int)pn < p.Ntot) { const unsigned img = pn / (unsigned)p.Npix; pvoff = (img * (unsigned)p.M * (unsigned)p.Npix + (pn - img * (unsigned)p.Npix)) * 4u + (unsigned)(4 * lk) * row_bytes; }
-    }
-    int mk3 = 0;
-    if (i + ST - 1 < n) { issue(i + ST - 1); mk3 = issued; }   // into the stage read during iteration i - 1 (everybody has passed its barrier)
-    if (seg_start) {
+  int stage = 0;
+  for (int seg = 0; seg < nseg; ++seg) {
+    int tile, c0, c1;
+    seg_desc(seg, tile, c0, c1);
+    const bool publish = has_pub && seg == 0;
+    const bool finish = has_fin && seg == nseg - 1;
+    const int lt = tA + tile, n_tile = lt / a.mt;
+    const int m0 = (lt - n_tile * a.mt) * BM, n0 = n_tile * BN;
+    // this lane's first pixel of the tile and its half-wave's 8-row step as ONE buffer offset (rows follow as wave-uniform SGPR offsets)
+    const unsigned pn = (unsigned)(n0 + wn * 32 * FN + FN * li);
+    unsigned pvoff = OOB;
+    if ((int)pn < p.Ntot) { const unsigned img = pn / (unsigned)p.Npix; pvoff = (img * (unsigned)p.M * (unsigned)p.Npix + (pn - img * (unsigned)p.Npix)) * 4u + (unsigned)(8 * lk) * row_bytes; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    }
-    // the epilogue's own loads (residual values, folded-BN rows), one chunk ahead of their use where the piece is long enough
-    if (!publish && (kc == cpt - 2 || (seg_start && kc > cpt - 2))) {
-      if (p.residual) {
+    for (int b = 0; b < NACC; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int mu = m0 + wm * 32 + row_local(r);
-          res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, pvoff, (unsigned)mu * row_bytes, 0));
-        }
-        issued += 16;
-      }
-      if (p.scale) {
-        const unsigned so = (unsigned)(m0 + wm * 32 + li) * 4u;
-        ssv = __uint_as_float(lk == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rss, so, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsh, so, 0, 0));
-        issued += 4;                                         // (counted as 4: the model works in multiples of 4; over-counting only waits longer)
-      }
-    }
-    {
-      const int stage = i % ST;
-      const float* As = smem + stage * STAGE + lk * BM + wm * 32 + li;
-      const float* Bs = smem + stage * STAGE + GK * BM + lk * BN + wn * 32 + li;
-      float fa[2], fb[2];
-      fa[0] = As[0]; fb[0] = Bs[0];
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const int kc_epi = (c1 - 2 > c0) ? c1 - 2 : c0;          // the chunk under which the epilogue's own loads are issued
+    for (int kc = c0; kc < c1; ++kc) {
+      const bool has_next = (kc + 1 < c1) || (seg + 1 < nseg);
+      const int nstage = (stage + 1) & (ST - 1);
+      const float* As = smem + stage * STAGE + lk * BM + wm * 64 + 2 * li;
+      const float* Bs = smem + stage * STAGE + GK * BM + lk * BN + wn * 32 * FN + FN * li;
+      const float* An = smem + nstage * STAGE + lk * BM + wm * 64 + 2 * li;
+      const float* Bn = smem + nstage * STAGE + GK * BM + lk * BN + wn * 32 * FN + FN * li;
+      f32x2 fa[NS + PD]; float fb[NS + PD][FN];
 #pragma unroll
-      for (int s = 0; s < GK / 2; ++s) {
-        if (s + 1 < GK / 2) { fa[(s + 1) & 1] = As[2 * (s + 1) * BM]; fb[(s + 1) & 1] = Bs[2 * (s + 1) * BN]; }
-        __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1], fb[s & 1], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (seg_end) {
-      if (publish) {
-        // ---- my piece of a tile somebody else finishes: 4 x 16-byte write-through stores per lane, drain, flag ----
-        const unsigned sbase = (unsigned)(blockIdx.x * SLOT_FLOATS + wid * 1024 + lane * 4) * 4u;
+      for (int s2 = 0; s2 < PD; ++s2) { fa[s2] = pa[s2]; fb[s2][0] = pb[s2][0]; if (FN == 2) fb[s2][FN - 1] = pb[s2][FN - 1]; }
+      int mk3 = mk2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rslot, sbase + (unsigned)(q * 256 * 4), 0, 16);     // aux 16 = sc1
-        }
-        issued += 4;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave drains (also retires every prefetch in flight)
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) {
-          const unsigned long long f = ((unsigned long long)a.token << 32) | (unsigned long long)(~a.token);
-          __hip_atomic_store(a.flags + blockIdx.x, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      } else {
-        const bool finish = i >= nT + nMid && nL > 0;
-        if (finish) {
-          // ---- the pieces of this tile that earlier workgroups of my slice published: wait (bounded), add in ascending order ----
-          const long long ut = (long long)t * cpt;                               // first unit of the tile (slice-relative)
-          int jA = (int)(((ut + 1) * Gx + Ux - 1) / Ux) - 1;                     // owner of the tile's first unit
-          if (jA < 0) jA = 0;
-          const unsigned long long want = ((unsigned long long)a.token << 32) | (unsigned long long)(~a.token);
-          for (int jj = jA; jj < j; ++jj) {
-            const int q0 = (int)(Ux * jj / Gx), q1 = (int)(Ux * (jj + 1) / Gx);
-            if (q1 <= q0) continue;                                              // (an empty share publishes nothing)
-            const int bb = x + 8 * jj;
-            if (tid == 0) {
-              const long long t0 = wall_clock64();
-              while (__hip_atomic_load(a.flags + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                __builtin_amdgcn_s_sleep(2);
-                if (wall_clock64() - t0 > a.spin_limit) { atomicAdd(&g_sk_timeouts, 1u); break; }
-              }
-              __hip_atomic_store(a.flags + bb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // consumed: zero for the next launch / replay
-            }
+      for (int s = 0; s < NS; ++s) {
+        if (s == NS / 2) {
+          // ---- mid-chunk: the next chunk has landed for everybody and everybody is done with the previous one -> refill its stage ----
+          if (has_next) {
+            const int d = issued - mk1;
+            if (d == NLD) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // steady state: only the chunk after next in flight
+            else wait_vm(d);
+#ifdef FRTM_DEBUG_ABLATE
+            if (!(a.dbg & 4))
+#endif
             __builtin_amdgcn_s_barrier();
-            const unsigned sbase = (unsigned)(bb * SLOT_FLOATS + wid * 1024 + lane * 4) * 4u;
-            f32x4 pv[4];
+          }
+#ifdef FRTM_DEBUG_ABLATE
+          if (a.dbg & 2) pf_valid = false;
+#endif
+          if (pf_valid) { issue(); mk3 = issued; }
+          // the epilogue's own loads (residual values, folded-BN rows), one chunk ahead of their use where the piece is long enough
+#ifdef FRTM_DEBUG_ABLATE
+          if (!publish && kc == kc_epi && !(a.dbg & 1)) {
+#else
+          if (!publish && kc == kc_epi) {
+#endif
+            if (FN == 2 && p.residual) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rslot, sbase + (unsigned)(q * 256 * 4), 0, 16));
-            issued += 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[4 * q + e] += pv[q][e];
+              for (int r = 0; r < 16; ++r) {
+                const int mu = m0 + wm * 64 + row_r(r);
+                res[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, pvoff, (unsigned)mu * row_bytes, 0));
+              }
+              issued += 16;
+            }
+            if (p.scale) {
+              const unsigned so = (unsigned)(m0 + wm * 64 + lane) * 4u;
+              ssa = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rss, so, 0, 0));
+              ssb = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsh, so, 0, 0));
+              issued += 4;                                   // (2 loads counted as 4)
+            }
           }
         }
-        // ---- epilogue straight from the 32x32 C layout: for a fixed accumulator register the 32 lanes of a half-wave hold 32
-        // consecutive pixels of one channel (128-byte segments); folded-BN rows through this wave's LDS strip ----
-        if (p.scale) {
-          ssw[lane] = ssv;                                   // lanes 0-31 scale[m0 + wm*32 + li], lanes 32-63 shift[...]
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+#ifdef FRTM_DEBUG_ABLATE
+        if (a.dbg & 8) { fa[s + PD] = fa[s]; fb[s + PD][0] = fb[s][0]; fb[s + PD][FN - 1] = fb[s][FN - 1]; } else
+#endif
+        if (s + PD < NS) read_frag(As, Bs, s + PD, fa[s + PD], fb[s + PD]);
+        else if (has_next) read_frag(An, Bn, s + PD - NS, fa[s + PD], fb[s + PD]);      // next chunk (landed: mid-chunk barrier)
+        else { fa[s + PD] = f32x2{0.f, 0.f}; fb[s + PD][0] = 0.f; if (FN == 2) fb[s + PD][FN - 1] = 0.f; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = row_local(r);
-          const int mu = m0 + wm * 32 + rl;
-          float v = acc[r];
-          if (p.scale) v = v * ssw[rl + 4 * lk] + ssw[32 + rl + 4 * lk];
-          if (p.residual) v += res[r];
-          if (p.relu) v = fmaxf(v, 0.f);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, pvoff, (unsigned)mu * row_bytes, 0);
+        for (int im = 0; im < 2; ++im)
+#pragma unroll
+          for (int jn = 0; jn < FN; ++jn)
+            acc[im * FN + jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][im], fb[s][jn], acc[im * FN + jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < PD; ++s2) { pa[s2] = fa[NS + s2]; pb[s2][0] = fb[NS + s2][0]; if (FN == 2) pb[s2][FN - 1] = fb[NS + s2][FN - 1]; }
+      mk1 = mk2; mk2 = mk3;
+      stage = nstage;
+    }
+    // ---------------------------------------------------------------- end of the segment
+    if (publish) {
+      // ---- my piece of a tile somebody else finishes: 16-byte write-through stores, every wave drains, one flag ----
+      const unsigned sbase = (unsigned)(blockIdx.x * SLOT_FLOATS + wid * (SLOT_FLOATS / 4) + lane * 4) * 4u;
+#pragma unroll
+      for (int b = 0; b < NACC; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[b][4 * q], acc[b][4 * q + 1], acc[b][4 * q + 2], acc[b][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rslot, sbase + (unsigned)((b * 4 + q) * 256 * 4), 0, 16);     // aux 16 = sc1
         }
-        issued += 16;
+      issued += 4 * NACC;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains (also retires every prefetch in flight)
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) {
+        const unsigned long long f = ((unsigned long long)a.token << 32) | (unsigned long long)(~a.token);
+        __hip_atomic_store(a.flags + blockIdx.x, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (finish) {
+      // ---- the pieces of this tile that earlier workgroups of my slice published: wait (bounded), add in ascending order ----
+      const long long ut = (long long)t_first * cpt;                               // first tail unit of the tile
+      int jA = (int)(((ut + 1) * Gx + Ut - 1) / Ut) - 1;                           // owner of the tile's first unit
+      if (jA < 0) jA = 0;
+      const unsigned long long want = ((unsigned long long)a.token << 32) | (unsigned long long)(~a.token);
+      for (int jj = jA; jj < j; ++jj) {
+        const int q0 = (int)(Ut * jj / Gx), q1 = (int)(Ut * (jj + 1) / Gx);
+        if (q1 <= q0) continue;                                                    // (an empty share publishes nothing)
+        const int bb = x + 8 * jj;
+        if (tid == 0) {
+          const long long t0 = wall_clock64();
+          while (__hip_atomic_load(a.flags + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > a.spin_limit) { atomicAdd(&g_sk_timeouts, 1u); break; }
+          }
+          __hip_atomic_store(a.flags + bb, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // consumed: zero for the next launch / replay
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned sbase = (unsigned)(bb * SLOT_FLOATS + wid * (SLOT_FLOATS / 4) + lane * 4) * 4u;
+#pragma unroll
+        for (int b = 0; b < NACC; ++b) {
+          f32x4 pv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rslot, sbase + (unsigned)((b * 4 + q) * 256 * 4), 0, 16));
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[b][4 * q + e] += pv[q][e];
+        }
+        issued += 4 * NACC;
       }
     }
-    if (i + 1 < n) {
-      wait_vm(issued - mk1);                                 // position i + 1 has landed (this wave's part)
+    // ---- epilogue straight from the 32x32 C layouts.  Interleaved blocks: for a fixed (im, r) the 32 lanes of a half-wave hold FN
+    // consecutive pixels each of ONE channel row -- 256-byte (FN = 2: dwordx2 per lane) or 128-byte runs; folded-BN rows through this
+    // wave's LDS strip ----
+    if (p.scale) {
+      ssw[lane] = ssa; ssw[64 + lane] = ssb;                 // scale / shift of the wave's 64 channel rows
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                          // ... everybody's has, and everybody is done reading stage i % ST
     }
-    mk0 = mk1; mk1 = mk2; mk2 = mk3;
+#ifdef FRTM_DEBUG_ABLATE
+    if ((a.dbg & 1) && acc[0][0] != 12345.678f) continue;
+#endif
+    f32x2 res1[FN == 2 ? 16 : 1];
+    if (FN == 2 && p.residual) {                             // block row im = 1: in flight while im = 0 leaves
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = m0 + wm * 64 + row_r(r) + 1;
+        res1[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, pvoff, (unsigned)mu * row_bytes, 0));
+      }
+    }
+#pragma unroll
+    for (int im = 0; im < 2; ++im)
+#pragma unroll
+      for (int h8 = 0; h8 < 2; ++h8) {
+        float scv[8], shv[8];
+        if (p.scale) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const int r = h8 * 8 + q; scv[q] = ssw[row_r(r) + 8 * lk + im]; shv[q] = ssw[64 + row_r(r) + 8 * lk + im]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = h8 * 8 + q;
+          const int mu = m0 + wm * 64 + row_r(r) + im;
+          float v0_ = acc[im * FN][r], v1_ = FN == 2 ? acc[im * FN + FN - 1][r] : 0.f;
+          if (p.scale) { v0_ = v0_ * scv[q] + shv[q]; v1_ = v1_ * scv[q] + shv[q]; }
+          if (p.residual) {
+            if (FN == 2) { const f32x2 rv = im == 0 ? res[r] : res1[r]; v0_ += rv[0]; v1_ += rv[1]; }
+            else v0_ += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rres, pvoff, (unsigned)mu * row_bytes, 0));
+          }
+          if (p.relu) { v0_ = fmaxf(v0_, 0.f); v1_ = fmaxf(v1_, 0.f); }
+          if (FN == 2) {
+            const f32x2 o = {v0_, v1_};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rout, pvoff, (unsigned)mu * row_bytes, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0_), rout, pvoff, (unsigned)mu * row_bytes, 0);
+          }
+        }
+      }
+    issued += p.residual ? 64 : 32;                          // (im = 1 residual loads / FN = 1 residual loads + the stores; an over-count only waits longer)
   }
-  (void)mk0;
 }
 
 std::atomic<unsigned> g_token{1};
 
 }  // namespace
 
-// Scratch (floats) the stream-K form needs at the END of a conv workspace: per workgroup one 64x64 slot, one 8-byte flag, + the error word.
-static inline size_t sk_scratch_floats(int G) { return (size_t)G * SLOT_FLOATS + (size_t)G * 2 + 16; }
+static inline size_t sk_scratch_floats(int G, int BN) { return (size_t)G * BM * BN + (size_t)G * 2 + 16; }
 
 static int sk_wpc() {
-  static const int v = getenv("FRTM_SK_WPC") ? std::max(1, std::min(4, atoi(getenv("FRTM_SK_WPC")))) : 2;
+  static const int v = getenv("FRTM_SK_WPC") ? std::max(1, std::min(2, atoi(getenv("FRTM_SK_WPC")))) : 2;
   return v;
 }
 
+static inline int sk_fn(const ConvParams& p) { return (p.w_img_stride && p.Npix % 128) ? 1 : 2; }
+
 // 0 = not eligible (the caller takes another kernel), else the grid size.
-int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems) {
-  static const bool on = !(getenv("FRTM_SK") && atoi(getenv("FRTM_SK")) == 0);
-  if (!on) return 0;
+// OPT-IN (FRTM_SK=1, or tile = FRTM_TILE_SK_64x64): measured behind the tiled kernels in round 4 (profiles/r04_stream_k.txt).
+int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems, bool forced) {
+  static const bool on = getenv("FRTM_SK") && atoi(getenv("FRTM_SK")) != 0;
+  if (!on && !forced) return 0;
   if (p.M % BM || p.Npix % 4 || p.Mp % 4 || ((size_t)p.wT) % 16 || ((size_t)p.in) % 16) return 0;
   if ((size_t)p.Ntot * p.M * 4 >= (1ull << 31)) return 0;
+  const int BN = 64 * sk_fn(p);
   if (p.w_img_stride && ((size_t)p.w_bytes * p.B >= (1ull << 31) || p.Npix % BN)) return 0;
   const long ntiles = (long)ceil_div(p.Ntot, BN) * (p.M / BM);
-  const long units = ntiles * p.nchunks;
-  if (ntiles < 512) return 0;                       // small launches keep the split-K planner
+  const long units = ntiles * p.nchunks * 2;
+  if ((long)ceil_div(p.Ntot, 64) * (p.M / 64) < 512) return 0;        // small launches keep the split-K planner
   int Gx = 32 * sk_wpc();                           // workgroups per XCD (32 CUs each)
-  while (Gx > 1 && units / (8L * Gx) < 4) Gx >>= 1;
+  while (Gx > 1 && units / (8L * Gx) < 8) Gx >>= 1;
   const int G = 8 * Gx;
-  if (ws_elems < ws_used_elems + sk_scratch_floats(G)) return 0;
+  if (ws_elems < ws_used_elems + sk_scratch_floats(G, BN)) return 0;
   return G;
 }
 
 // The caller guarantees: 1x1 / stride 1 / NCHW, no split-K, `ws` not used by any concurrent launch; the scratch is the workspace's tail.
 int frtm_sk_launch(const ConvParams& p, float* ws, size_t ws_elems, int G, hipStream_t st) {
-  static bool attr_set = false;
-  const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    FRTM_HIP(hipFuncSetAttribute((const void*)k_gemm_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  const int FN = sk_fn(p), BN = 64 * FN;
+  const size_t lds = (size_t)(ST * GK * (BM + BN) + 4 * 128) * sizeof(float);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[FN]) {
+    if (FN == 2) FRTM_HIP(hipFuncSetAttribute((const void*)k_gemm_sk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else FRTM_HIP(hipFuncSetAttribute((const void*)k_gemm_sk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[FN] = true;
   }
-  float* tail = ws + ws_elems - sk_scratch_floats(G);
+  float* tail = ws + ws_elems - sk_scratch_floats(G, BN);
   tail = (float*)(((size_t)tail + 15) & ~(size_t)15);
   SKArgs a;
-  a.ntiles = ceil_div(p.Ntot, BN) * (p.M / BM); a.mt = p.M / BM; a.cpt = p.nchunks;
+  a.ntiles = ceil_div(p.Ntot, BN) * (p.M / BM); a.mt = p.M / BM; a.cpt = p.nchunks * 2;
   a.slots = tail;
-  a.flags = (unsigned long long*)(tail + (size_t)G * SLOT_FLOATS);
+  a.flags = (unsigned long long*)(tail + (size_t)G * BM * BN);
   a.token = g_token.fetch_add(1);
   if (a.token == 0) a.token = g_token.fetch_add(1);
   a.spin_limit = 200000000LL;                       // 2 s
-  k_gemm_sk<<<G, NT, lds, st>>>(p, a);
+  a.dbg = 0;
+#ifdef FRTM_DEBUG_ABLATE
+  a.dbg = getenv("FRTM_SK_DBG") ? atoi(getenv("FRTM_SK_DBG")) : 0;
+#endif
+  if (FN == 2) k_gemm_sk<2><<<G, NT, lds, st>>>(p, a);
+  else k_gemm_sk<1><<<G, NT, lds, st>>>(p, a);
   return FRTM_OK;
 }
 

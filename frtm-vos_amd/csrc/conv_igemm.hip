@@ -30,7 +30,7 @@ int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile,
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
 // conv_gemm_sk.hip (round 4): persistent stream-K GEMM; plan returns 0 when the launch is not eligible (small, odd shapes, no scratch)
-int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems);
+int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems, bool forced);
 int frtm_sk_launch(const ConvParams& p, float* ws, size_t ws_elems, int G, hipStream_t st);
 // FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
 // measured equal inside the trunk (round 3, rocprofv3 kernel trace of tools/trunk_bench.py 8 1: 78.4 vs 76.9 us per 1x1 launch,
@@ -477,7 +477,7 @@ static int halo_tile_width(int Ho, int Wo) {
 int frtm_igemm_batched(const ConvParams& q, int tile, float* scratch, size_t scratch_elems, hipStream_t st) {
   if (q.Npix % 64 || !q.w_img_stride) { frtm_set_error("frtm_igemm_batched: Npix must be a multiple of 64"); return FRTM_ERR_ARG; }
   if (tile == 0 || tile == FRTM_TILE_SK_64x64) {            // round 4: the persistent stream-K kernel where the launch is large enough
-    const int G = scratch ? frtm_sk_plan(q, scratch_elems, 0) : 0;
+    const int G = scratch ? frtm_sk_plan(q, scratch_elems, 0, tile == FRTM_TILE_SK_64x64) : 0;
     if (G > 0) {
       int rc = frtm_sk_launch(q, scratch, scratch_elems, G, st);
       if (rc) return rc;
@@ -604,7 +604,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if ((tile == 0 || tile == FRTM_TILE_SK_64x64) && splitk <= 1 && vec1x1 && !halo_layout_requested(d) && !d->out_transposed) {
     ConvParams q = p;
     q.splitk = 1; q.chunks_per_split = q.nchunks;
-    const int G = workspace ? frtm_sk_plan(q, (size_t)std::max(d->ws_elems, 0), 0) : 0;
+    const int G = workspace ? frtm_sk_plan(q, (size_t)std::max(d->ws_elems, 0), 0, tile == FRTM_TILE_SK_64x64) : 0;
     if (G > 0) {
       int rc = frtm_sk_launch(q, workspace, (size_t)d->ws_elems, G, (hipStream_t)stream);
       if (rc) return rc;

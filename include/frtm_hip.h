@@ -290,9 +290,10 @@ typedef struct {
 #define FRTM_TILE_G32_128x128_S3 27
 #define FRTM_TILE_G32_128x64_S3 28
 #define FRTM_TILE_G32P_64x64 30     /* persistent workgroups: loads across tile boundaries, epilogue of a tile under the next tile's K loop */
-#define FRTM_TILE_SK_64x64 31       /* round 4 (csrc/conv_gemm_sk.hip): persistent STREAM-K workgroups, two per CU, 4-stage LDS-DMA ring; needs >= 512 tiles,
-                                       Cout % 64 == 0 and FRTM_CONV_SK_SCRATCH_ELEMS floats of workspace; tile = 0 (auto) takes it where eligible */
-#define FRTM_CONV_SK_SCRATCH_ELEMS (1024 * 4096 + 1024 * 2 + 64)   /* upper bound of the stream-K scratch at the END of the workspace (floats) */
+#define FRTM_TILE_SK_64x64 31       /* round 4 (csrc/conv_gemm_sk.hip): persistent STREAM-K workgroups (128x128 tiles, two workgroups per CU, 4-stage LDS-DMA ring);
+                                       needs >= 512 64x64-tile equivalents, Cout % 128 == 0 and FRTM_CONV_SK_SCRATCH_ELEMS floats of workspace.  Opt-in: this
+                                       tile id, or FRTM_SK=1 in the environment for tile = 0 (measured behind the tiled kernels, profiles/r04_stream_k.txt) */
+#define FRTM_CONV_SK_SCRATCH_ELEMS (512 * 16384 + 512 * 2 + 64)   /* upper bound of the stream-K scratch at the END of the workspace (floats) */
 /* Stream-K GEMM (csrc/conv_gemm_sk.hip): inter-workgroup hand-off spins that ran into their 2 s time-out since the library was loaded.
  * 0 on a healthy run; anything else means a conv result may be wrong (the caller should stop and set FRTM_SK=0).  Synchronises the
  * device.  No reference counterpart (the reference's convs are cuDNN calls, model/feature_extractor.py:50-65). */

@@ -172,7 +172,8 @@ def _sk_case(B, cin, cout, h, w, seed, residual=True, scale=True, relu=True):
     (8, 64, 256, 120, 214),        # 2 chunks per tile, 12 840 tiles
     (4, 2048, 512, 16, 28),        # 64 chunks per tile, 224 -> not eligible (fewer than 512 tiles): must be refused when forced
     (3, 96, 128, 60, 108),         # K = 96 = 3 chunks; 608 tiles; images of 6 480 pixels (not a multiple of 64: tiles straddle images)
-    (2, 40, 64, 128, 260),         # K = 40: a ragged last chunk (zero rows of the packed weights, out-of-bounds activation rows)
+    (2, 40, 128, 128, 260),        # K = 40: a ragged last chunk (zero rows of the packed weights, out-of-bounds activation rows)
+    (2, 40, 64, 128, 260),         # Cout = 64 is not a multiple of the 128-row tile: refused when forced
 ])
 def test_stream_k_gemm_against_fp64(shape):
     """k_gemm_sk (persistent stream-K 1x1 conv GEMM) against a float64-accumulated reference, forced (tile = FRTM_TILE_SK_64x64) and as the
@@ -185,15 +186,15 @@ def test_stream_k_gemm_against_fp64(shape):
     ws = torch.empty(1 << 24, device=DEV)
     ws.uniform_(-1, 1)                                     # the scratch is NOT zeroed by anybody: flags must not depend on it
     ntiles = -(-B * h * w // 64) * (cout // 64)
-    if ntiles < 512:
+    if ntiles < 512 or cout % 128:                         # not eligible: refused when forced (tile = 0 falls back to the tiled kernels)
         with pytest.raises(RuntimeError):
             ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
         return
     out = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
     err = float((out.double() - ref).abs().max() / ref.abs().max())
     assert err < 3e-6, err
-    auto = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, ws=ws)      # tile 0: the planner takes stream-K here
-    assert torch.equal(auto, out)
+    auto = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, ws=ws)      # tile 0: the planner's choice (stream-K only with FRTM_SK=1)
+    assert float((auto - out).abs().max() / ref.abs().max()) < 3e-6
     old = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=4, splitk=1)       # k_conv_igemm 64x64 8 waves
     assert float((old - out).abs().max() / ref.abs().max()) < 3e-6
     side = torch.cuda.Stream()
@@ -239,22 +240,23 @@ def test_stream_k_plain_epilogue_and_graph_replay():
 
 @pytest.mark.parametrize('m', [4, 6])
 def test_winograd_products_on_stream_k_equal_the_tiled_kernel(m):
-    """The batched products of the three-launch Winograd forms (36 / 64 GEMMs with one weight matrix each) on the stream-K kernel -- taken
-    automatically when the workspace has the scratch behind V and M -- against the same conv with a workspace WITHOUT it (k_conv_igemm)."""
+    """The batched products of the three-launch Winograd forms (36 / 64 GEMMs with one weight matrix each) on the stream-K kernel (tile =
+    FRTM_TILE_SK_64x64 with the scratch behind V and M in the workspace: the 128 x 64 form, the products' "images" are padded to 64 columns)
+    against the same conv on the tiled kernel (k_conv_igemm)."""
     from frtm_vos_amd import ops
     g = torch.Generator().manual_seed(3)
     B, C, h, w = 8, 256, 30, 54
     x = torch.randn(B, C, h, w, generator=g).to(DEV)
     wt = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(DEV)
     layout = 3 if m == 4 else 4
-    wT, _, _ = ops.pack_weights(wt, layout=layout)
+    wT, _, _ = ops.pack_weights(wt, wino4=(m == 4), wino6=(m == 6))
     th, tw = -(-h // m), -(-w // m)
     Tp = (B * th * tw + 63) // 64 * 64
     need = (m + 2) ** 2 * 2 * C * Tp
-    small, big = torch.empty(need, device=DEV), torch.empty(need + (1 << 22) + 4096, device=DEV)
+    small, big = torch.empty(need, device=DEV), torch.empty(need + 512 * 16384 + 2048, device=DEV)
     a = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=small)
-    b = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=big)
+    b = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=big, tile=31)
     ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
     ea, eb = float((a.double() - ref).abs().max() / ref.abs().max()), float((b.double() - ref).abs().max() / ref.abs().max())
-    assert eb < 3e-5 and eb < 2 * ea + 1e-6, (ea, eb)
-    assert float((a - b).abs().max() / ref.abs().max()) < 1e-5
+    assert eb < 4e-5 and eb < 2 * ea + 1e-6, (ea, eb)
+    assert float((a - b).abs().max() / ref.abs().max()) < 3e-5        # (k is summed in pairs instead of quadruples: the output transform amplifies that rounding)
