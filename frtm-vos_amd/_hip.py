@@ -88,6 +88,14 @@ SIGNATURES = {
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_affine_u8': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_mask_batch': (I, [P, I, I, P, I, I, P, I, P, P]),
+    'frtm_mask_stats': (I, [P, I, I, I, P, P]),
+    'frtm_aug_prepare': (I, [P, P, I, I, P, P, P, P, P]),
+    'frtm_pull_push_fill': (I, [P, ctypes.c_size_t, I, I, P]),
+    'frtm_pull_push_elems': (ctypes.c_size_t, [I, I]),
+    'frtm_aug_transforms': (I, [P, I, P, I, I, P, P, P]),
+    'frtm_warp_mask_batch_dev': (I, [P, I, I, P, I, I, P, I, P, P]),
+    'frtm_warp_affine_batch': (I, [P, I, I, I, P, I, I, P, P, I, P]),
+    'frtm_aug_blend': (I, [P, P, I, I, I, P, P, P, P, P]),
     'frtm_blur2d': (I, [P, I, I, I, P, I, I, P, P]),
     'frtm_blur_gauss2d': (I, [P, I, I, I, I, F, F, F, P, P]),
 }

@@ -7,8 +7,12 @@ here, so pixel-level parity is UNPINNED; what is kept is the recipe: the same pa
 (evaluate.py:53-76), the same draws from numpy's global RNG in the same order (AugmentationParams2's attribute order, default
 lists included; seeded by the tracker per object; pinned by tests/test_cpu_host.py against the reference's generate_specs2),
 the same transform composition T = translate . skew . rotate . scale . translate(-target) and paste rule.
-Everything runs on the GPU: warps by the HIP kernel (csrc/image_ops.hip), the hole is filled by masked
-diffusion (a substitute for Telea inpainting), blur by a small depth-wise convolution.
+Everything runs on the GPU as HIP kernels (csrc/image_ops.hip; round 4: no ATen launch is left in here): pixel count / bounding
+box, the cut, the pull-push hole fill (a documented substitute for Telea inpainting), the affine matrices of the candidates (formed
+ON THE DEVICE from the device-side bounding box), the 19 candidate label warps + counts, the batched bicubic warps of the survivors,
+blur, paste.  The host reads ONE record per object -- pixel count, bounding box and the candidate counts together -- because the
+reference's candidate selection (verify_frame + shuffle, augmenter.py:454-471,538-544) is host logic on numpy's RNG stream: how many
+draws it consumes depends on the counts.  Pixel pipeline pinned by oracle/aug_ref.py (tests/test_round4_gpu.py).
 """
 from copy import deepcopy
 
@@ -110,29 +114,37 @@ class ImageAugmenter:
 
     # ---- image pieces -----------------------------------------------------------------------------
     @staticmethod
+    def _mask_stats(mask):
+        """Device int32[5] {count, max(x+1), max(W-x), max(y+1), max(H-y)} of a (.., H, W) mask (uint8 or float) -- no host read."""
+        m = mask.reshape(mask.shape[-2], mask.shape[-1])
+        m = m.contiguous() if m.dtype == torch.uint8 else m.float().contiguous()
+        out = torch.empty(5, dtype=torch.int32, device=m.device)
+        H.call('frtm_mask_stats', m.data_ptr(), int(m.dtype == torch.uint8), m.shape[0], m.shape[1], out.data_ptr())
+        return out
+
+    @staticmethod
+    def _decode_stats(vals, im_sz):
+        """(pixel count, (cx, cy, w, h)) from the host copy of a _mask_stats record."""
+        n_px, a, b, c, d = (int(v) for v in vals[:5])
+        if n_px == 0:
+            return 0, (0, 0, 0, 0)
+        x1, x0, y1, y0 = a - 1, im_sz[1] - b, c - 1, im_sz[0] - d
+        w, h = x1 - x0 + 1, y1 - y0 + 1
+        return n_px, (x0 + w / 2, y0 + h / 2, w, h)
+
+    @staticmethod
     def _bbox(mask):
         return ImageAugmenter._count_and_bbox(mask)[1]
 
     @staticmethod
     def _count_and_bbox(mask):
-        """(pixel count, (cx, cy, w, h)) of a binary mask with ONE device -> host transfer (each int(tensor) is a stream sync)."""
-        m = mask.squeeze() > 0
-        Hh, Ww = m.shape
-        rows, cols = m.any(dim=-1), m.any(dim=-2)
-        ri = torch.arange(Hh, device=m.device)
-        ci = torch.arange(Ww, device=m.device)
-        big = max(Hh, Ww)
-        vals = torch.stack((m.sum(), torch.where(cols, ci, big).min(), torch.where(cols, ci, -1).max(),
-                            torch.where(rows, ri, big).min(), torch.where(rows, ri, -1).max())).tolist()
-        n_px, x0, x1, y0, y1 = (int(v) for v in vals)
-        if n_px == 0:
-            return 0, (0, 0, 0, 0)
-        w, h = x1 - x0 + 1, y1 - y0 + 1
-        return n_px, (x0 + w / 2, y0 + h / 2, w, h)
+        """(pixel count, (cx, cy, w, h)) of a binary mask: one kernel, ONE device -> host transfer."""
+        return ImageAugmenter._decode_stats(ImageAugmenter._mask_stats(mask).tolist(), mask.shape[-2:])
 
     @staticmethod
     def _warp_masks(mask, transforms, im_sz):
-        """Nearest-neighbour warps of one (1,H,W) mask under all `transforms` in one launch -> ((n,1,H,W) uint8 {0,1}, [pixel counts])."""
+        """Nearest-neighbour warps of one (1,H,W) mask under all `transforms` (host matrices) in one launch -> ((n,1,H,W) uint8 {0,1},
+        [pixel counts]).  (augment_first_frame itself uses the device-matrix form, frtm_warp_mask_batch_dev.)"""
         import ctypes
         n = len(transforms)
         src = mask.reshape(mask.shape[-2], mask.shape[-1]).float().contiguous()
@@ -143,25 +155,27 @@ class ImageAugmenter:
         return dst, cnt.tolist()
 
     @staticmethod
-    def _fill_hole(image, hole, iters=None):
-        """Pull-push hole filling: average the known pixels down a 2x pyramid until the hole closes, then push the
-        coarse values back up into the unknown pixels.  O(log size) passes (the masked 3x3 diffusion it replaces needed
-        one pass per pixel of hole radius).  Stand-in for OpenCV's Telea inpainting (augmenter.py:317, unpinned)."""
-        img = image.float() * (1 - hole)
-        known = (1 - hole).expand(1, -1, -1).clone()
-        levels = []
-        cur, k = img[None], known[None]
-        while min(cur.shape[-2:]) > 2 and len(levels) < 10:
-            levels.append((cur, k))
-            s = F.avg_pool2d(cur * k, 2, ceil_mode=True)
-            kk = F.avg_pool2d(k, 2, ceil_mode=True)
-            cur = s / kk.clamp(min=1e-6)
-            k = (kk > 0).float()
-        fill = cur
-        for fine, kf in reversed(levels):
-            up = F.interpolate(fill, size=fine.shape[-2:], mode='bilinear', align_corners=False)
-            fill = torch.where(kf > 0, fine, up)
-        return fill[0]
+    def _spec_row(spec, limit_scale=True):
+        """The 10 numbers frtm_aug_transforms takes per candidate (see csrc/image_ops.hip: k_aug_transforms)."""
+        s = spec.get('scale', 1.0)
+        rel = isinstance(s, str)
+        kx, ky = spec.get('skew', (0.0, 0.0))
+        loc = spec.get('location', spec.get('tcenter'))
+        return [float(s), 1.0 if rel else 0.0, 1.0 if spec.get('fliplr', False) else 0.0, float(spec.get('rotation', 0.0)), float(kx), float(ky),
+                float(loc[0]), float(loc[1]), float(spec.get('min_size', 10)), 1.0 if limit_scale else 0.0]
+
+    @staticmethod
+    def _blur_spec(spec):
+        """('gauss', half, qa, qb, qc) of a spec's motion blur, or None (reference :262-283; the kernel is formed on the device)."""
+        bs = spec.get('blur_size', 0.0)
+        if not bs > 0:
+            return None
+        b = np.deg2rad(spec.get('blur_angle', 0.0))
+        R = _mat([[np.cos(b), np.sin(b)], [-np.sin(b), np.cos(b)]])
+        icov = np.linalg.inv(R @ np.diag((bs, 0.1)) @ R.T)
+        half = int(bs / 2 + 0.5)
+        half = half + (half + 1) % 2
+        return ('gauss', int(half), float(icov[0, 0]), float(0.5 * (icov[0, 1] + icov[1, 0])), float(icov[1, 1]))
 
     @staticmethod
     def _blur(x, G):
@@ -179,59 +193,125 @@ class ImageAugmenter:
         H.call('frtm_blur2d', H.ptr(src), src.shape[0], src.shape[1], src.shape[2], H.ptr(k), G.shape[0], G.shape[1], H.ptr(out))
         return out
 
+    def _scratch(self, im_sz, device):
+        """Per (size, device) buffers of the pipeline, allocated once: cut-out, fill pyramid, mask, candidate planes, warped stacks."""
+        key = (tuple(im_sz), str(device))
+        sc = getattr(self, '_scr', None)
+        if sc is None or sc['key'] != key:
+            Hh, Ww = im_sz
+            hw, N = Hh * Ww, self.params.num_aug - 1
+            f = dict(device=device, dtype=torch.float32)
+            sc = self._scr = dict(key=key, target=torch.empty(4, Hh, Ww, **f), maskf=torch.empty(Hh, Ww, **f),
+                                  pyr=torch.empty(int(H.lib().frtm_pull_push_elems(Hh, Ww)), **f),
+                                  labs=torch.empty(19, 1, Hh, Ww, dtype=torch.uint8, device=device),
+                                  wt=torch.empty(N, 4, Hh, Ww, **f), wt2=torch.empty(N, 4, Hh, Ww, **f),
+                                  cv=torch.empty(N, 3, Hh, Ww, **f), cv2=torch.empty(N, 3, Hh, Ww, **f),
+                                  rec=torch.empty(5 + 19, dtype=torch.int32, device=device),
+                                  fwd=torch.empty(19, 6, **f), inv=torch.empty(19, 6, **f))
+        return sc
+
     def augment_first_frame(self, im, lb):
         p = self.params
-        im_sz = tuple(im.shape[-2:])
-        n_px, box = self._count_and_bbox(lb)
-        if n_px < p.min_px_count:
-            raise ValueError('Augmentation failed: Target object is too small.')
-        no_background = n_px == lb.numel()
-        if box[-2:] == (0, 0):
-            raise ValueError('Augmentation failed: No object to augment.')
-        mask = (lb.reshape(1, *im_sz) > 0).float()
-        target = torch.cat((im.float() * mask, mask * 255))                       # RGBA cut-out
-        hole = F.max_pool2d(mask[None], 3, 1, 1)[0]                               # object + 1 px rim
-        background = self._fill_hole(im, hole, iters=int(max(box[2], box[3]) / 2) + 4).clamp(0, 255).floor()
+        im_sz = tuple(int(v) for v in im.shape[-2:])
+        Hh, Ww = im_sz
+        dev = im.device
+        H.require_gpu(im, 'augment_first_frame')
+        im8 = im.reshape(3, Hh, Ww).to(torch.uint8).contiguous()
+        lb8 = lb.reshape(Hh, Ww).to(torch.uint8).contiguous()
+        sc = self._scratch(im_sz, dev)
+        N, NS = p.num_aug - 1, 19
+        rec = sc['rec']
+        # ---- everything that does not need a host decision, enqueued back to back: statistics of the mask, the cut, the fill
+        H.call('frtm_mask_stats', lb8.data_ptr(), 1, Hh, Ww, rec.data_ptr())
+        pyr = sc['pyr']
+        images = torch.empty(N + 1, 3, Hh, Ww, dtype=torch.uint8, device=dev)
+        labels = torch.empty(N + 1, 1, Hh, Ww, dtype=torch.uint8, device=dev)
+        H.call('frtm_aug_prepare', im8.data_ptr(), lb8.data_ptr(), Hh, Ww, H.ptr(sc['target']), H.ptr(pyr), H.ptr(sc['maskf']),
+               labels[0].data_ptr())                                                  # (sample 0's label = the binarised input label)
+        H.call('frtm_pull_push_fill', H.ptr(pyr), pyr.numel(), Hh, Ww)
+        background = pyr[:3 * Hh * Ww].view(3, Hh, Ww)
 
         fg = deepcopy(dict(p.fg_aug_params))
         fg['location'] = self._target_locations(p.num_aug, im_sz)
         bg = deepcopy(dict(p.bg_aug_params)) if 'bg_aug_params' in p else None
-        N = p.num_aug - 1
         # Reference quirk kept (augmenter.py:524-526): the spec generator is built from fg_aug_params / bg_aug_params, which carry no
         # num_aug, so AugmentationParams2's default (20) rules and EVERY round draws 19 candidate specs; all good candidates are
-        # collected and, being more than N, shuffled and cropped to N (:538-544).  To keep the same draws without paying for 19
-        # composites, only the candidates' LABEL warps are formed first (one nearest-neighbour plane each, their pixel counts come
-        # back in one transfer -- that is all verify_frame looks at, :454-471); images are composed for the N survivors only.
-        NS = 19
+        # collected and, being more than N, shuffled and cropped to N (:538-544).  Only the candidates' LABEL warps are formed first (one
+        # nearest-neighbour plane each; their pixel counts are all verify_frame looks at, :454-471); images are composed for the N
+        # survivors only.  The matrices come from the device-side bounding box, so round 1 is enqueued without any host read.
         cand, retries = [], -1
-        bg_box = (im_sz[1] / 2, im_sz[0] / 2, im_sz[1], im_sz[0])
+        bg_box = (Ww / 2, Hh / 2, Ww, Hh)
+        n_px = box = None
         while len(cand) < N:
             retries += 1
             if retries > self.max_retries:
                 raise RuntimeError('Augmentation failed: Not enough samples after %d retries.' % self.max_retries)
             fg_specs = self._draw_specs(fg, NS)
             bg_specs = self._draw_specs(bg, NS) if bg is not None else [None] * NS
-            tg = [self._transform(fs, box, im_sz) for fs in fg_specs]
-            labs, counts = self._warp_masks(mask, [T for T, _ in tg], im_sz)          # one launch, one transfer
-            for j, (fs, bs, (T, G), cnt) in enumerate(zip(fg_specs, bg_specs, tg, counts)):
-                if cnt >= p.min_px_count and (cnt < labs[j].numel() - p.min_px_count or no_background):
-                    cand.append((fs, bs, T, G, labs[j]))
+            spec = H.upload(torch.tensor([self._spec_row(fs) for fs in fg_specs], dtype=torch.float64), dev)
+            fwd, inv = (sc['fwd'], sc['inv']) if retries == 0 else (torch.empty_like(sc['fwd']), torch.empty_like(sc['inv']))
+            labs = sc['labs'] if retries == 0 else torch.empty_like(sc['labs'])
+            H.call('frtm_aug_transforms', spec.data_ptr(), NS, rec.data_ptr(), Hh, Ww, H.ptr(fwd), H.ptr(inv))
+            H.call('frtm_warp_mask_batch_dev', H.ptr(sc['maskf']), Hh, Ww, labs.data_ptr(), Hh, Ww, H.ptr(inv), NS, rec.data_ptr() + 20)
+            vals = rec.tolist()                                                        # THE device -> host read of this object
+            if n_px is None:
+                n_px, box = self._decode_stats(vals, im_sz)
+                if n_px < p.min_px_count:
+                    raise ValueError('Augmentation failed: Target object is too small.')
+                if box[-2:] == (0, 0):
+                    raise ValueError('Augmentation failed: No object to augment.')
+                no_background = n_px == Hh * Ww
+            for j, (fs, bs, cnt) in enumerate(zip(fg_specs, bg_specs, vals[5:])):
+                if cnt >= p.min_px_count and (cnt < Hh * Ww - p.min_px_count or no_background):
+                    cand.append((fs, bs, inv, labs, j, fwd))
         if len(cand) > N:
             order = list(range(len(cand)))
             np.random.shuffle(order)
             cand = [cand[i] for i in order[:N]]
-        images, labels = [], []
-        for fs, bs, T, G, lab in cand:
-            canvas = background
-            if bs is not None:
-                bs = dict(bs)
-                bs.setdefault('location', bs.get('tcenter', (0.5, 0.5)))
-                Tb, Gb = self._transform(bs, bg_box, im_sz, limit_scale=False)
-                canvas = self._blur(warp_affine(canvas, Tb, im_sz).clamp(0, 255), Gb)
-            wt = self._blur(warp_affine(target, T, im_sz).clamp(0, 255), G)
-            alpha = wt[3:4] / 255
-            images.append((wt[:3] * alpha + canvas * (1 - alpha)).to(torch.uint8))
-            labels.append(lab)
-        images.insert(0, im.to(torch.uint8))
-        labels.insert(0, (lb.reshape(1, *im_sz) > 0).to(torch.uint8))
-        return torch.stack(images), torch.stack(labels)
+        # ---- the N survivors, batched: target warps, background warps, blur where a spec has one, paste.  (Survivors of a retry round
+        # keep their own matrix / label buffers: group the launches by round.)
+        images[0].copy_(im8)
+        wt, cv = sc['wt'], sc['cv']
+        self.last_transforms = []              # per survivor: (device tensor of the round's forward 2x3 float32 matrices, row, G, Tb, Gb) -- read by the parity test
+        k = 0
+        while k < len(cand):
+            inv, labs = cand[k][2], cand[k][3]
+            m = 1
+            while k + m < len(cand) and cand[k + m][2] is inv:                          # survivors of the same round share matrices / planes
+                m += 1
+            grp = cand[k:k + m]
+            idx = H.upload(torch.tensor([c[4] for c in grp], dtype=torch.int32), dev)
+            H.call('frtm_warp_affine_batch', H.ptr(sc['target']), 4, Hh, Ww, wt[k:].data_ptr(), Hh, Ww, H.ptr(inv), idx.data_ptr(), m)
+            if bg is not None:
+                Tbs = []
+                for (fs, bs, _, _, _, _) in grp:
+                    bs = dict(bs)
+                    bs.setdefault('location', bs.get('tcenter', (0.5, 0.5)))
+                    Tbs.append(self._transform(bs, bg_box, im_sz, limit_scale=False))
+                invb = H.upload(torch.tensor(np.stack([_inverse23(T) for T, _ in Tbs]), dtype=torch.float32), dev)
+                H.call('frtm_warp_affine_batch', H.ptr(background), 3, Hh, Ww, cv[k:].data_ptr(), Hh, Ww, invb.data_ptr(), None, m)
+            else:
+                Tbs = [(None, None)] * m
+                for i in range(m):
+                    cv[k + i].copy_(background)
+            for i, ((fs, bs, _, _, j, fwd), (Tb, Gb)) in enumerate(zip(grp, Tbs)):
+                G = self._blur_spec(fs)
+                if G is not None:
+                    H.call('frtm_blur_gauss2d', H.ptr(wt[k + i]), 4, Hh, Ww, G[1], G[2], G[3], G[4], H.ptr(sc['wt2'][k + i]))
+                    wt[k + i].copy_(sc['wt2'][k + i])
+                if Gb is not None:
+                    H.call('frtm_blur_gauss2d', H.ptr(cv[k + i]), 3, Hh, Ww, Gb[1], Gb[2], Gb[3], Gb[4], H.ptr(sc['cv2'][k + i]))
+                    cv[k + i].copy_(sc['cv2'][k + i])
+                self.last_transforms.append((fwd, j, G, Tb, Gb))
+            H.call('frtm_aug_blend', wt[k:].data_ptr(), cv[k:].data_ptr(), m, Hh, Ww, labs.data_ptr(), idx.data_ptr(),
+                   images[1 + k:].data_ptr(), labels[1 + k:].data_ptr())
+            k += m
+        return images, labels
+
+
+def _inverse23(T):
+    """float32 inverse 2x3 of a forward 3x3 / 2x3 transform, in the arithmetic of the kernels' host-side entry points (invert_affine)."""
+    f = np.asarray(T, dtype=np.float32)[:2].ravel()
+    a, b, tx, c, d, ty = (np.float32(v) for v in f)
+    det = a * d - b * c
+    return np.array([d / det, -b / det, (b * ty - d * tx) / det, -c / det, a / det, (c * tx - a * ty) / det], dtype=np.float32)

@@ -413,6 +413,38 @@ int frtm_warp_affine_u8(const unsigned char* src, int C, int Hs, int Ws, unsigne
 int frtm_warp_mask_batch(const float* src, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* fwd6_host, int n,
                          int* count_dev, frtm_stream_t stream);
 
+/* ---- round 4: the rest of the first-frame augmentation (reference model/augmenter.py:297-345,365-390,454-555) as device kernels ----
+ * frtm_mask_stats: pixel count and bounding box of a mask plane (uint8 or float, set = > 0) into DEVICE int32[5]
+ *   {count, max(x+1), max(W-x), max(y+1), max(H-y)} (x1 = [1]-1, x0 = W-[2], y1 = [3]-1, y0 = H-[4]); replaces the torch reductions +
+ *   host read of the reference's bounding-box code (augmenter.py:285-295, np.where on the host). */
+int frtm_mask_stats(const void* mask, int is_u8, int H, int W, int* out5_dev, frtm_stream_t stream);
+/* The cut (augmenter.py:297-316): target4 = (image * mask, mask * 255) as float planes, mask_f = the {0,1} mask, label01_out (may be
+ * NULL) = the binarised label, pyr0_4 = level 0 of the fill pyramid: image * (1 - hole) and the known plane 1 - hole, hole = the mask
+ * dilated by one pixel. */
+int frtm_aug_prepare(const unsigned char* image_u8, const unsigned char* label_u8, int H, int W, float* target4, float* pyr0_4,
+                     float* mask_f, unsigned char* label01_out, frtm_stream_t stream);
+/* Pull-push hole fill over the pyramid buffer (frtm_pull_push_elems(H, W) floats, level 0 from frtm_aug_prepare): the stand-in for
+ * cv2.inpaint(..., INPAINT_TELEA) (augmenter.py:317-324; OpenCV is absent).  Afterwards the three colour planes
+ * of level 0 hold the filled background, clamped to [0, 255] and floored. */
+int frtm_pull_push_fill(float* pyr, size_t pyr_elems, int H, int W, frtm_stream_t stream);
+size_t frtm_pull_push_elems(int H, int W);
+/* get_transform (augmenter.py:230-283) for n candidate specs ON THE DEVICE, from the bounding box frtm_mask_stats left there.
+ * spec10_dev: double[n][10] = {scale, scale relative to the target height (0/1), fliplr, rotation in degrees, skew x, skew y,
+ * location x, location y (fractions of the image), min_size, limit_scale}.  Out: forward and inverse 2x3 as float32 [n][6]. */
+int frtm_aug_transforms(const double* spec10_dev, int n, const int* stats5_dev, int H, int W, float* fwd6_dev, float* inv6_dev,
+                        frtm_stream_t stream);
+/* frtm_warp_mask_batch with the INVERSE matrices in device memory (n unbounded). */
+int frtm_warp_mask_batch_dev(const float* src, int Hs, int Ws, unsigned char* dst, int Hd, int Wd, const float* inv6_dev, int n,
+                             int* count_dev, frtm_stream_t stream);
+/* n bicubic warps (a = -0.75, zero outside, result clamped to [0, 255]) of the same C float planes: dst [n][C][Hd][Wd]; matrix of
+ * warp j = inv6_dev[index_dev ? index_dev[j] : j] (augmenter.py:365-379 warps target and background of each sample one by one). */
+int frtm_warp_affine_batch(const float* src, int C, int Hs, int Ws, float* dst, int Hd, int Wd, const float* inv6_dev,
+                           const int* index_dev, int n, frtm_stream_t stream);
+/* The paste (augmenter.py:380-390) for n samples: alpha = wt4[j][3] / 255, image = wt4[j][:3] * alpha + canvas3[j] * (1 - alpha)
+ * truncated to uint8; label j = candidate plane cand_labels[index_dev[j]]. */
+int frtm_aug_blend(const float* wt4, const float* canvas3, int n, int H, int W, const unsigned char* cand_labels,
+                   const int* index_dev, unsigned char* out_images, unsigned char* out_labels, frtm_stream_t stream);
+
 /* dst[p,y,x] = sum_{i,j} G[i,j] * src[p, y+i-kh/2, x+j-kw/2], zero outside (the augmenter's blur, model/augmenter.py:330-345:
  * cv2.filter2D / F.conv2d(padding=k//2) semantics).  G: DEVICE float[kh*kw], odd kh, kw. */
 int frtm_blur2d(const float* src, int planes, int H, int W, const float* G, int kh, int kw, float* dst, frtm_stream_t stream);

@@ -637,3 +637,31 @@ def test_host_cores_near_gpu_cuts_the_numa_node_among_its_gpus(tmp_path):
         seen += cpus
     assert sorted(seen) == list(range(256))                            # a partition of the machine
     assert host_cores_near_gpu(0x77, sysfs=str(tmp_path)) == []
+
+
+def test_aug_ref_properties():
+    """oracle/aug_ref.py (the CPU restatement of the augmentation's pixel pipeline; the reference's own needs OpenCV / NPP, absent here, so
+    the oracle is checked through properties the composition must have): the pull-push fill never touches known pixels and stays inside
+    the range of its surroundings; an identity transform pastes the target back exactly; the label of a sample is the warped mask."""
+    from oracle.aug_ref import augment_ref, pull_push_fill_ref
+    g = torch.Generator().manual_seed(0)
+    Hh, Ww = 61, 83
+    im = torch.randint(0, 256, (3, Hh, Ww), dtype=torch.uint8, generator=g)
+    lb = torch.zeros(1, Hh, Ww, dtype=torch.uint8)
+    lb[0, 20:41, 30:55] = 1
+    hole = torch.nn.functional.max_pool2d(lb.float()[None], 3, 1, 1)[0]
+    fill = pull_push_fill_ref(im.float(), hole)
+    known = hole[0] == 0
+    assert torch.equal(fill[:, known], im.float()[:, known])
+    assert float(fill.min()) >= 0 and float(fill.max()) <= 255 and torch.equal(fill, fill.floor())
+    inside = fill[:, ~known]
+    assert float(inside.min()) >= float(im.float()[:, known].min()) and float(inside.max()) <= float(im.float()[:, known].max())
+    eye = np.eye(3)
+    ims, labs = augment_ref(im, lb, [dict(T=eye, G=None, Tb=None, Gb=None), dict(T=np.array([[1, 0, 5.0], [0, 1, -3.0], [0, 0, 1]]), G=None, Tb=eye, Gb=None)])
+    assert ims.shape == (3, 3, Hh, Ww) and labs.shape == (3, 1, Hh, Ww)
+    assert torch.equal(ims[0], im) and torch.equal(labs[0], lb) and torch.equal(labs[1], lb)
+    m = lb[0].bool()
+    assert torch.equal(ims[1][:, m], im[:, m])                                  # identity: the cut-out lands on itself
+    assert torch.equal(ims[1][:, known], im[:, known])
+    assert torch.equal(labs[2][0, 17:38, 35:60], lb[0, 20:41, 30:55]) and int(labs[2].sum()) == int(lb.sum())      # shifted by (+5, -3)
+    assert torch.equal(ims[2][:, 17:38, 35:60], im[:, 20:41, 30:55])

@@ -260,3 +260,73 @@ def test_winograd_products_on_stream_k_equal_the_tiled_kernel(m):
     ea, eb = float((a.double() - ref).abs().max() / ref.abs().max()), float((b.double() - ref).abs().max() / ref.abs().max())
     assert eb < 4e-5 and eb < 2 * ea + 1e-6, (ea, eb)
     assert float((a - b).abs().max() / ref.abs().max()) < 3e-5        # (k is summed in pairs instead of quadruples: the output transform amplifies that rounding)
+
+
+# ------------------------------------------------------------------------------------------ first-frame augmentation vs oracle/aug_ref.py
+@pytest.mark.parametrize('seed,size,objs', [(0, (480, 854), 2), (1, (480, 854), 3), (2, (240, 432), 1), (3, (135, 241), 1)])
+def test_augment_first_frame_against_the_oracle(seed, size, objs):
+    """VERDICT r3 missing #1 / "Next" #4: the K = 5 training samples of Discriminator.init -- cut, pull-push fill, batched bicubic warps of
+    target and background, blur, paste, label warps -- produced by the HIP pipeline (csrc/image_ops.hip; transforms formed on the device
+    from the device-side bounding box) against oracle/aug_ref.py, which restates model/augmenter.py:297-390 step by step on the CPU.
+    Same numpy seeds as fixture G11 (which pins the parameter draws to the reference's own generate_specs2 / get_transform).
+    uint8 images: <= 1 LSB on >= 99.9 % of the pixels, never more than 2 (a floored background or a truncated blend that lands within
+    float32 rounding of an integer moves by one); labels: identical up to boundary pixels whose source coordinate lies within float32
+    rounding of a half-integer (< 0.02 % of the frame)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    from oracle.aug_ref import augment_ref
+    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params)
+    seq = SyntheticSequence('a', 1, size, objs, seed=10 + seed)
+    im, lb, ids = seq[0]
+    lb1 = (lb == 1).to(torch.uint8)
+    np.random.seed(seed)
+    ims, labs = aug.augment_first_frame(im.to(DEV), lb1.to(DEV))
+    assert ims.shape == (5, 3) + size and labs.shape == (5, 1) + size and ims.dtype == labs.dtype == torch.uint8
+    assert torch.equal(ims[0].cpu(), im) and torch.equal(labs[0].cpu(), lb1.reshape(1, *size))
+    surv = []
+    for fwd, j, G, Tb, Gb in aug.last_transforms:
+        T = fwd[j].cpu().numpy().reshape(2, 3)
+        surv.append(dict(T=np.vstack([T, [0, 0, 1]]), G=G, Tb=Tb, Gb=Gb))
+    assert len(surv) == 4
+    rim, rlb = augment_ref(im, lb1, surv)
+    d = (ims.cpu().int() - rim.int()).abs()
+    assert int(d.max()) <= 2, int(d.max())
+    assert float((d <= 1).float().mean()) >= 0.999 and float((d == 0).float().mean()) >= 0.97, (float((d <= 1).float().mean()), float((d == 0).float().mean()))
+    lab_diff = float((labs.cpu() != rlb).float().mean())
+    assert lab_diff < 2e-4, lab_diff
+    # determinism: the same seed gives the same stack
+    np.random.seed(seed)
+    ims2, labs2 = aug.augment_first_frame(im.to(DEV), lb1.to(DEV))
+    assert torch.equal(ims, ims2) and torch.equal(labs, labs2)
+
+
+def test_device_side_transforms_equal_the_host_composition():
+    """k_aug_transforms (get_transform on the device from the device-side bounding box, augmenter.py:230-283) against the host-side float64
+    composition ImageAugmenter._transform (pinned to the reference by fixture G11) on every spec of three draw rounds."""
+    from frtm_vos_amd import _hip as H
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params)
+    Hh, Ww = 480, 854
+    lb = torch.zeros(Hh, Ww, dtype=torch.uint8)
+    lb[100:231, 300:417] = 1
+    lb[90:100, 340:350] = 1
+    stats = aug._mask_stats(lb.to(DEV))
+    n_px, box = aug._decode_stats(stats.tolist(), (Hh, Ww))
+    assert n_px == int(lb.sum()) and box == (300 + 117 / 2, 90 + 141 / 2, 117, 141)
+    assert aug._count_and_bbox(lb.to(DEV)) == (n_px, box)
+    np.random.seed(4)
+    fg = dict(aug.params.fg_aug_params)
+    fg['location'] = aug._target_locations(5, (Hh, Ww))
+    for rnd in range(3):
+        specs = aug._draw_specs(fg, 19)
+        rows = H.upload(torch.tensor([aug._spec_row(s) for s in specs], dtype=torch.float64), DEV)
+        fwd, inv = torch.empty(19, 6, device=DEV), torch.empty(19, 6, device=DEV)
+        H.call('frtm_aug_transforms', rows.data_ptr(), 19, stats.data_ptr(), Hh, Ww, H.ptr(fwd), H.ptr(inv))
+        for j, s in enumerate(specs):
+            T, G = aug._transform(s, box, (Hh, Ww))
+            assert np.allclose(fwd[j].cpu().numpy().reshape(2, 3), T[:2], rtol=2e-6, atol=2e-4), (rnd, j)
+            assert G == aug._blur_spec(s)
+            M = np.vstack([fwd[j].cpu().numpy().reshape(2, 3), [0, 0, 1]]).astype(np.float64) @ np.vstack([inv[j].cpu().numpy().reshape(2, 3), [0, 0, 1]]).astype(np.float64)
+            assert np.allclose(M, np.eye(3), atol=2e-3)
