@@ -45,6 +45,9 @@ SIGNATURES = {
     'frtm_joint_mid': (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P]),
     'frtm_joint_q_pq': (I, [P, I, F, P, I, I, I, F, P, P, F, P, P, P, P]),
     'frtm_cg_persistent_plan': (I, [I, I, I, I, P, P]),
+    'frtm_joint_persistent_plan': (I, [I, I, I, I, I, P]),
+    'frtm_joint_persistent_scratch': (ctypes.c_size_t, [I, I, I, I, I]),
+    'frtm_joint_run_persistent': (I, [P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, F, F, P, I, P]),
     'frtm_cg_run_persistent': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P]),
     'frtm_cg_run_persistent_guarded': (I, [P, P, P, P, I, I, I, I, P, P, P, P, P, P, I, I, I, I, I, F, F, F, F, P, I, P, I, I, P, P]),
     'frtm_guarded_copy': (I, [P, P, I, P, I, I, P, I, P]),

@@ -1,0 +1,601 @@
+// One Gauss-Newton iteration of the JOINT first-frame problem (reference discriminator.py:154-199 on optimizer.py:77-153: variables
+// project.weight (c, Cin, 1, 1) and filter.weight (1, c, 3, 3); right-hand side, `iters` conjugate-gradient steps, x += step * delta)
+// as ONE persistent launch for gfx950 -- the resident form of the "composed" operator of csrc/joint_fit.hip (round 4; VERDICT r3 "Next" #3).
+//
+// The chain form spends 74-108 us per operator application in 8 dependent launches, two of them passes over the 33 MB of raw features
+// (RN101, 480p, 5 augmented samples).  Here those features stay in VECTOR REGISTERS for the whole Gauss-Newton iteration, exactly like the
+// memory of the filter problem in cg_persistent.hip, with ONE MORE DIMENSION: the Cin raw channels are cut into GROUPS of 96, and the c
+// projected channels Z = w1 X (formed once per Gauss-Newton iteration by the GEMM kernel, before this launch) are one more group:
+//
+//   workgroup (group g, sample n, row part) = 8 waves x 12 channels, lane = x; it keeps its channels' rows [r0 - 2, r0 + R + 2) in registers.
+//   One operator application  q = J^T J p + lam^2 p  with the direction p = (p1 (Cin x c, stored transposed), p2 (c x 9)):
+//     every group holds its 3x3 "direction filter" F_g (96 x 9): raw groups the COMPOSED kernel F = p1 . w2 (the score has one channel, so
+//     project-then-filter is one 3x3 filter over the raw features), the Z group F = p2;
+//     1. partial scores of the own channels under F_g for the rows [r0 - 1, r0 + R]          -> global, write-through      | barrier A
+//     2. every workgroup of (n, part) sums the NG partial maps itself (fixed order), applies the stencil t = sw (B s [- c])
+//     3. weight gradient of the own channels against t from the SAME registers -> one 96 x 9 slab per workgroup            | barrier B
+//     4. the KK = N x parts workgroups of a group each OWN a few of its channels: owner sums the KK slabs of its channels (fixed order) and
+//        expands through w2:  q1[ch][c] = sum_tap G[ch][tap] w2[c][tap] + lam1 p1[ch][c]   (Z group: q2 = G + lam2 p2)
+//   and the conjugate-gradient vectors (b, r, r_prev, p, q, x: 6 x 99 168 floats) are DISTRIBUTED the same way: each workgroup holds the
+//   rows of its owned channels in LDS and performs the literal recurrences (optimizer.py:107-151, quirks of SURVEY App. B.8-10 included) on
+//   them; the two dot products of an iteration are reduced through global memory (partials per workgroup, every workgroup sums all of
+//   them in the same fixed order: identical scalars everywhere)                                                   | barriers C and D
+//   The new direction p' = z + beta p is linear, so the owners publish the composed rows of z BEFORE barrier D, together with the partial
+//   dots, and every workgroup forms F' = F_z + beta F locally afterwards: no fifth barrier.
+// 4 grid barriers (3 on the last iteration) per operator application, XCD-hierarchical as in cg_persistent.hip; same exchange protocol
+// (sc1 payloads, every storing wave drains, sc1 reads; polled words zeroed by memset nodes per launch; bounded spins).  A launch that
+// times out writes NOTHING back (every workgroup checks the launch's abort word behind a final barrier) and bumps the sticky abort
+// counter; the host then falls back to the chain form (model/optimizer.py).
+// Results: the same algorithm as the chain form; dot products and slab sums have another (fixed) summation order and the new direction's
+// composed kernel is formed as F_z + beta F instead of from p' itself: rounding-level differences, gated like the filter problem's
+// persistent form (tests/test_round4_gpu.py).
+#include "frtm_common.h"
+#include "../../include/frtm_hip.h"
+
+namespace {
+
+constexpr int NT = 512;            // threads per workgroup (8 waves: one workgroup per CU)
+constexpr int NWAVE = 8;
+constexpr int CPW = 12;            // channels per wave
+constexpr int GCH = CPW * NWAVE;   // 96 channels per group
+constexpr int RMAX = 8;            // output rows per workgroup (8 + 4 halo rows x 12 channels = 144 feature registers per lane)
+constexpr int XR = RMAX + 4;       // feature rows held per lane
+constexpr int SR = RMAX + 2;       // score rows (stencil halo)
+constexpr int PW = 66;             // LDS row pitch of s / t (x = -1 .. 64)
+constexpr int FN = GCH * 9;        // 864: a group's direction filter / slab
+
+struct JParams {
+  const float* X; const float* Z; const float* Bm; const float* cm; const float* sw;
+  const float* w1T;                // (Cin, c): the projection, transposed (this launch's linearisation point)
+  float* w1;                       // (c, Cin): updated in place at the end
+  float* w2;                       // (c, 9): updated in place at the end
+  float* vec; float* state;
+  float* spart; float* slabs; float* Fbuf; float* dots;
+  unsigned* bar; unsigned* hbar; unsigned* stats;
+  int N, Cin, c, h, w, R, parts, NGr, cpo, own_stride, iters, has_p, apply_dff, fr, std_alpha;
+  float dff, lam1, lam2, invM1, invM2, step;
+  long long spin_limit;
+};
+
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_flag, unsigned* stats, unsigned target, long long limit, int* sh_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY wave drains its write-through stores before the workgroup is counted
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > limit) {
+        if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
+          __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *sh_flag = ok;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+// XCD-hierarchical barrier, layout and protocol of cg_persistent.hip (guide: "barrier-xcd")
+constexpr int HB_ARR = 0, HB_GEN = 128, HB_TOP = 256, HB_POP = 272, HB_WORDS = 288;
+__device__ __forceinline__ bool hier_sync(unsigned* hbar, unsigned* abort_flag, unsigned* stats, int xcc, unsigned n_x, unsigned n_active,
+                                          unsigned epoch, long long limit, int* sh_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    auto give_up = [&]() {
+      if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
+        __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const unsigned old = __hip_atomic_fetch_add(hbar + HB_ARR + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == epoch * n_x) {
+      __hip_atomic_fetch_add(hbar + HB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(hbar + HB_TOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * n_active) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
+      }
+      if (ok) __hip_atomic_store(hbar + HB_GEN + 16 * xcc, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(hbar + HB_GEN + 16 * xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
+      }
+    }
+    *sh_flag = ok;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to63(float v) {
+  v = dpp_add<0x111, 0xf>(v);
+  v = dpp_add<0x112, 0xf>(v);
+  v = dpp_add<0x114, 0xf>(v);
+  v = dpp_add<0x118, 0xf>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return v;
+}
+// deterministic block sums of two values over NT threads (fixed butterfly + fixed wave order); all threads receive the totals
+__device__ __forceinline__ void bsum2(float& a, float& b, float* red) {
+  a = wave_sum_to63(a);
+  b = wave_sum_to63(b);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 63) { red[wid] = a; red[16 + wid] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWAVE; ++i) { ta += red[i]; tb += red[16 + i]; }
+  a = ta; b = tb;
+}
+
+// LDS carve-up (floats) behind the six owned vector slices (6 * own_stride floats, own_stride from the host)
+constexpr int L_W2 = 0;                               // [96][9] filter.weight of this launch's linearisation point
+constexpr int L_F = L_W2 + FN;                        // my group's direction filter
+constexpr int L_FZ = L_F + FN;                        // scratch: composed z of my group / F of the carried direction
+constexpr int L_GL = L_FZ + FN;                       // slab staging
+constexpr int L_GX = L_GL + FN;                       // summed weight gradient of the owned channels [cpo][9] (<= 96 * 9)
+constexpr int L_B = L_GX + FN;                        // [9][RMAX][64]
+constexpr int L_C = L_B + 9 * RMAX * 64;              // [RMAX][64]
+constexpr int L_S = L_C + RMAX * 64;                  // [SR][PW]
+constexpr int L_T = L_S + SR * PW;                    // [RMAX][PW]
+constexpr int L_RED = L_T + RMAX * PW;                // [NWAVE][SR][64]
+constexpr int L_SRED = L_RED + NWAVE * SR * 64;       // 32
+constexpr int L_FLAG = L_SRED + 32;                   // 4 ints
+constexpr int L_FIXED = L_FLAG + 4;
+
+__global__ __launch_bounds__(NT) void k_joint_run_persistent(const JParams P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w2l = lds + L_W2; float* vF = lds + L_F; float* vFz = lds + L_FZ; float* gl = lds + L_GL; float* gx = lds + L_GX;
+  float (*Bl)[RMAX][64] = (float (*)[RMAX][64])(lds + L_B);
+  float (*cl)[64] = (float (*)[64])(lds + L_C);
+  float (*sl)[PW] = (float (*)[PW])(lds + L_S);
+  float (*tl)[PW] = (float (*)[PW])(lds + L_T);
+  float (*red)[SR][64] = (float (*)[SR][64])(lds + L_RED);
+  float* sred = lds + L_SRED;
+  int* sh_flag_p = (int*)(lds + L_FLAG);
+  const int OS = P.own_stride;
+  float* vb = lds + L_FIXED; float* vr = vb + OS; float* vrp = vr + OS; float* vp = vrp + OS; float* vq = vp + OS; float* vx = vq + OS;
+  float* vw = vx + OS;             // the owned slice of the variables (7th slice)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int KK = P.N * P.parts, NG = P.NGr + 1;
+  const int g = bid / KK, k = bid - g * KK;
+  const int n_s = k / P.parts, part = k - n_s * P.parts;
+  const int r0 = part * P.R;
+  const int R = min(P.R, P.h - r0);
+  const int c = P.c, h = P.h, w = P.w, hw = h * w, Cin = P.Cin;
+  const bool zgrp = g == P.NGr;                       // the projected-feature group
+  const int gbase = zgrp ? 0 : g * GCH;               // first channel of my group (in X or in Z)
+  const int gcnt = zgrp ? c : min(GCH, Cin - gbase);  // channels of my group
+  const int n1 = Cin * c;
+  // owned channels (local to the group) and the owned slice of the vectors
+  const int o0 = min(k * P.cpo, gcnt), o1 = min((k + 1) * P.cpo, gcnt), ocnt = o1 - o0;
+  const int per = zgrp ? 9 : c;                       // vector elements per owned channel
+  const int own = ocnt * per;
+  const int vbase = zgrp ? n1 + o0 * 9 : (gbase + o0) * c;       // first global vector index of the owned slice (contiguous)
+  const float lam = zgrp ? P.lam2 : P.lam1, invM = zgrp ? P.invM2 : P.invM1;
+  unsigned* counter = P.bar;
+  unsigned* abort_flag = P.bar + 2;
+  unsigned epoch = 0;
+
+  // ---- resident data ----
+  float xr[CPW][XR];
+  {
+    const float* src = zgrp ? P.Z + (size_t)n_s * c * hw : P.X + ((size_t)n_s * Cin + gbase) * hw;
+#pragma unroll
+    for (int kk = 0; kk < CPW; ++kk) {
+      const int ch = wid * CPW + kk;
+      const float* Xc = src + (size_t)min(ch, gcnt - 1) * hw;
+#pragma unroll
+      for (int i = 0; i < XR; ++i) {
+        const int yy = r0 - 2 + i;
+        const bool ok = ch < gcnt && lane < w && (unsigned)yy < (unsigned)h && i < P.R + 4;
+        xr[kk][i] = ok ? Xc[yy * w + lane] : 0.f;
+      }
+    }
+  }
+  for (int i = tid; i < 9 * RMAX * 64; i += NT) {
+    const int d = i / (RMAX * 64), rr = (i / 64) % RMAX, x = i & 63;
+    (&Bl[0][0][0])[i] = (rr < R && x < w) ? P.Bm[((size_t)n_s * 9 + d) * hw + (r0 + rr) * w + x] : 0.f;
+  }
+  for (int i = tid; i < RMAX * 64; i += NT) {
+    const int rr = i / 64, x = i & 63;
+    (&cl[0][0])[i] = (rr < R && x < w) ? P.cm[(size_t)n_s * hw + (r0 + rr) * w + x] : 0.f;
+  }
+  for (int i = tid; i < SR * PW; i += NT) (&sl[0][0])[i] = 0.f;
+  for (int i = tid; i < RMAX * PW; i += NT) (&tl[0][0])[i] = 0.f;
+  for (int i = tid; i < FN; i += NT) { w2l[i] = i < c * 9 ? P.w2[i] : 0.f; vF[i] = 0.f; vFz[i] = 0.f; gx[i] = 0.f; }
+  if (tid == 0) sh_flag_p[0] = 1;
+  for (int i = tid; i < OS; i += NT) {
+    const bool on = i < own;
+    // variables of the owned slice: raw groups rows of w1T (Cin x c), the Z group rows of w2 (c x 9)
+    vw[i] = on ? (zgrp ? P.w2[o0 * 9 + i] : P.w1T[(size_t)(gbase + o0) * c + i]) : 0.f;
+    vp[i] = (on && P.has_p) ? P.vec[(size_t)3 * (n1 + c * 9) + vbase + i] : 0.f;
+    vrp[i] = (on && P.has_p) ? P.vec[(size_t)2 * (n1 + c * 9) + vbase + i] : 0.f;
+    vb[i] = vr[i] = vq[i] = vx[i] = 0.f;
+  }
+  const float swn = P.sw[n_s];
+  // ---- XCD registration (as cg_persistent.hip), then ONE flat barrier ----
+  const bool hier = P.hbar != nullptr;
+  int xcc = 0; unsigned n_x = 1, n_active = 1, hepoch = 0;
+  if (hier) {
+    if (tid == 0) {
+      const int xx = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);          // HW_REG_XCC_ID
+      sh_flag_p[1] = xx;
+      __hip_atomic_fetch_add(P.hbar + HB_POP + xx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p)) return;
+    if (tid == 0) {
+      unsigned act = 0, mine = 0;
+      for (int xx = 0; xx < 8; ++xx) {
+        const unsigned c_ = __hip_atomic_load(P.hbar + HB_POP + xx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        act += c_ > 0u ? 1u : 0u;
+        if (xx == sh_flag_p[1]) mine = c_;
+      }
+      sh_flag_p[2] = (int)mine; sh_flag_p[3] = (int)act;
+    }
+    __syncthreads();
+    xcc = sh_flag_p[1]; n_x = (unsigned)sh_flag_p[2]; n_active = (unsigned)sh_flag_p[3];
+  }
+  auto gsync = [&]() -> bool {
+    if (hier) return hier_sync(P.hbar, abort_flag, P.stats, xcc, n_x, n_active, ++hepoch, P.spin_limit, sh_flag_p);
+    return grid_sync(counter, abort_flag, P.stats, (++epoch) * (unsigned)G, P.spin_limit, sh_flag_p);
+  };
+  __syncthreads();
+
+  // ---- composed rows of an owned vector slice -> Fbuf[slot][g][(o0 + chl) * 9 + tap]  (raw groups: v . w2; Z group: v itself) ----
+  auto publish_compose = [&](const float* v, int slot) {
+    float* dst = P.Fbuf + ((size_t)slot * NG + g) * FN + o0 * 9;
+    for (int e = tid; e < ocnt * 9; e += NT) {
+      float s = 0.f;
+      if (zgrp) s = v[e];
+      else {
+        const int chl = e / 9, tap = e - chl * 9;
+        const float* vrow = v + chl * c;
+        for (int cc = 0; cc < c; ++cc) s += vrow[cc] * w2l[cc * 9 + tap];           // fixed order
+      }
+      st_wt(dst + e, s);
+    }
+  };
+  auto read_F = [&](float* dstl, int slot) {           // my group's published filter -> LDS (zeros beyond the group's channels)
+    const float* src = P.Fbuf + ((size_t)slot * NG + g) * FN;
+    for (int i = tid; i < FN; i += NT) dstl[i] = i < gcnt * 9 ? ld_l2(src + i) : 0.f;
+  };
+  // ---- global sums of two per-workgroup partials (every workgroup sums all of them in the same order) ----
+  auto publish_dots = [&](float a, float b, int slot) {
+    if (tid == 0) { st_wt(P.dots + ((size_t)slot * G + bid) * 2, a); st_wt(P.dots + ((size_t)slot * G + bid) * 2 + 1, b); }
+  };
+  auto sum_dots = [&](float& a, float& b, int slot) {
+    float sa = 0.f, sb = 0.f;
+    if (wid == 0) {
+      for (int q = lane; q < G; q += 64) { sa += ld_l2(P.dots + ((size_t)slot * G + q) * 2); sb += ld_l2(P.dots + ((size_t)slot * G + q) * 2 + 1); }
+      sa = wave_sum_to63(sa); sb = wave_sum_to63(sb);
+      if (lane == 63) { sred[0] = sa; sred[1] = sb; }
+    }
+    __syncthreads();
+    a = sred[0]; b = sred[1];
+    __syncthreads();
+  };
+
+  // ---- one operator application with the group filters in vF: vq (owned slice) <- (J^T (sw (B s - c?)))_owned + lam v_owned ----
+  auto apply = [&](const float* v_own, bool with_c, bool scores_on) -> bool {
+    // 1. partial scores of the own channels: three column partials per score row
+    float* sp = P.spart + ((size_t)k * NG + g) * (SR * 64);
+    if (scores_on) {
+      float S0[SR], S1[SR], S2[SR];
+#pragma unroll
+      for (int jj = 0; jj < SR; ++jj) { S0[jj] = 0.f; S1[jj] = 0.f; S2[jj] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < CPW; ++kk) {
+        const float* f = vF + (wid * CPW + kk) * 9;          // LDS broadcast reads (zero beyond the group's channels)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float f0 = f[dy * 3 + 0], f1 = f[dy * 3 + 1], f2_ = f[dy * 3 + 2];
+#pragma unroll
+          for (int jj = 0; jj < SR; ++jj) {
+            const float xv = xr[kk][jj + dy];
+            S0[jj] += f0 * xv; S1[jj] += f1 * xv; S2[jj] += f2_ * xv;
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < SR; ++jj) {
+        const float l = __shfl_up(S0[jj], 1, 64), r = __shfl_down(S2[jj], 1, 64);
+        red[wid][jj][lane] = (lane > 0 ? l : 0.f) + S1[jj] + (lane < 63 ? r : 0.f);
+      }
+      __syncthreads();
+      for (int i = tid; i < SR * 64; i += NT) {
+        const int jj = i >> 6, x = i & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NWAVE; q += 4) s += (red[q][jj][x] + red[q + 1][jj][x]) + (red[q + 2][jj][x] + red[q + 3][jj][x]);
+        st_wt(sp + i, s);
+      }
+    } else {
+      for (int i = tid; i < SR * 64; i += NT) st_wt(sp + i, 0.f);
+    }
+    if (!gsync()) return false;                                                       // ---- barrier A
+    // 2. the full score rows of (n, part): sum of the NG partial maps, fixed order; then the stencil
+    for (int i = tid; i < SR * 64; i += NT) {
+      const int jj = i >> 6, x = i & 63;
+      const int yy = r0 - 1 + jj;
+      float s = 0.f;
+      const float* base = P.spart + (size_t)k * NG * (SR * 64) + i;
+      for (int q = 0; q < NG; ++q) s += ld_l2(base + (size_t)q * (SR * 64));
+      sl[jj][x + 1] = (x < w && (unsigned)yy < (unsigned)h && jj < R + 2) ? s : 0.f;
+    }
+    __syncthreads();
+    for (int rr = wid; rr < RMAX; rr += NWAVE) {
+      float acc = 0.f;
+      if (rr < R && lane < w) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) acc += Bl[dy * 3 + dx][rr][lane] * sl[rr + dy][lane + dx];
+        if (with_c) acc -= cl[rr][lane];
+        acc *= swn;
+      }
+      tl[rr][lane + 1] = acc;
+    }
+    __syncthreads();
+    // 3. weight gradient of the own channels from the resident rows
+    float tv[RMAX][3];
+#pragma unroll
+    for (int rr = 0; rr < RMAX; ++rr)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) tv[rr][dx] = tl[rr][lane + 2 - dx];
+#pragma unroll
+    for (int kk = 0; kk < CPW; ++kk) {
+      float a[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) a[e] = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RMAX; ++rr)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const float xv = xr[kk][rr + dy + 1];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) a[dy * 3 + dx] += tv[rr][dx] * xv;
+        }
+      float* dst = gl + (wid * CPW + kk) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const float tot = wave_sum_to63(a[e]);
+        if (lane == 63) dst[e] = tot;
+      }
+    }
+    __syncthreads();
+    float* slab = P.slabs + ((size_t)g * KK + k) * FN;
+    for (int i = tid; i < FN; i += NT) st_wt(slab + i, gl[i]);
+    if (!gsync()) return false;                                                       // ---- barrier B
+    // 4. owners: sum of the KK slabs of the owned channels (one wave per element, fixed order), then the expansion through w2
+    for (int e0 = wid; e0 < ocnt * 9; e0 += NWAVE) {
+      const int e = o0 * 9 + e0;
+      float s = 0.f;
+      for (int q = lane; q < KK; q += 64) s += ld_l2(P.slabs + ((size_t)g * KK + q) * FN + e);
+      s = wave_sum_to63(s);
+      if (lane == 63) gx[e0] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < OS; i += NT) {
+      float qv = 0.f;
+      if (i < own) {
+        if (zgrp) qv = gx[i];
+        else {
+          const int chl = i / c, cc = i - chl * c;
+          const float* gr = gx + chl * 9;
+          const float* wr = w2l + cc * 9;
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) qv += gr[tap] * wr[tap];
+        }
+        qv += lam * v_own[i];
+      }
+      vq[i] = qv;
+    }
+    __syncthreads();
+    return true;
+  };
+
+  // ---- right-hand side b = -(J^T f(w) + lam^2 w): the scores are Z * w2 (the Z group alone contributes, with F = w2) ----
+  if (zgrp) { for (int i = tid; i < FN; i += NT) vF[i] = w2l[i]; }
+  if (P.has_p) publish_compose(vp, 1);                 // composed kernel of the carried direction (slot 1), read behind the barrier below
+  __syncthreads();
+  if (!apply(vw, true, zgrp)) return;
+  // r = b; z = M^-1 r; rho' = <r,z>; rho2 = <r_prev,z>   (optimizer.py:107-130)
+  float rho_cur;
+  {
+    float d0 = 0.f, d1 = 0.f;
+    for (int i = tid; i < OS; i += NT) {
+      const float bv = -vq[i];
+      vb[i] = bv; vr[i] = bv;
+      const float z = bv * invM;
+      d0 += bv * z;
+      if (P.has_p && !P.fr) d1 += vrp[i] * z;
+      vx[i] = z;                                       // (vx is free until the first step: staging of z for the compose below)
+    }
+    bsum2(d0, d1, sred);
+    publish_dots(d0, d1, 0);
+    publish_compose(vx, 0);                            // composed rows of z (slot 0)
+    if (!gsync()) return;                                                              // ---- barrier C'
+    sum_dots(d0, d1, 0);
+    float beta = 0.f;
+    if (P.has_p) {
+      float rho1 = P.state[0];
+      if (P.apply_dff) rho1 = rho1 / P.dff;
+      const float vv = P.fr ? d0 / rho1 : (d0 - d1) / rho1;
+      beta = (vv < 0.f) ? 0.f : vv;
+    }
+    read_F(vFz, 0);
+    if (P.has_p) read_F(vF, 1);
+    __syncthreads();
+    for (int i = tid; i < FN; i += NT) vF[i] = P.has_p ? vFz[i] + vF[i] * beta : vFz[i];
+    for (int i = tid; i < OS; i += NT) {
+      const float z = vr[i] * invM;
+      vp[i] = P.has_p ? (z + vp[i] * beta) : z;
+      vx[i] = 0.f;
+    }
+    rho_cur = d0;
+    __syncthreads();
+  }
+  float alpha = 0.f, beta_last = 0.f, rho_prev = P.state[0];
+  for (int it = 0; it < P.iters; ++it) {
+    if (!apply(vp, false, true)) return;
+    const bool first = it == 0, last = it == P.iters - 1;
+    float pq = 0.f, pr = 0.f;
+    for (int i = tid; i < OS; i += NT) { pq += vp[i] * vq[i]; pr += vp[i] * vr[i]; }
+    bsum2(pq, pr, sred);
+    publish_dots(pq, pr, 1);
+    if (!gsync()) return;                                                              // ---- barrier C
+    sum_dots(pq, pr, 1);
+    alpha = P.std_alpha ? rho_cur / pq : pr / pq;
+    float rn_ = 0.f, r2_ = 0.f;
+    for (int i = tid; i < OS; i += NT) {
+      const float rv = vr[i], pv = vp[i];
+      vrp[i] = rv;
+      vx[i] = first ? pv * alpha : vx[i] + pv * alpha;
+      float rn = rv;
+      if (!last) { rn = rv - vq[i] * alpha; vr[i] = rn; }
+      const float z = rn * invM;
+      rn_ += rn * z;
+      r2_ += rv * z;
+    }
+    rho_prev = rho_cur;
+    if (!last) {
+      // z of the owned slice, staged in vq (its content is consumed): composed rows published together with the partial dots
+      for (int i = tid; i < OS; i += NT) vq[i] = vr[i] * invM;
+      bsum2(rn_, r2_, sred);
+      publish_dots(rn_, r2_, 0);
+      publish_compose(vq, 0);
+      if (!gsync()) return;                                                            // ---- barrier D
+      sum_dots(rn_, r2_, 0);
+      const float vv = P.fr ? rn_ / rho_cur : (rn_ - r2_) / rho_cur;
+      beta_last = (vv < 0.f) ? 0.f : vv;
+      read_F(vFz, 0);
+      __syncthreads();
+      for (int i = tid; i < FN; i += NT) vF[i] = vFz[i] + vF[i] * beta_last;
+      for (int i = tid; i < OS; i += NT) vp[i] = vq[i] + vp[i] * beta_last;
+      rho_cur = rn_;
+    }
+    __syncthreads();
+  }
+  // ---- write back: every workgroup its owned slices, behind a final barrier, and only if the launch has not been aborted ----
+  if (!gsync()) return;
+  if (tid == 0) sh_flag_p[0] = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1 : 0;
+  __syncthreads();
+  if (!sh_flag_p[0]) return;
+  const size_t n = (size_t)n1 + c * 9;
+  for (int i = tid; i < own; i += NT) {
+    P.vec[0 * n + vbase + i] = vb[i];
+    P.vec[1 * n + vbase + i] = vr[i];
+    P.vec[2 * n + vbase + i] = vrp[i];
+    P.vec[3 * n + vbase + i] = vp[i];
+    P.vec[4 * n + vbase + i] = vq[i];
+    P.vec[5 * n + vbase + i] = vx[i];
+    const float nv = vw[i] + P.step * vx[i];
+    if (zgrp) P.w2[o0 * 9 + i] = nv;
+    else { const int chl = i / c, cc = i - chl * c; P.w1[(size_t)cc * Cin + gbase + o0 + chl] = nv; }      // un-transposed: project.weight is (c, Cin)
+  }
+  if (bid == 0 && tid == 0) {
+    P.state[0] = P.iters > 0 ? rho_prev : P.state[0];
+    P.state[4] = rho_cur;
+    P.state[1] = alpha;
+    P.state[2] = beta_last;
+    if (P.stats) __hip_atomic_fetch_add(P.stats + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int joint_budget() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 240; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+  return cus - cus / 16;
+}
+
+// Workgroups of the resident form of the joint problem (0: the problem does not fit).  out4 = {parts, rows per part, owned channels per
+// workgroup, floats of one owned vector slice in LDS}.
+int frtm_joint_persistent_plan(int N, int Cin, int c, int h, int w, int* out4) {
+  if (N < 1 || Cin < 1 || c < 1 || c > GCH || w < 1 || w > 64 || h < 1) return 0;
+  const int budget = joint_budget();
+  const int NG = ceil_div(Cin, GCH) + 1;
+  const int min_parts = ceil_div(h, RMAX);
+  if ((long)NG * N * min_parts > budget) return 0;
+  int parts = budget / (NG * N);
+  if (parts > h) parts = h;
+  if (parts < min_parts) parts = min_parts;
+  int R = ceil_div(h, parts);
+  parts = ceil_div(h, R);
+  const int KK = N * parts;
+  const int cpo = ceil_div(GCH, KK);
+  const int own_stride = cpo * (c > 9 ? c : 9);
+  if ((size_t)(L_FIXED + 7 * own_stride) * 4 > 160 * 1024) return 0;
+  if (out4) { out4[0] = parts; out4[1] = R; out4[2] = cpo; out4[3] = own_stride; }
+  return NG * N * parts;
+}
+
+// Scratch (floats) of a launch: partial score rows, slabs, two filter slots, two dot slots.
+size_t frtm_joint_persistent_scratch(int N, int Cin, int c, int h, int w) {
+  int o[4];
+  const int G = frtm_joint_persistent_plan(N, Cin, c, h, w, o);
+  if (G <= 0) return 0;
+  const int NG = ceil_div(Cin, GCH) + 1, KK = N * o[0];
+  return (size_t)KK * NG * SR * 64 + (size_t)NG * KK * FN + (size_t)2 * NG * FN + (size_t)2 * G * 2 + 64;
+}
+
+int frtm_joint_run_persistent(const float* X, const float* Z, const float* Bm, const float* cm, const float* sw, int N, int Cin, int c, int h, int w,
+                              const float* w1T, float* w1, float* w2, float* vec, float* state, float* scratch, unsigned* bar, unsigned* hbar,
+                              int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff, float lam1, float lam2,
+                              float invM1, float invM2, float step, unsigned* stats, int debug_abort, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(X && Z && Bm && cm && sw && w1T && w1 && w2 && vec && state && scratch && bar && iters >= 0, "frtm_joint_run_persistent: bad argument");
+  int o[4];
+  const int G = frtm_joint_persistent_plan(N, Cin, c, h, w, o);
+  FRTM_CHECK_ARG(G > 0, "frtm_joint_run_persistent: problem (N=%d, Cin=%d, c=%d, %dx%d) does not fit the resident form", N, Cin, c, h, w);
+  JParams P;
+  P.X = X; P.Z = Z; P.Bm = Bm; P.cm = cm; P.sw = sw; P.w1T = w1T; P.w1 = w1; P.w2 = w2; P.vec = vec; P.state = state;
+  const int NG = ceil_div(Cin, GCH) + 1, KK = N * o[0];
+  P.spart = scratch;
+  P.slabs = P.spart + (size_t)KK * NG * SR * 64;
+  P.Fbuf = P.slabs + (size_t)NG * KK * FN;
+  P.dots = P.Fbuf + (size_t)2 * NG * FN;
+  P.bar = bar; P.hbar = hbar; P.stats = stats;
+  P.N = N; P.Cin = Cin; P.c = c; P.h = h; P.w = w; P.R = o[1]; P.parts = o[0]; P.NGr = NG - 1; P.cpo = o[2]; P.own_stride = o[3];
+  P.iters = iters; P.has_p = has_p; P.apply_dff = apply_dff; P.fr = fletcher_reeves; P.std_alpha = standard_alpha;
+  P.dff = dff; P.lam1 = lam1; P.lam2 = lam2; P.invM1 = invM1; P.invM2 = invM2; P.step = step;
+  P.spin_limit = debug_abort ? 0LL : 400000LL;
+  const size_t lds = (size_t)(L_FIXED + 7 * o[3]) * 4;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    FRTM_HIP(hipFuncSetAttribute((const void*)k_joint_run_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  FRTM_HIP(hipMemsetAsync(bar, 0, 3 * sizeof(unsigned), (hipStream_t)stream));
+  if (hbar) FRTM_HIP(hipMemsetAsync(hbar, 0, HB_WORDS * sizeof(unsigned), (hipStream_t)stream));
+  k_joint_run_persistent<<<G, NT, lds, (hipStream_t)stream>>>(P);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+}  // extern "C"

@@ -153,6 +153,26 @@ class DiscriminatorLoss(MinimizationProblem):
         H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
         return self.partial, self.N * parts, self.c * 9, self.filter_regs[0] ** 2
 
+    # joint problem: a whole Gauss-Newton iteration as ONE resident launch (csrc/joint_persistent.hip) where the shape fits
+    persistent_joint = not __import__('os').environ.get('FRTM_NO_PERSISTENT_JOINT')
+
+    def persistent_joint_args(self):
+        """Operands of the resident form of the JOINT problem, or None (filter problem, maps wider than a wavefront, memory too large)."""
+        if not self.joint or self.N < 1 or not self.persistent_joint or not self._use_composed():
+            return None
+        if H.lib().frtm_joint_persistent_plan(self.N, self.Cin, self.c, self.h, self.w, None) <= 0:
+            return None
+        m = self.mem
+        return dict(joint=True, X=m.samples, Z=self.Z, B=m.normal_B, c_map=m.normal_c, sw=m.weights, N=self.N, Cin=self.Cin, c=self.c,
+                    h=self.h, w=self.w, w1T=self.w1T, w1=self.w1.data, w2=self.w2.data, lam1=self.filter_regs[0] ** 2, lam2=self.filter_regs[1] ** 2)
+
+    def prepare_linearization(self):
+        """What every form of a Gauss-Newton iteration of the joint problem starts with: the transposed projection and the projected
+        features Z = w1 X at the current linearisation point (reference: the forward pass of the autograd graph, optimizer.py:80-84)."""
+        N, c = self.N, self.c
+        ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
+        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
+
     def persistent_args(self):
         """Operands of the one-launch form of a GN iteration (filter problem only; None for the joint problem)."""
         if self.joint or self.N < 1:
@@ -207,8 +227,7 @@ class DiscriminatorLoss(MinimizationProblem):
             self._filter_grad(self.mem.samples, self.filter_regs[0] ** 2, H.ptr(self.w2.data), -1.0, H.ptr(b))
             return
         n1 = self.Cin * c
-        ops.transpose2d(self.w1.data.view(c, self.Cin), out=self.w1T)
-        ops.conv2d(self.mem.samples, self.w1T, c, out=self.Z, shape=(N, self.Cin, self.h, self.w), w_pitch=c, ws=self.ws)
+        self.prepare_linearization()
         ops.filter_scores(self.Z, self.w2.data, out=self.s, n=N)
         if self._use_composed():
             self._stencil(True)
@@ -563,6 +582,7 @@ class Discriminator(nn.Module):
         p0, p1, o0, o1 = self._init_problems(mem0, memory)
         # joint fit of (project, filter) on the K raw samples
         o0.rewind().run(self.init_iters)
+        self._init_opt = o0
         self._invalidate()
         xp = ops.conv2d(mem0.samples[:K], self._project_T(), self.project.out_channels, w_pitch=self.project.out_channels, ws=p0.ws)   # re-project (:178)
         # memory + filter-only problem used for the rest of the sequence
@@ -624,6 +644,18 @@ class Discriminator(nn.Module):
                 self.recover_from_abort()
             opt.run(self.update_iters, guard=counts[W - 1, plane:plane + 1], guard_min=10)
             self._guarded_runs += 1
+
+    def init_aborted(self):
+        """True if a resident launch of the first-frame fit (csrc/joint_persistent.hip) timed out since the last call: that Gauss-Newton
+        iteration is MISSING from this target model.  SYNCHRONISES (4 bytes); the tracker asks after the final synchronise of a sequence and
+        then re-runs the sequence with the chain form (the resident form is switched off for the process)."""
+        o = getattr(self, '_init_opt', None)
+        if o is None:
+            return False
+        n = o.joint_aborts()
+        seen = getattr(o, '_joint_aborts_seen', 0)
+        o._joint_aborts_seen = n
+        return n > seen
 
     def recover_from_abort(self):
         """A persistent launch of the update solver timed out (its workgroups did not all become resident: the GPU is shared): it left

@@ -220,6 +220,47 @@ class GaussNewtonCG:
     hierarchical_barrier = not __import__('os').environ.get('FRTM_FLAT_BARRIER')     # persistent launches: XCD-hierarchical grid barrier (False: one flat counter)
     persistent = False      # filter problem: run a whole GN iteration as one persistent launch (csrc/cg_persistent.hip) when the shape fits
 
+    def _persistent_joint_plan(self):
+        pr = self.problem
+        if not self.persistent_joint or not hasattr(pr, 'persistent_joint_args'):
+            return None
+        return pr.persistent_joint_args()
+
+    persistent_joint = True     # joint problem: resident form (csrc/joint_persistent.hip) where the problem offers it; switched off for the
+                                # whole process once a launch has timed out (GaussNewtonCG.abort_seen_in_process)
+
+    def _run_persistent_joint(self, num_cg_iter, a):
+        """linearize + run_CG + apply_step of run_GN_iter for the JOINT problem: two small launches (transpose, Z = w1 X) + ONE resident
+        launch.  Host-side bookkeeping as in run_CG."""
+        pr = self.problem
+        pr.prepare_linearization()
+        if getattr(self, '_jbuf', None) is None or self._jbuf[0].numel() < int(H.lib().frtm_joint_persistent_scratch(a['N'], a['Cin'], a['c'], a['h'], a['w'])):
+            dev = self._buf.device
+            self._jbuf = (torch.empty(int(H.lib().frtm_joint_persistent_scratch(a['N'], a['Cin'], a['c'], a['h'], a['w'])), device=dev),
+                          torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(288, dtype=torch.int32, device=dev))
+        scratch, bar, hbar = self._jbuf
+        stats = self._stats()
+        dff = float(self.direction_forget_factor)
+        if dff == 0:
+            self.reset_state()
+        n1, n2, m1, m2 = pr.vector_layout()
+        H.call('frtm_joint_run_persistent', H.ptr(a['X']), H.ptr(a['Z']), H.ptr(a['B']), H.ptr(a['c_map']), H.ptr(a['sw']), a['N'], a['Cin'], a['c'],
+               a['h'], a['w'], H.ptr(a['w1T']), H.ptr(a['w1']), H.ptr(a['w2']), H.ptr(self._buf), H.ptr(self._state), H.ptr(scratch), H.ptr(bar),
+               H.ptr(hbar) if self.hierarchical_barrier else None, int(num_cg_iter), int(self._has_p), int(self._has_p and dff != 0),
+               int(self.fletcher_reeves), int(self.standard_alpha), dff if dff != 0 else 1.0, float(a['lam1']), float(a['lam2']), 1.0 / m1, 1.0 / m2,
+               float(self.step_alpha), H.ptr(stats), int(bool(self.debug_abort)))
+        self._has_p = True
+        self._joint_launched = True
+        if hasattr(pr, '_invalidate_views'):
+            pr._invalidate_views()
+
+    def joint_aborts(self):
+        """Aborted resident launches of the joint problem so far (stats[2]).  SYNCHRONISES; an aborted launch wrote nothing, i.e. that
+        Gauss-Newton iteration is MISSING from the fit: the caller re-runs the fit in the chain form (Discriminator.init / Tracker)."""
+        if not getattr(self, '_joint_launched', False) or self._gstats is None:
+            return 0
+        return int(self._gstats[2].item())
+
     def _persistent_plan(self):
         pr = self.problem
         args = pr.persistent_args() if hasattr(pr, 'persistent_args') else None
@@ -297,6 +338,11 @@ class GaussNewtonCG:
         return launched[len(launched) - missed:] if launched and missed else ([launched[-1]] * missed if launched else [])
 
     def run_GN_iter(self, num_cg_iter):
+        aj = self._persistent_joint_plan() if num_cg_iter > 0 else None
+        if aj is not None:
+            self._run_persistent_joint(num_cg_iter, aj)
+            self.step_alpha = min(self.step_alpha * 1.2, 1.0)
+            return
         a = self._persistent_plan() if num_cg_iter > 0 else None
         if a is not None:
             self._run_persistent(num_cg_iter, a)

@@ -336,6 +336,20 @@ class Tracker(nn.Module):
             d = t.discriminator
             if d is not None and d.recover_from_abort():     # a timed-out persistent launch: its solve is re-run now (multi-kernel form)
                 torch.cuda.synchronize()
+        if any(t.discriminator is not None and t.discriminator.init_aborted() for t in self.targets.values()) and not getattr(self, '_rerun', False):
+            # a resident launch of a first-frame fit timed out (another process holds CUs): the target model lacks a Gauss-Newton iteration.
+            # Switch the resident form of the joint problem off for the process and track the sequence again in the chain form.
+            from .discriminator import DiscriminatorLoss
+            from .optimizer import GaussNewtonCG
+            DiscriminatorLoss.persistent_joint = False
+            GaussNewtonCG.persistent_joint = False
+            self._rerun = True
+            try:
+                self.release_targets()
+                self.clear()
+                return self._run_sequence_loop(sequence, speedrun, ytvos_merge)
+            finally:
+                self._rerun = False
         T = time() - t0
         self._raw_log = None
         self._lut = None

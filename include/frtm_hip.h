@@ -212,6 +212,23 @@ int frtm_guarded_copy(float* dst, const float* src, int n, const int* guard_coun
 int frtm_cg_step_small(const float* slabs, int nslab, int stride, float lam2, float* x, float* r, float* r_prev,
                        float* p, float* q, int n, float invM, int first, int last, int standard_alpha,
                        int fletcher_reeves, float* state, frtm_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Round 4: one Gauss-Newton iteration of the JOINT first-frame problem (reference discriminator.py:154-199 on optimizer.py:77-153) as ONE
+ * resident launch (csrc/joint_persistent.hip): the raw features X (N, Cin, h, w) and the projected features Z (N, c, h, w) = w1 X stay in
+ * registers, channel group by channel group, for the right-hand side, `iters` CG steps and the step x += step * delta.
+ * plan: number of workgroups (0 = does not fit: w > 64, c > 96, too many samples); out4 = {row parts, rows per part, owned channels per
+ * workgroup, floats per owned vector slice}.  scratch: floats of exchange scratch a launch needs.
+ * w1T (Cin, c) = project.weight transposed at the linearisation point (input); w1 (c, Cin) and w2 (c, 9) are UPDATED in place; vec / state
+ * as in frtm_cg_*: vec = [b, r, r_prev, p, q, delta] x (Cin c + 9 c) with the projection part stored transposed, state[0] = rho ...
+ * bar: >= 3 zero-initialised words (zeroed again by every launch); hbar: 288 words or NULL (flat barrier); stats (may be NULL):
+ * [2] += 1 if the launch timed out (nothing is written back then), [3] += 1 if it committed.
+ * ------------------------------------------------------------------------------------------ */
+int frtm_joint_persistent_plan(int N, int Cin, int c, int h, int w, int* out4);
+size_t frtm_joint_persistent_scratch(int N, int Cin, int c, int h, int w);
+int frtm_joint_run_persistent(const float* X, const float* Z, const float* Bm, const float* cm, const float* sw, int N, int Cin, int c, int h, int w,
+                              const float* w1T, float* w1, float* w2, float* vec, float* state, float* scratch, unsigned* bar, unsigned* hbar,
+                              int iters, int has_p, int apply_dff, int fletcher_reeves, int standard_alpha, float dff, float lam1, float lam2,
+                              float invM1, float invM2, float step, unsigned* stats, int debug_abort, frtm_stream_t stream);
 /* y += a * x */
 int frtm_vec_axpy(float* y, float a, const float* x, int n, frtm_stream_t stream);
 /* out[c*rows + r] = in[r*cols + c]  (small 2-D transpose, rows x cols -> cols x rows) */

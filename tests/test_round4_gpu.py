@@ -330,3 +330,91 @@ def test_device_side_transforms_equal_the_host_composition():
             assert G == aug._blur_spec(s)
             M = np.vstack([fwd[j].cpu().numpy().reshape(2, 3), [0, 0, 1]]).astype(np.float64) @ np.vstack([inv[j].cpu().numpy().reshape(2, 3), [0, 0, 1]]).astype(np.float64)
             assert np.allclose(M, np.eye(3), atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------ resident joint fit (csrc/joint_persistent.hip)
+def _joint_case(cin, c, h, w, Hh, Ww, seed, persistent):
+    from frtm_vos_amd.lib.tensorlist import TensorList
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.memory import Memory
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    gg = torch.Generator().manual_seed(seed)
+    Y = torch.zeros(5, 1, Hh, Ww, dtype=torch.uint8)
+    for k in range(5):
+        Y[k, 0, Hh // 5 + 4 * k:Hh * 5 // 8, Ww // 4:Ww * 5 // 8 + 6 * k] = 1
+    x = torch.relu(torch.randn(5, cin, h, w, generator=gg))
+    w1_0 = (torch.rand(c, cin, 1, 1, generator=gg) * 2 - 1) / cin ** 0.5
+    w2_0 = (torch.rand(1, c, 3, 3, generator=gg) * 2 - 1) / (9 * c) ** 0.5
+    mem = Memory(5, (cin, h, w), (1, Hh, Ww), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1))
+    mem.initialize(x.to(DEV), Y.to(DEV))
+    w1 = torch.nn.Parameter(w1_0.clone().to(DEV), requires_grad=False)
+    w2 = torch.nn.Parameter(w2_0.clone().to(DEV), requires_grad=False)
+    prob = DiscriminatorLoss(mem, (1e-4, 1e-2), (1e-4, 1e-2), w2, w1)
+    prob.persistent_joint = persistent
+    opt = GaussNewtonCG(prob, TensorList([w1, w2]), fletcher_reeves=False, standard_alpha=True, direction_forget_factor=0.9 ** 750)
+    return mem, prob, opt, w1, w2
+
+
+@pytest.mark.parametrize('shape', [(1024, 96, 30, 54, 480, 854), (256, 96, 30, 54, 480, 854), (200, 40, 17, 31, 272, 496), (64, 16, 12, 64, 96, 512)])
+def test_resident_joint_fit_equals_the_chain_form(shape):
+    """k_joint_run_persistent (a whole Gauss-Newton iteration of the joint first-frame problem as one resident launch: features in
+    registers, channel groups, distributed CG vectors) against the composed chain form of csrc/joint_fit.hip on the same problem:
+      * one GN iteration with ONE CG step: b, q, the step and both weight tensors agree to summation order (2e-5);
+      * two GN iterations (3, 3) with the CG state carried from the first into the second (has_p, Polak-Ribiere beta, rho / dff);
+      * the whole (5, 10, 10, 10, 10) schedule: within the chain form's own sensitivity to a one-ulp perturbation of the features (the
+        truncated fits amplify rounding, DESIGN.md section 2), measured in this test;
+      * bit-identical results when repeated (fixed summation orders)."""
+    cin, c, h, w, Hh, Ww = shape
+
+    def run(persistent, schedule, scale=1.0):
+        mem, prob, opt, w1, w2 = _joint_case(cin, c, h, w, Hh, Ww, 3, persistent)
+        if scale != 1.0:
+            mem.samples.mul_(scale)
+        prob.initialize()
+        assert (opt._persistent_joint_plan() is not None) == persistent
+        opt.run(schedule)
+        torch.cuda.synchronize()
+        assert opt.joint_aborts() == 0
+        return w1.detach().clone(), w2.detach().clone(), opt._buf.clone(), opt._state.clone()
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+    # (a) one step
+    A, B = run(True, (1,)), run(False, (1,))
+    assert rel(A[0], B[0]) < 2e-5 and rel(A[1], B[1]) < 2e-5, (rel(A[0], B[0]), rel(A[1], B[1]))
+    for k, name in enumerate(('b', 'r', 'r_prev', 'p', 'q', 'delta')):
+        assert rel(A[2][k], B[2][k]) < 5e-5, (name, rel(A[2][k], B[2][k]))
+    assert rel(A[3][:5], B[3][:5]) < 5e-5
+    # (b) carried CG state
+    A, B = run(True, (3, 3)), run(False, (3, 3))
+    assert rel(A[0], B[0]) < 2e-4 and rel(A[1], B[1]) < 2e-4, (rel(A[0], B[0]), rel(A[1], B[1]))
+    # (c) the whole schedule against the chain form's own sensitivity
+    full = (5, 10, 10, 10, 10)
+    A, B, Bp = run(True, full), run(False, full), run(False, full, scale=1.0 + 2.0 ** -22)
+    sens = max(rel(Bp[0], B[0]), rel(Bp[1], B[1]), 1e-4)
+    err = max(rel(A[0], B[0]), rel(A[1], B[1]))
+    print('Cin=%d %dx%d: resident vs chain after the full fit %.2e, chain vs itself (+1 ulp features) %.2e' % (cin, h, w, err, sens))
+    assert err < 10 * sens, (err, sens)
+    # (d) determinism
+    A2 = run(True, full)
+    assert torch.equal(A[0], A2[0]) and torch.equal(A[1], A2[1])
+
+
+def test_resident_joint_fit_abort_writes_nothing():
+    """A resident launch that times out (debug_abort: the first waiting workgroup gives up at once) leaves the variables and the solver
+    state untouched and is counted; Discriminator.init_aborted() / GaussNewtonCG.joint_aborts() report it (the tracker then re-runs the
+    sequence in the chain form)."""
+    mem, prob, opt, w1, w2 = _joint_case(256, 32, 24, 40, 96, 160, 7, True)
+    prob.initialize()
+    assert opt._persistent_joint_plan() is not None
+    opt._alloc()
+    w1_0, w2_0, buf0, st0 = w1.detach().clone(), w2.detach().clone(), opt._buf.clone(), opt._state.clone()
+    opt.debug_abort = True
+    opt.run((4,))
+    opt.debug_abort = False
+    torch.cuda.synchronize()
+    assert opt.joint_aborts() >= 1 and int(opt._gstats[3]) == 0
+    assert torch.equal(w1.detach(), w1_0) and torch.equal(w2.detach(), w2_0) and torch.equal(opt._buf, buf0) and torch.equal(opt._state, st0)
+    opt.run((4,))
+    torch.cuda.synchronize()
+    assert int(opt._gstats[3]) == 1 and not torch.equal(w2.detach(), w2_0)
