@@ -645,6 +645,15 @@ class Discriminator(nn.Module):
             opt.run(self.update_iters, guard=counts[W - 1, plane:plane + 1], guard_min=10)
             self._guarded_runs += 1
 
+    def resident_init(self, K, h, w):
+        """Will init() on K samples of (in_channels, h, w) features run its joint fit in the resident form (csrc/joint_persistent.hip)?
+        Such fits each want the whole chip: the tracker then enqueues the objects one after the other instead of on concurrent streams
+        (two resident grids cannot be co-resident; measured with five objects on four streams: 51 ms instead of 40, and time-outs)."""
+        from .optimizer import GaussNewtonCG
+        if not (DiscriminatorLoss.persistent_joint and GaussNewtonCG.persistent_joint):
+            return False
+        return H.lib().frtm_joint_persistent_plan(int(K), int(self.project.in_channels), int(self.project.out_channels), int(h), int(w), None) > 0
+
     def init_aborted(self):
         """True if a resident launch of the first-frame fit (csrc/joint_persistent.hip) timed out since the last call: that Gauss-Newton
         iteration is MISSING from this target model.  SYNCHRONISES (4 bytes); the tracker asks after the final synchronise of a sequence and

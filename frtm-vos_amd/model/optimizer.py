@@ -95,6 +95,14 @@ class GaussNewtonCG:
         self._shadow = None
         self._partial = torch.zeros(4 * 64, device=dev)
         self._has_p = False
+        # everything a launch may need exists BEFORE a caller opens a hipGraph capture around run(): the counters (+ their pinned mirror)
+        # and, for a joint problem that can take the resident form, its exchange scratch (sized for the memory's capacity)
+        self._stats()
+        pr = self.problem
+        if getattr(pr, 'joint', False) and hasattr(pr, 'persistent_joint_args'):
+            need = int(H.lib().frtm_joint_persistent_scratch(int(pr.mem.capacity), int(pr.Cin), int(pr.c), int(pr.h), int(pr.w)))
+            if need > 0 and (getattr(self, '_jbuf', None) is None or self._jbuf[0].numel() < need):
+                self._jbuf = (torch.empty(need, device=dev), torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(288, dtype=torch.int32, device=dev))
 
     @property
     def b(self):

@@ -595,6 +595,11 @@ class Tracker(nn.Module):
             # they overlap on the GPU (reference :186-187 runs them one after the other)
             cur = torch.cuda.current_stream()
             lanes = self._init_streams(min(len(fresh), self.init_lanes)) if len(fresh) > 1 and self.init_lanes > 1 else []
+            if lanes:
+                # resident fits (one launch per Gauss-Newton iteration, all CUs each) go one after the other on this stream
+                fshape = (ft_all if share else ft)[fresh[0][0].disc_layer].shape
+                if fresh[0][0].discriminator.resident_init(fresh[0][1].shape[0], fshape[-2], fshape[-1]):
+                    lanes = []
             for st in lanes:
                 st.wait_stream(cur)
             b0 = 1 if share else 0
