@@ -47,6 +47,8 @@ struct frtm_backbone {
   bool use_winograd = true;
   // three-launch Winograd where it is eligible (run_conv): 0 = off, 1 = F(4x4,3x3) only, 2 = F(4x4,3x3) or F(6x6,3x3), whichever has fewer products
   int use_winograd4 = getenv("FRTM_NO_WINO4") ? 0 : getenv("FRTM_NO_WINO6") ? 1 : 2;
+  // fewest 64x64 product tiles for which the three-launch forms are taken (256 = one per CU: measured at batch 1 -- the streaming path -- 2.49 -> 2.23 ms per trunk pass; FRTM_WINO4_MIN_TILES)
+  int wino4_min_tiles = getenv("FRTM_WINO4_MIN_TILES") ? atoi(getenv("FRTM_WINO4_MIN_TILES")) : 256;
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
@@ -129,7 +131,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       if (m == 6 && (bb->use_winograd4 < 2 || !c.wW6)) continue;
       const int th = ceil_div(*Ho, m), tw = ceil_div(*Wo, m), NP = (m + 2) * (m + 2);
       const long T = (long)B * th * tw, Tp = (T + 63) / 64 * 64;
-      if ((long)ceil_div(c.Cout, 64) * (NP * Tp / 64) < 512 || (long)m * m * th * tw * 4 > (long)5 * (*Ho) * (*Wo) ||
+      if ((long)ceil_div(c.Cout, 64) * (NP * Tp / 64) < bb->wino4_min_tiles || (long)m * m * th * tw * 4 > (long)5 * (*Ho) * (*Wo) ||
           (size_t)NP * std::max(c.Cin, c.Cout) * Tp * 4 >= 0x7fffffffull)       // (32-bit buffer offsets of the transformed tensors)
         continue;
       if (!best_m || NP * Tp < best_cost) { best_m = m; best_cost = NP * Tp; best_T = T; best_Tp = Tp; }
