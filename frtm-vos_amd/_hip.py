@@ -68,6 +68,7 @@ SIGNATURES = {
     'frtm_backbone_conv_info': (I, [P, I, P]),
     'frtm_backbone_set_conv': (I, [P, I, P, P, P, P]),
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
+    'frtm_backbone_forward_at': (I, [P, I, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_last_flops': (D, [P]),
     'frtm_backbone_last_flops_executed': (D, [P]),
     'frtm_backbone_last_flops_form': (D, [P, I]),

@@ -39,7 +39,7 @@ struct frtm_backbone {
   std::vector<std::vector<BlockL>> stages;   // 4 stages
   std::vector<Lane> lanes = std::vector<Lane>(1);
   int nlanes = 1;
-  hipEvent_t fork = nullptr;
+  hipEvent_t fork = nullptr, fork1 = nullptr;      // one fork event per lane set
   double last_flops = 0.0;
   double last_flops_form[4] = {0.0, 0.0, 0.0, 0.0};   // algorithmic FLOPs of the last pass by kernel form: direct, Winograd F(2x2,3x3), F(4x4,3x3), F(6x6,3x3)
   double last_flops_exec = 0.0;    // the same with Winograd launches counted at the MACs they execute (F(2x2,3x3): 16 per 2x2 outputs instead of 36; F(4x4,3x3): 36 per 4x4 tile instead of 144, partial edge tiles included)
@@ -307,6 +307,7 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
     if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   if (bb->fork) (void)hipEventDestroy(bb->fork);
+  if (bb->fork1) (void)hipEventDestroy(bb->fork1);
   delete bb;
   return FRTM_OK;
 }
@@ -374,8 +375,10 @@ int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable) {
 
 int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
   FRTM_CHECK_ARG(bb && lanes >= 1 && lanes <= 8, "frtm_backbone_set_lanes: lanes must be 1..8");
-  if ((int)bb->lanes.size() < lanes) bb->lanes.resize(lanes);
-  for (int l = 1; l < lanes; ++l) {
+  // TWO lane sets (round 4): set 0 = lanes [0, n), set 1 = lanes [n, 2n) with their own arenas / scratch / streams, so that two passes
+  // (the first tracking pass and initialize()'s pass over the augmented stacks) can be in flight at once (frtm_backbone_forward_at)
+  if ((int)bb->lanes.size() < 2 * lanes) bb->lanes.resize(2 * lanes);
+  for (int l = 1; l < 2 * lanes; ++l) {
     Lane& ln = bb->lanes[l];
     if (!ln.stream) FRTM_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     if (!ln.done) FRTM_HIP(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
@@ -388,7 +391,21 @@ int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
 int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                           const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
                           int stop_after_layer, frtm_stream_t stream) {
+  return frtm_backbone_forward_at(bb, 0, image_u8, B, H, W, norm_scale3, norm_bias3, layer1, layer2, layer3, layer4, layer5, stop_after_layer, stream);
+}
+
+int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
+                             const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
+                             int stop_after_layer, frtm_stream_t stream) {
   FRTM_CHECK_ARG(bb && image_u8 && norm_scale3 && norm_bias3 && B > 0 && H >= 32 && W >= 32, "frtm_backbone_forward: bad argument");
+  FRTM_CHECK_ARG(lane_set == 0 || lane_set == 1, "frtm_backbone_forward_at: lane_set must be 0 or 1");
+  if ((int)bb->lanes.size() < 2 * bb->nlanes) { int rc = frtm_backbone_set_lanes(bb, bb->nlanes); if (rc) return rc; }
+  const int lbase = lane_set * bb->nlanes;
+  hipEvent_t fork = bb->fork;
+  if (lane_set == 1) {
+    if (!bb->fork1) FRTM_HIP(hipEventCreateWithFlags(&bb->fork1, hipEventDisableTiming));
+    fork = bb->fork1;
+  }
   FRTM_CHECK_ARG(stop_after_layer >= 1 && stop_after_layer <= 5, "frtm_backbone_forward: stop_after_layer must be 1..5");
   hipStream_t st = (hipStream_t)stream;
   bb->last_flops = 0.0;
@@ -409,13 +426,13 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
     per_img[s + 1] = (size_t)(64 << s) * exp * th * tw;
   }
   float* taps[5] = {layer1, layer2, layer3, layer4, layer5};
-  if (L > 1) FRTM_HIP(hipEventRecord(bb->fork, st));
+  if (L > 1) FRTM_HIP(hipEventRecord(fork, st));
   int b0 = 0;
   for (int l = 0; l < L; ++l) {
-    Lane& ln = bb->lanes[l];
+    Lane& ln = bb->lanes[lbase + l];
     const int Bl = B / L + (l < B % L ? 1 : 0);
     hipStream_t ls = (l == 0) ? st : ln.stream;              // lane 0 stays on the caller's stream
-    if (l > 0) FRTM_HIP(hipStreamWaitEvent(ls, bb->fork, 0));
+    if (l > 0) FRTM_HIP(hipStreamWaitEvent(ls, fork, 0));
     for (int c0 = 0; c0 < Bl; c0 += max_imgs) {              // one call per lane unless the batch is too large for it
       const int Bc = std::min(max_imgs, Bl - c0);
       float* tl[5];
@@ -427,7 +444,7 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
     if (l > 0) FRTM_HIP(hipEventRecord(ln.done, ls));
     b0 += Bl;
   }
-  for (int l = 1; l < L; ++l) FRTM_HIP(hipStreamWaitEvent(st, bb->lanes[l].done, 0));
+  for (int l = 1; l < L; ++l) FRTM_HIP(hipStreamWaitEvent(st, bb->lanes[lbase + l].done, 0));
   return FRTM_OK;
 }
 

@@ -160,7 +160,7 @@ class ResnetFeatureExtractor:
         self._winograd6 = not os.environ.get('FRTM_NO_WINO6')
         self.use_graph = False         # with reuse_outputs: replay a captured hipGraph per (batch, size) instead of enqueuing the launches
         self.capture_after = 1         # trunk shapes are replayed as hipGraphs from their (capture_after + 1)-th use on
-        self._pass_done = None         # event behind the last pass: the native trunk (lane arenas, split-K scratch) is not re-entrant
+        self._pass_done = {}           # lane set -> event behind its last pass: a lane set (arenas, scratch) runs one pass at a time
         self.pass_frames = []
         self.pass_events = None        # a list: every pass appends (start event, end event, FLOPs, conv launches)  (bench.py's roofline leg)
 
@@ -259,8 +259,10 @@ class ResnetFeatureExtractor:
                        H.ptr(scale), H.ptr(shift))
             torch.cuda.current_stream().synchronize()      # the temporaries above die with this scope
 
-    def __call__(self, input, output_layers=None):
-        """input: (B,3,H,W) or (3,H,W) uint8 -> dict of fp32 NCHW taps 'layer1'..'layer5' (reference :40-68)."""
+    def __call__(self, input, output_layers=None, lane_set=0):
+        """input: (B,3,H,W) or (3,H,W) uint8 -> dict of fp32 NCHW taps 'layer1'..'layer5' (reference :40-68).
+        ``lane_set`` (0 / 1): which of the native trunk's two sets of lanes (arenas, scratch, streams) runs the pass; passes on different
+        sets may be in flight at once (frtm_backbone_forward_at), passes on the same set are serialised here."""
         if self._handle is None:
             raise RuntimeError('call .to(device) first')
         x = input
@@ -274,8 +276,9 @@ class ResnetFeatureExtractor:
         # main stream) share the lanes' activation arenas, so a pass first waits for the previous one, whatever stream that ran on.
         cur = torch.cuda.current_stream(self.device)
         capturing = torch.cuda.is_current_stream_capturing()
-        if self._pass_done is not None and not capturing:
-            cur.wait_event(self._pass_done)
+        self._lane_set = int(lane_set)
+        if self._pass_done.get(self._lane_set) is not None and not capturing:
+            cur.wait_event(self._pass_done[self._lane_set])
         timed = self.pass_events is not None and not capturing
         if timed:                                             # (after the wait: the pair brackets this pass's own kernels)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,8 +295,8 @@ class ResnetFeatureExtractor:
                 if getattr(self, 'pass_form_flops', None) is not None:
                     self.pass_form_flops.append(list(self.last_flops_form))
             if not capturing:
-                self._pass_done = torch.cuda.Event()
-                self._pass_done.record(cur)
+                self._pass_done[self._lane_set] = torch.cuda.Event()
+                self._pass_done[self._lane_set].record(cur)
 
     @H.roctx('trunk pass')
     def _call(self, x, B, Hh, Ww, output_layers):
@@ -314,7 +317,7 @@ class ResnetFeatureExtractor:
             return out
         # persistent taps: one allocation per (size, tap set) with room for the largest batch seen; smaller batches (the
         # last pass of a sequence) write a prefix of it, so consumers keyed by tap addresses (the refiner's graphs) stay valid
-        okey = (Hh, Ww, tuple(want), self.output_set)
+        okey = (Hh, Ww, tuple(want), self.output_set, getattr(self, '_lane_set', 0))
         buf = self._out_bufs.get(okey)
         if buf is None or buf['cap'] < B:
             self._buf_serial += 1
@@ -358,7 +361,7 @@ class ResnetFeatureExtractor:
 
     def _forward(self, x, out, args, stop):
         ptrs = [H.ptr(out.get(L)) for L in ('layer1', 'layer2', 'layer3', 'layer4', 'layer5')]
-        H.call('frtm_backbone_forward', self._handle, H.ptr(x), *args, *ptrs, stop)
+        H.call('frtm_backbone_forward_at', self._handle, int(getattr(self, '_lane_set', 0)), H.ptr(x), *args, *ptrs, stop)
         self.last_flops = H.lib().frtm_backbone_last_flops(self._handle)
         self.last_flops_executed = H.lib().frtm_backbone_last_flops_executed(self._handle)    # Winograd launches at the MACs they execute
         self.last_flops_form = [H.lib().frtm_backbone_last_flops_form(self._handle, k) for k in range(4)]   # direct, F(2x2,3x3), F(4x4,3x3), F(6x6,3x3)

@@ -99,6 +99,13 @@ class Tracker(nn.Module):
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
         self.share_first_sample = True   # the un-augmented frame (sample 0 of every object's stack) passes the trunk once per frame
         self.early_first_pass = True     # first tracking pass enqueued before initialize(): it runs under the host-bound augmentation
+        # ... and initialize()'s own pass could run NEXT TO it on the trunk's second lane set (frtm_backbone_forward_at).  OFF: measured in
+        # round 4 (20-frame sequence, tools/timeline_init.sh): with the runtime's default 4 hardware queues the tracker's stream shares a queue
+        # with a trunk lane and runs behind it anyway; with GPU_MAX_HW_QUEUES=8 the two passes do overlap ([0, 29.3] and [3.4, 18.9] ms) but
+        # finish no earlier than one after the other (30.2 ms): four lanes share the GPU at 110 TFLOP/s, and more hardware queues slow
+        # everything else down (397 instead of 415 frames/s at 8, 350 at 16).
+        self.concurrent_init_pass = bool(os.environ.get('FRTM_CONCURRENT_INIT_PASS'))
+        self._early_pass_event = None
         self._init_pool = []
         self._disc_pool = []
         self.graph_refiner = True
@@ -498,6 +505,8 @@ class Tracker(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(st)
                 batch.record_stream(st)
+                if on is not None:
+                    self._early_pass_event = ev          # initialize() runs its own pass NEXT TO this one (second lane set) and waits here before the fits
             else:
                 if persistent:
                     ext.output_set = 0              # single tap set: the refiner's graphs stay keyed to 4 slice addresses
@@ -584,10 +593,18 @@ class Tracker(nn.Module):
             # Sample 0 of every object's augmented stack is the frame itself (augment_first_frame's contract, reference
             # augmenter.py:546-547): it goes through the trunk ONCE for all objects that start here, not once per object.
             share = self.share_first_sample and len(fresh) > 1
+            # (opt-in, concurrent_init_pass: with the first tracking pass in flight on a side stream this pass takes the trunk's SECOND lane
+            # set and runs next to it instead of behind it; measured: no gain, see __init__)
+            early = getattr(self, '_early_pass_event', None) if self.concurrent_init_pass else None
+            ls = 1 if early is not None else 0
             if share:
-                ft_all = self.feature_extractor(torch.cat([fresh[0][1][:1]] + [im[1:] for _, im, _ in fresh]), layers)
+                ft_all = self.feature_extractor(torch.cat([fresh[0][1][:1]] + [im[1:] for _, im, _ in fresh]), layers, lane_set=ls)
             else:
-                ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers)
+                ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers, lane_set=ls)
+            if early is not None:
+                # the fits wait for the tracking pass: a resident fit wants every CU (two of them next to trunk kernels time out)
+                torch.cuda.current_stream().wait_event(early)
+            self._early_pass_event = None
             if self._after_init_trunk is not None:
                 hook, self._after_init_trunk = self._after_init_trunk, None
                 hook()

@@ -338,6 +338,13 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
                           const float* norm_scale3, const float* norm_bias3,
                           float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
                           int stop_after_layer, frtm_stream_t stream);
+/* The same pass on lane set `lane_set` (0 or 1).  The two sets own separate activation arenas, scratch and internal streams, so ONE pass per
+ * set may be in flight at a time: the first tracking pass of a sequence (set 0, enqueued before Tracker.initialize, reference
+ * tracker.py:165-191) next to initialize()'s pass over the augmented first-frame stacks (set 1, feature_extractor.py:40-68 called from
+ * tracker.py:186).  Results do not depend on the set. */
+int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
+                             const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
+                             int stop_after_layer, frtm_stream_t stream);
 /* FLOPs (2*MAC over all convs) of the last forward() call. */
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */

@@ -87,16 +87,23 @@ def main():
     ap.add_argument('--out', default=None)
     ap.add_argument('--spec', default='v1', help="v1 = fixture G12 (round 3), v2 = fixture G14 (round 4: 32 x 40, 1-5 objects)")
     ap.add_argument('--no-labels', action='store_true', help='store J / F per object only (noise-floor and arbiter runs)')
+    ap.add_argument('--perturb', type=int, default=0,
+                    help="noise-floor runs: the trunk's stem weights scaled by (1 + K * 2^-23), i.e. a K-ulp relative change of every feature -- the size "
+                         "of a different summation order; how far does the REFERENCE arithmetic move under it at dataset level?")
     args = ap.parse_args()
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     torch.set_num_threads(args.threads)
     dtype = getattr(torch, args.dtype)
     P = O.resnet_random_params(BACKBONE, seed=0)
+    if args.perturb:
+        P = dict(P)
+        P['conv1.weight'] = P['conv1.weight'] * (1.0 + args.perturb * 2.0 ** -23)
     refiner = refiner_for()
     out = args.out or os.path.join(ROOT, 'tests', 'golden', 'g12_jf_%s.npz' % args.dtype)
     res = dict(np.load(out)) if (args.first > 0 and os.path.exists(out)) else {}
     specs = sequence_specs(args.sequences, args.frames, args.spec)
     res['threads'] = np.array(args.threads)
+    res['perturb_ulps'] = np.array(args.perturb)
     res['specs'] = np.array([[f, n, s] for _, f, n, s in specs])
     for k, (name, n_frames, n_obj, seed) in enumerate(specs):
         if k < args.first:

@@ -11,7 +11,7 @@ python $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/bench64.json 2> 
 python $R/bench.py --steps 20 --warmup 5 > $O/bench20.json 2> $O/bench20.err
 # 2. kernel trace + stats of the same default command
 rm -rf /tmp/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -o prof -- python $R/bench.py --no-cpu-baseline --no-init-sweep --no-cg-roofline --no-dataset-sim > $O/bench_traced.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -o prof -- python $R/bench.py --no-cpu-baseline --no-init-sweep --no-cg-roofline --no-dataset-sim --no-streaming --repeats 1 > $O/bench_traced.json 2>/dev/null
 mkdir -p $O/prof_final
 cp $(find /tmp/prof_final -name "prof_kernel_stats.csv" | head -1) $O/prof_final/
 python - <<PY
@@ -45,6 +45,5 @@ done
 rm -rf /tmp/pmc_sq; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -o p -- python $R/tools/trunk_bench.py 8 1 > /dev/null 2>&1
 mkdir -p $O/pmc_sq; cp $(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1) $O/pmc_sq/
 python $R/tools/trunk_bench.py 16 2 > $O/trunk_plain.txt 2>/dev/null; python $R/tools/trunk_bench.py 8 1 >> $O/trunk_plain.txt 2>/dev/null
-# 4. the other configurations
-python $R/tools/run_configs.py $tag > /dev/null 2>&1; cp $R/gpurun_out/${tag}_configs.txt $O/ 2>/dev/null
+# 4. the other configurations: tools/run_configs.py, run separately (it takes longer than everything above)
 du -sh $O; ls $O
