@@ -390,7 +390,7 @@ def jf_vs_fixture(dev):
     hip = np.concatenate([np.array(res[k]) for k in range(len(specs))]).mean(1) * 100
     ora = np.concatenate([fx['jf_%d' % k] for k in range(len(specs))]).mean(1) * 100
     others = {}
-    for name in ('float32_t2', 'float32_t3', 'float32_t6', 'float64'):
+    for name in ('float32_t2', 'float32_t3', 'float32_t6', 'float32_p1', 'float32_p3', 'float64'):
         f = os.path.join(G, 'g14_jf_%s.npz' % name)
         if os.path.exists(f):
             o = np.load(f)

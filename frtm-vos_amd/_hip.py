@@ -92,6 +92,8 @@ SIGNATURES = {
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_affine_u8': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_mask_batch': (I, [P, I, I, P, I, I, P, I, P, P]),
+    'frtm_fill32': (I, [P, ctypes.c_size_t, ctypes.c_uint, P]),
+    'frtm_label_mask': (I, [P, I, ctypes.c_size_t, P, P, P]),
     'frtm_mask_stats': (I, [P, I, I, I, P, P]),
     'frtm_aug_prepare': (I, [P, P, I, I, P, P, P, P, P]),
     'frtm_pull_push_fill': (I, [P, ctypes.c_size_t, I, I, P]),
@@ -215,6 +217,17 @@ def upload(t, device):
         st = _stagers[key] = _Stager()
     with torch.cuda.device(key):
         return st.put(t, dev)
+
+
+def fill(t, value=0):
+    """In-place fill of a DENSE float32 / int32 tensor (or slice) as a runtime memset node -- no framework kernel (frtm_fill32)."""
+    import struct
+    assert t.is_contiguous() and t.element_size() == 4, 'fill: dense 4-byte elements only'
+    if t.numel() == 0:
+        return t
+    bits = struct.unpack('<I', struct.pack('<f', float(value)))[0] if t.dtype == torch.float32 else (int(value) & 0xffffffff)
+    call('frtm_fill32', t.data_ptr(), t.numel(), bits)
+    return t
 
 
 def normalize_device(device):

@@ -508,3 +508,28 @@ extern "C" int frtm_aug_blend(const float* wt4, const float* canvas3, int n, int
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
+
+// ---- n 32-bit words <- pattern, as a runtime memset node (no framework kernel): the zero / one fills of the per-sequence state
+// (solver vectors, memory weights, counters, mask planes) on the initialize() path.
+extern "C" int frtm_fill32(void* dst, size_t n_words, unsigned pattern, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(dst || n_words == 0, "frtm_fill32: null pointer");
+  if (n_words) FRTM_HIP(hipMemsetD32Async((hipDeviceptr_t)dst, (int)pattern, n_words, (hipStream_t)stream));
+  return FRTM_OK;
+}
+
+// ---- Tracker.initialize (reference tracker.py:170-172,188): mask = (labels == obj_id) as uint8 AND as the float plane of current_masks
+__global__ __launch_bounds__(256) void k_label_mask(const unsigned char* __restrict__ labels, int obj_id, size_t n, unsigned char* __restrict__ mask_u8,
+                                                     float* __restrict__ plane) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned char m = labels[i] == (unsigned char)obj_id ? 1 : 0;
+    mask_u8[i] = m;
+    if (plane) plane[i] = (float)m;
+  }
+}
+
+extern "C" int frtm_label_mask(const unsigned char* labels_u8, int obj_id, size_t n, unsigned char* mask_u8, float* plane_f32, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(labels_u8 && mask_u8 && n > 0 && obj_id >= 0 && obj_id < 256, "frtm_label_mask: bad argument");
+  k_label_mask<<<(int)min((n + 255) / 256, (size_t)1024), 256, 0, (hipStream_t)stream>>>(labels_u8, obj_id, n, mask_u8, plane_f32);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}

@@ -20,6 +20,7 @@ from .. import _hip as H
 
 
 class Memory:
+    _init_weights = {}           # (K, device) -> the initial sample weights (2, 1, ..., 1) / (K + 1), formed once in the reference's arithmetic
 
     def __init__(self, capacity, feature_size, labels_size, device, learning_rates, grid_size=None,
                  pixel_weighting=None, keep_hires=False):
@@ -146,13 +147,13 @@ class Memory:
 
     def clear(self):
         self.current_size = 0
-        self.weights.zero_()
+        H.fill(self.weights, 0.0)
 
     def reset(self):
         """Back to the state after construction (buffers are kept: a recycled memory serves the next object)."""
         self.clear()
-        self._slot[:2].fill_(-1)
-        self._slot[2:].zero_()
+        H.fill(self._slot[:2], -1)
+        H.fill(self._slot[2:], 0)
         self._have_prev = False
 
     def matches(self, capacity, feature_size, labels_size, grid_size=None, keep_hires=False):
@@ -176,10 +177,15 @@ class Memory:
         """Reference memory.py:33-48.  pixel_weights=None: hinge weights are computed inside the kernel."""
         K = init_features.shape[0]
         assert init_labels.shape[0] == K and K <= self._capacity
-        self.samples[:K] = init_features.detach()
-        w = torch.full((K,), 1.0 / K, device=self.device)
-        w[:1].fill_(2.0 / K)            # (not `w[0] = ...`: a Python scalar assigned by index goes through a blocking H2D copy)
-        self.weights[:K] = w / w.sum()
+        self.samples[:K].copy_(init_features.detach())
+        # (2, 1, ..., 1) / (K + 1) in the reference's float32 arithmetic (memory.py:38-46: w = [2/K, 1/K, ...]; w / w.sum()), computed once per
+        # K and kept on the device: the per-sequence path is one device-to-device copy, no framework kernel
+        cache = Memory._init_weights.get((K, str(self.device)))
+        if cache is None:
+            w = torch.full((K,), 1.0 / K, device=self.device)
+            w[:1].fill_(2.0 / K)
+            cache = Memory._init_weights[(K, str(self.device))] = (w / w.sum()).contiguous()
+        self.weights[:K].copy_(cache)
         lab, pw = self._build_normals(init_labels, pixel_weights, K, None, 0)
         if self.keep_hires:
             self._labels[:K] = lab.float().view(K, *self.labels_size)
@@ -192,10 +198,10 @@ class Memory:
         static device buffers are touched, so the call can be part of a captured hipGraph (Discriminator.init)."""
         K = init_features.shape[0]
         assert K == other.current_size and K <= self._capacity and self.grid == other.grid and not self.keep_hires
-        self.samples[:K] = init_features.detach()
-        self.weights[:K] = other.weights[:K]          # (2, 1, ..., 1) / (K + 1): memory.py:38-46, same for both memories
-        self.normal_B[:K] = other.normal_B[:K]
-        self.normal_c[:K] = other.normal_c[:K]
+        self.samples[:K].copy_(init_features.detach())
+        self.weights[:K].copy_(other.weights[:K])     # (2, 1, ..., 1) / (K + 1): memory.py:38-46, same for both memories
+        self.normal_B[:K].copy_(other.normal_B[:K])
+        self.normal_c[:K].copy_(other.normal_c[:K])
         self.current_size = K
 
     def _hires_pw(self, lab):

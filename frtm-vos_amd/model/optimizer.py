@@ -135,9 +135,8 @@ class GaussNewtonCG:
         """Back to the state of a newly constructed solver, keeping the device buffers (a recycled target model re-runs its
         first-frame fit through the same buffers, possibly as a replayed hipGraph: only device-side fills, no allocation)."""
         self._alloc()
-        self._buf.zero_()
-        self._state.zero_()
-        self._state[:1].fill_(1.0)
+        H.fill(self._all, 0.0)                              # _buf and _state are slices of this one allocation
+        H.fill(self._state[:1], 1.0)
         self._has_p = False
         self.step_alpha = self._step_alpha0
         return self
@@ -146,7 +145,7 @@ class GaussNewtonCG:
         self._g.update(p=None, rho=torch.ones(1), r_prev=None)
         self._has_p = False
         if self._buf is not None:
-            self._state[:1].fill_(1.0)
+            H.fill(self._state[:1], 1.0)
 
     # ---- solver ---------------------------------------------------------------------------
     # Set (for the whole process) once a persistent launch has timed out: the GPU is shared with something that keeps this solver's
@@ -307,7 +306,7 @@ class GaussNewtonCG:
 
     def reset_persistent_counts(self):
         if self._gstats is not None:
-            self._gstats[:2].zero_()
+            H.fill(self._gstats[:2], 0)
 
     def persistent_counts(self):
         """(guarded runs completed, guarded runs that took the device-side early-out) so far.  SYNCHRONISES."""

@@ -567,10 +567,16 @@ class Tracker(nn.Module):
     @H.roctx('initialize')
     def initialize(self, image, labels, new_objects):
         """Reference tracker.py:165-191."""
-        self.current_masks = torch.zeros((len(self.targets) + len(new_objects) + 1, *image.shape[-2:]), device=self.device)
+        Hh, Ww = image.shape[-2:]
+        self.current_masks = H.fill(torch.empty((len(self.targets) + len(new_objects) + 1, Hh, Ww), device=self.device), 0.0)
+        lab8 = labels.reshape(Hh, Ww)
+        lab8 = (lab8 if lab8.dtype == torch.uint8 else lab8.to(torch.uint8)).contiguous()
         fresh = []
         for obj_id in new_objects:
-            mask = (labels == obj_id).byte()
+            # mask = (labels == obj_id) as uint8 and as the object's plane of current_masks: one kernel (reference :170-172,188)
+            mask = torch.empty(1, Hh, Ww, dtype=torch.uint8, device=self.device)
+            H.call('frtm_label_mask', lab8.data_ptr(), int(obj_id), Hh * Ww, mask.data_ptr(),
+                   self.current_masks[len(self.targets) + 1].data_ptr())
             target = TargetObject(obj_id=obj_id, index=len(self.targets) + 1, disc_params=self.disc_params,
                                   discriminator=self._disc_pool.pop() if self._disc_pool else None,
                                   start_frame=self.current_frame, start_mask=mask)
@@ -585,7 +591,6 @@ class Tracker(nn.Module):
             np.random.seed(0)                  # augmentation draws are identical for every object
             im, msk = self.augment(image, mask)
             fresh.append((target, im, msk))
-            self.current_masks[target.index] = mask
         if fresh:
             # one trunk call for the augmented stacks of ALL objects that start on this frame (the reference runs one per
             # object, :186); same per-image results, larger launches and one lane per object
@@ -596,11 +601,18 @@ class Tracker(nn.Module):
             # (opt-in, concurrent_init_pass: with the first tracking pass in flight on a side stream this pass takes the trunk's SECOND lane
             # set and runs next to it instead of behind it; measured: no gain, see __init__)
             early = getattr(self, '_early_pass_event', None) if self.concurrent_init_pass else None
-            ls = 1 if early is not None else 0
+            kw = dict(lane_set=1) if early is not None else {}      # (a caller-supplied extractor need not know about lane sets)
+            def gather(parts):                  # (torch.cat without its framework kernel: device-to-device copies into one batch)
+                out = torch.empty((sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+                o = 0
+                for p in parts:
+                    out[o:o + p.shape[0]].copy_(p)
+                    o += p.shape[0]
+                return out
             if share:
-                ft_all = self.feature_extractor(torch.cat([fresh[0][1][:1]] + [im[1:] for _, im, _ in fresh]), layers, lane_set=ls)
+                ft_all = self.feature_extractor(gather([fresh[0][1][:1]] + [im[1:] for _, im, _ in fresh]), layers, **kw)
             else:
-                ft = self.feature_extractor(torch.cat([im for _, im, _ in fresh]), layers, lane_set=ls)
+                ft = self.feature_extractor(gather([im for _, im, _ in fresh]), layers, **kw)
             if early is not None:
                 # the fits wait for the tracking pass: a resident fit wants every CU (two of them next to trunk kernels time out)
                 torch.cuda.current_stream().wait_event(early)
@@ -624,7 +636,7 @@ class Tracker(nn.Module):
                 k = im.shape[0] - 1 if share else im.shape[0]
                 def fit(target=target, msk=msk, b0=b0, k=k):
                     # (the gather of the shared sample runs on the stream of the fit that reads it)
-                    feats = ({L: torch.cat((ft_all[L][:1], ft_all[L][b0:b0 + k])) for L in layers} if share
+                    feats = ({L: gather((ft_all[L][:1], ft_all[L][b0:b0 + k])) for L in layers} if share
                              else {L: ft[L][b0:b0 + k] for L in layers})
                     target.initialize(feats, msk)
                 if lanes:

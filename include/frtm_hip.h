@@ -469,6 +469,12 @@ int frtm_warp_affine_batch(const float* src, int C, int Hs, int Ws, float* dst, 
 int frtm_aug_blend(const float* wt4, const float* canvas3, int n, int H, int W, const unsigned char* cand_labels,
                    const int* index_dev, unsigned char* out_images, unsigned char* out_labels, frtm_stream_t stream);
 
+/* n 32-bit words <- pattern (a runtime memset node): the zero / one fills of per-sequence state on the initialize() path
+ * (reference: torch.zeros / fill_ in tracker.py:166, memory.py:33-48, optimizer.py:29-40). */
+int frtm_fill32(void* dst, size_t n_words, unsigned pattern, frtm_stream_t stream);
+/* mask = (labels == obj_id) as uint8 {0,1} and, if plane_f32 != NULL, as a float plane (reference tracker.py:170-172,188). */
+int frtm_label_mask(const unsigned char* labels_u8, int obj_id, size_t n, unsigned char* mask_u8, float* plane_f32, frtm_stream_t stream);
+
 /* dst[p,y,x] = sum_{i,j} G[i,j] * src[p, y+i-kh/2, x+j-kw/2], zero outside (the augmenter's blur, model/augmenter.py:330-345:
  * cv2.filter2D / F.conv2d(padding=k//2) semantics).  G: DEVICE float[kh*kw], odd kh, kw. */
 int frtm_blur2d(const float* src, int planes, int H, int W, const float* G, int kh, int kw, float* dst, frtm_stream_t stream);
