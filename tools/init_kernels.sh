@@ -7,15 +7,14 @@ import csv, glob, collections
 rows = list(csv.DictReader(open(glob.glob('/tmp/tl/**/t_kernel_trace.csv', recursive=True)[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 ms = [i for i, r in enumerate(rows) if 'k_mask_stats' in r['Kernel_Name']]
-# objects of the last sequence: the trailing run of k_mask_stats launches that are close together
+# the LAST sequence's initialize(): its objects' k_mask_stats launches are the last NOBJ ones
+import os
+nobj = int(os.environ.get('NOBJ', '2'))
 last = ms[-1]
-i0 = last
-for i in reversed(ms):
-    if int(rows[last]['Start_Timestamp']) - int(rows[i]['Start_Timestamp']) < 200e6:
-        i0 = i
+i0 = ms[-nobj]
 end = next((i for i in range(last, len(rows)) if 'k_track_merge' in rows[i]['Kernel_Name'] or 'k_filter_scores' in rows[i]['Kernel_Name'] and 'pitched' in rows[i]['Kernel_Name']), len(rows))
 cnt, tot = collections.Counter(), collections.Counter()
-for r in rows[max(i0 - 6, 0):end]:
+for r in rows[max(i0 - 4, 0):end]:
     n = r['Kernel_Name']
     if 'k_conv' in n or 'k_wino' in n or 'maxpool' in n or 'normalize_u8' in n or 'splitk' in n:
         n = '(trunk kernels)'
