@@ -66,6 +66,7 @@ SIGNATURES = {
     'frtm_backbone_destroy': (I, [P]),
     'frtm_backbone_num_convs': (I, [P]),
     'frtm_backbone_conv_info': (I, [P, I, P]),
+    'frtm_backbone_set_conv_plan': (I, [P, I, I, I]),
     'frtm_backbone_set_conv': (I, [P, I, P, P, P, P]),
     'frtm_backbone_forward': (I, [P, P, I, I, I, P, P, P, P, P, P, P, I, P]),
     'frtm_backbone_forward_at': (I, [P, I, P, I, I, I, P, P, P, P, P, P, P, I, P]),

@@ -17,6 +17,9 @@ struct ConvL {
   float* wW6 = nullptr;         // ... and the 64 matrices of F(6x6,3x3) (FRTM_WLAYOUT_WINO6)
   bool loaded = false;
   int layout = 0;
+  // per-conv launch plan (frtm_backbone_set_conv_plan; 0 = the planner's choice): the GEMM tile of the path the conv takes (direct 1x1 /
+  // gather conv, or the batched products of the three-launch Winograd forms; the output block 1..3 of the fused F(2x2,3x3) kernel) and split-K
+  int plan_tile = 0, plan_splitk = 0;
 };
 struct BlockL { int conv[3]; int nconv; int ds; };   // conv indices (ds = -1: identity shortcut)
 
@@ -100,6 +103,18 @@ static int ensure(frtm_backbone* bb, float** p, size_t* have, size_t need) {
   return FRTM_OK;
 }
 
+// The planner's exceptions from the IN-TRUNK tile scan (tools/trunk_tile_scan.py, profiles/r04_trunk_tile_scan.txt: every candidate tile
+// of every conv class timed as a whole RN101 pass with the tracker's lanes).  At 16 frames in two lanes NO class moves the pass by more
+// than the run-to-run noise (+0.2 % for the whole scanned plan: the concurrent lane fills the tails that separate the tiles when a launch
+// is timed alone, profiles/r03_g32p_bench.txt); at the 4-5 frames per lane of the first-frame pass the 32x32x2-MFMA kernel is ahead on the
+// two dominant layer3 GEMMs (9.08 -> 8.92 ms per 9-frame pass).
+static int scanned_tile(const ConvL& c, int B, int Ho, int Wo) {
+  const long ntiles = ((long)B * Ho * Wo + 63) / 64;
+  if (ntiles < 64 || ntiles > 130 || c.Cin != 256) return 0;
+  if ((c.ks == 3 && c.stride == 1 && c.Cout == 256) || (c.ks == 1 && c.stride == 1 && c.Cout == 1024)) return FRTM_TILE_G32_64x64;
+  return 0;
+}
+
 static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Win, const float* in, const float* residual, int relu,
                     float* out, int* Ho, int* Wo, hipStream_t st) {
   ConvL& c = bb->convs[idx];
@@ -144,6 +159,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       if (rc) return rc;
       d.w_layout = best_m == 6 ? FRTM_WLAYOUT_WINO6 : FRTM_WLAYOUT_WINO4;
       d.splitk = 1;
+      d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo);
       d.ws_elems = (int)std::min<size_t>(ln.ws4_elems, 0x7fffffff);
       bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * NP * (double)best_T;
       bb->last_flops_form[best_m == 6 ? 3 : 2] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
@@ -155,12 +171,15 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       (long)B * ceil_div(*Ho, 8) * ceil_div(*Wo, 8) * ceil_div(c.Cout, 32) >= FRTM_WINO_MIN_BLOCKS) {
     d.w_layout = FRTM_WLAYOUT_WINO3X3;
     d.splitk = 1;
+    d.tile = (c.plan_tile >= 1 && c.plan_tile <= 3) ? c.plan_tile : 0;
     bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks * (16.0 / 36.0);
     bb->last_flops_form[1] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
     return frtm_conv2d(&d, in, c.wW, nullptr, c.scale, c.shift, residual, out, ln.ws, st);
   }
   bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   bb->last_flops_form[0] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
+  d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo);
+  d.splitk = c.plan_splitk;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
 }
 
@@ -225,6 +244,10 @@ static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_
         idn = t3;
       }
       if (bl.nconv == 3) {
+#ifdef FRTM_DEBUG_ABLATE   // tools/trunk_fusion_bound.sh: upper bound of fusing conv3 + BN + residual + ReLU with the next block's conv1 in layer1 / layer2
+        static const int trunk_ablate = getenv("FRTM_TRUNK_ABLATE") ? atoi(getenv("FRTM_TRUNK_ABLATE")) : 0;
+        if ((trunk_ablate & 1) && s < 2 && bl.ds < 0) { ho = ch; wo = cw; } else      // conv1 of the identity-shortcut blocks NOT run (results wrong on purpose)
+#endif
         rc = run_conv(bb, ln, bl.conv[0], B, ch, cw, x, nullptr, 1, t1, &ho, &wo, st);
         if (rc) return rc;
         rc = run_conv(bb, ln, bl.conv[1], B, ho, wo, t1, nullptr, 1, t2, &h2, &w2, st);
@@ -319,6 +342,14 @@ int frtm_backbone_conv_info(const frtm_backbone_t* bb, int idx, int* out6) {
   const ConvL& c = bb->convs[idx];
   out6[0] = c.Cout; out6[1] = c.Cin; out6[2] = c.ks; out6[3] = c.stride; out6[4] = c.pad; out6[5] = 0;
   for (auto& st : bb->stages) for (auto& bl : st) if (bl.conv[bl.nconv - 1] == idx) out6[5] = 1;
+  return FRTM_OK;
+}
+
+int frtm_backbone_set_conv_plan(frtm_backbone_t* bb, int idx, int tile, int splitk) {
+  FRTM_CHECK_ARG(bb && idx >= 0 && idx < (int)bb->convs.size() && tile >= 0 && splitk >= 0, "frtm_backbone_set_conv_plan: bad argument");
+  bb->convs[idx].plan_tile = tile;
+  bb->convs[idx].plan_splitk = splitk;
+  bb->generation += 1;                 // captured graphs hold the old launches
   return FRTM_OK;
 }
 

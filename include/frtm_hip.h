@@ -332,6 +332,11 @@ int frtm_backbone_destroy(frtm_backbone_t* bb);
 int frtm_backbone_num_convs(const frtm_backbone_t* bb);
 /* Shape of conv #idx in forward order: out6 = {Cout, Cin, ksize, stride, pad, has_residual_input} */
 int frtm_backbone_conv_info(const frtm_backbone_t* bb, int idx, int* out6_host);
+/* Per-conv launch plan override (0 = the planner's choice): `tile` = FRTM_TILE_* of the GEMM launch of whichever path the conv takes (the
+ * direct 1x1 / gather conv, the batched products of the three-launch Winograd forms) or the output block 1..3 of the fused F(2x2,3x3)
+ * kernel; `splitk` as in frtm_conv_desc.  Used by tools/trunk_tile_scan.py to scan tiles IN the trunk (concurrent lanes change the
+ * ranking of the isolated scan) and by the planner's committed table.  Invalidates captured graphs (generation bump). */
+int frtm_backbone_set_conv_plan(frtm_backbone_t* bb, int idx, int tile, int splitk);
 int frtm_backbone_set_conv(frtm_backbone_t* bb, int idx, const float* w_oihw, const float* bn_scale,
                            const float* bn_shift, frtm_stream_t stream);
 int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W,
