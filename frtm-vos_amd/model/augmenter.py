@@ -12,7 +12,7 @@ box, the cut, the pull-push hole fill (a documented substitute for Telea inpaint
 ON THE DEVICE from the device-side bounding box), the 19 candidate label warps + counts, the batched bicubic warps of the survivors,
 blur, paste.  The host reads ONE record per object -- pixel count, bounding box and the candidate counts together -- because the
 reference's candidate selection (verify_frame + shuffle, augmenter.py:454-471,538-544) is host logic on numpy's RNG stream: how many
-draws it consumes depends on the counts.  Pixel pipeline pinned by oracle/aug_ref.py (tests/test_round4_gpu.py).
+draws it consumes depends on the counts.  Pixel pipeline pinned by the CPU restatement aug_ref.py of the test infrastructure (tests/test_round4_gpu.py).
 """
 from copy import deepcopy
 

@@ -418,3 +418,52 @@ def test_resident_joint_fit_abort_writes_nothing():
     opt.run((4,))
     torch.cuda.synchronize()
     assert int(opt._gstats[3]) == 1 and not torch.equal(w2.detach(), w2_0)
+
+
+def test_per_conv_tile_plan_changes_launches_not_results():
+    """frtm_backbone_set_conv_plan (tools/trunk_tile_scan.py): another GEMM tile for whole conv classes -- 1x1 convs on the
+    32x32x2-MFMA kernel, Winograd products on 32x64 tiles, a split-K gather conv -- changes the summation order only (taps within 2e-5 of
+    the planner's pass, relative to the tap's scale), bumps the generation (captured graphs are stale), a tile the path cannot run fails
+    loudly, and plan 0 restores the planner's pass bit for bit."""
+    import ctypes
+    from frtm_vos_amd import _hip as H
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    torch.manual_seed(3)
+    ext = ResnetFeatureExtractor('resnet50').to(DEV)
+    ext.lanes = 2
+    img = torch.randint(0, 256, (6, 3, 256, 448), dtype=torch.uint8, device=DEV)      # every map a multiple of 4 pixels: the G32 tiles apply
+    layers = ['layer2', 'layer3', 'layer4', 'layer5']
+    ref = {k: v.clone() for k, v in ext(img, layers).items()}
+    h = ext._handle
+    n = H.lib().frtm_backbone_num_convs(h)
+    info = []
+    for i in range(n):
+        o = (ctypes.c_int * 6)()
+        H.call_nostream('frtm_backbone_conv_info', h, i, o)
+        info.append(tuple(o))
+    gen0 = H.lib().frtm_backbone_generation(h)
+    touched = 0
+    for i, (co, ci, ks, st, _, _) in enumerate(info):
+        if ks == 1 and st == 1 and ci >= 256 and co >= 128:
+            H.call_nostream('frtm_backbone_set_conv_plan', h, i, 23, 0)      # FRTM_TILE_G32_64x64
+            touched += 1
+        elif ks == 3 and st == 1 and ci >= 128:
+            H.call_nostream('frtm_backbone_set_conv_plan', h, i, 2, 0)       # products / direct conv on 32x64 tiles
+            touched += 1
+        elif ks == 1 and st == 2:
+            H.call_nostream('frtm_backbone_set_conv_plan', h, i, 1, 2)       # gather conv, 64x64 tile, split-K 2
+            touched += 1
+    assert touched > 20 and H.lib().frtm_backbone_generation(h) > gen0
+    out = {k: v.clone() for k, v in ext(img, layers).items()}
+    for k in layers:
+        scale = float(ref[k].abs().max())
+        assert float((out[k] - ref[k]).abs().max()) <= 2e-5 * scale, k
+    assert any(not torch.equal(out[k], ref[k]) for k in layers), 'the plan did not change a single launch'
+    H.call_nostream('frtm_backbone_set_conv_plan', h, 0, 23, 0)              # the 7x7 stem cannot run on the 1x1 GEMM kernel
+    with pytest.raises(RuntimeError):
+        ext(img, layers)
+    torch.cuda.synchronize()
+    for i in range(n):
+        H.call_nostream('frtm_backbone_set_conv_plan', h, i, 0, 0)
+    again = ext(img, layers)
+    assert all(torch.equal(again[k], ref[k]) for k in layers)
