@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-streaming', action='store_true', help='skip the streaming leg (Tracker.track frame by frame: what an online caller gets)')
     ap.add_argument('--no-jf-fixture', action='store_true', help='skip the dataset-level J&F leg (fixture G14 tracked on the HIP path, ~40 s)')
+    ap.add_argument('--jf-draws', type=int, default=4, help='dataset runs of the HIP path in the J&F leg (stem weights moved by 0 .. n-1 ulp; the gate in tests/ uses 8)')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
@@ -353,12 +354,15 @@ def streaming_leg(tracker, seq, dev, n_frames=40):
     return out
 
 
-def jf_vs_fixture(dev):
+def jf_vs_fixture(dev, draws=4):
     """Dataset-level J&F parity in the driver's line (round-3 VERDICT "Next" #1): fixture G14's synthetic dataset (BASELINE config 3's shape:
     32 sequences x 40 frames, 1-5 objects, 77 objects, ResNet-101, full schedule, memory 80) is tracked on the HIP product path with the
     fixture's start weights / augmentation / refiner and evaluated with the G10-pinned DAVIS measures; the CPU side is NOT re-run here: the
-    fixture holds the float32 oracle's per-object J / F (oracle/make_golden_jf.py --spec v2), the same oracle at other thread counts (its
-    own noise floor) and its float64 run.  Part of the cpu_baseline leg (the only place bench.py may touch oracle/)."""
+    fixture holds the float32 oracle's per-object J / F (oracle/make_golden_jf.py --spec v2) at four thread counts and with its stem
+    weights moved by 1 / 3 ulp (the single-run noise of the REFERENCE arithmetic) and its float64 run.  The HIP side is tracked `draws`
+    times, stem weights moved by K = 0 .. draws-1 ulp (K = 0: the build as it ships): the +-0.1 bar is a statement about expectations --
+    one dataset-level run of EITHER implementation moves by ~0.05 (1 sigma) under such perturbations (tests/test_north_star_gpu.py runs
+    eight draws and gates on it).  Part of the cpu_baseline leg (the only place bench.py may touch oracle/)."""
     import copy
     from concurrent.futures import ProcessPoolExecutor
     import numpy as np
@@ -375,19 +379,25 @@ def jf_vs_fixture(dev):
     params.disc_params.update(**JF.DISC)
     trk = params.get_model().eval()
     trk.augment = shift_flip_augment
-    jobs = []
+    ext = trk.feature_extractor
+    stem = ext.resnet.conv1.weight.data.clone()
+    futs = {}
     t0 = time.time()
-    for k, (n_frames, n_obj, seed) in enumerate(specs):
-        seq = SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed)
-        trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
-        seq.preload(dev)
-        labels, _ = trk.run_sequence(seq)
-        seq.release()
-        jobs.append((k, torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy(), n_frames, n_obj, seed))
-    t_track = time.time() - t0
     with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2))) as ex:
-        res = dict(ex.map(_jf_eval_job, jobs))
-    hip = np.concatenate([np.array(res[k]) for k in range(len(specs))]).mean(1) * 100
+        for di in range(max(1, int(draws))):
+            ext.resnet.conv1.weight.data.copy_(stem * (1.0 + di * 2.0 ** -23))
+            ext.upload()
+            for k, (n_frames, n_obj, seed) in enumerate(specs):
+                seq = SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed)
+                trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
+                seq.preload(dev)
+                labels, _ = trk.run_sequence(seq)
+                seq.release()
+                futs[(di, k)] = ex.submit(_jf_eval_job, (k, torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy(), n_frames, n_obj, seed))
+        t_track = time.time() - t0
+        res = {key: np.array(f.result()[1]) for key, f in futs.items()}
+    hips = [np.concatenate([res[(di, k)] for k in range(len(specs))]).mean(1) * 100 for di in range(max(1, int(draws)))]
+    hip = hips[0]
     ora = np.concatenate([fx['jf_%d' % k] for k in range(len(specs))]).mean(1) * 100
     others = {}
     for name in ('float32_t2', 'float32_t3', 'float32_t6', 'float32_p1', 'float32_p3', 'float64'):
@@ -396,23 +406,26 @@ def jf_vs_fixture(dev):
             o = np.load(f)
             if all(('jf_%d' % k) in o for k in range(len(specs))):
                 others[name] = np.concatenate([o['jf_%d' % k] for k in range(len(specs))]).mean(1) * 100
-    draws = [ora] + [v for n_, v in others.items() if n_.startswith('float32')]
-    floor = max([abs(float(a.mean() - b.mean())) for i, a in enumerate(draws) for b in draws[i + 1:]] or [0.0])
-    spread = np.max([np.abs(a - b) for i, a in enumerate(draws) for b in draws[i + 1:]], axis=0) if len(draws) > 1 else np.zeros_like(ora)
-    stable = spread <= 1.0
-    out = {'fixture': 'tests/golden/g14_jf_float32.npz (32 sequences x 40 frames, %d objects; float32 CPU oracle, 4 threads)' % len(ora),
-           'J&F_hip_path': round(float(hip.mean()), 3), 'J&F_cpu_oracle_f32': round(float(ora.mean()), 3),
-           'diff_points': round(float(hip.mean() - ora.mean()), 3),
-           'oracle_noise_floor_points': round(floor, 3),
-           'oracle_other_runs': {n_: round(float(v.mean()), 3) for n_, v in others.items()},
-           'objects_stable_in_the_oracle': int(stable.sum()),
-           'diff_points_stable_objects': round(float(hip[stable].mean() - ora[stable].mean()), 3),
-           'per_object_abs_diff_mean': round(float(np.abs(hip - ora).mean()), 3), 'per_object_abs_diff_max': round(float(np.abs(hip - ora).max()), 2),
-           'per_object_median_diff': round(float(np.median(hip - ora)), 3),
+    o_draws = [ora] + [v for n_, v in others.items() if n_.startswith('float32')]
+    o_vals = np.array([float(v.mean()) for v in o_draws])
+    h_vals = np.array([float(v.mean()) for v in hips])
+    o_mean_obj = np.mean(o_draws, axis=0)
+    out = {'fixture': 'tests/golden/g14_jf_float32*.npz (32 sequences x 40 frames, %d objects; float32 CPU oracle: %d recorded runs)' % (len(ora), len(o_draws)),
+           'J&F_hip_path_mean_of_draws': round(float(h_vals.mean()), 3), 'J&F_cpu_oracle_f32_mean_of_runs': round(float(o_vals.mean()), 3),
+           'diff_points': round(float(h_vals.mean() - o_vals.mean()), 3),
+           'hip_draws_stem_weights_moved_by_K_ulp': [round(float(v), 3) for v in h_vals],
+           'oracle_f32_runs': {'float32_t4': round(float(ora.mean()), 3), **{n_: round(float(v.mean()), 3) for n_, v in others.items() if n_.startswith('float32')}},
+           'oracle_f64': round(float(others['float64'].mean()), 3) if 'float64' in others else None,
+           'single_run_noise_floor_points': {'oracle_f32_range': round(float(o_vals.max() - o_vals.min()), 3), 'hip_range': round(float(h_vals.max() - h_vals.min()), 3)},
+           'default_build_vs_oracle_4_threads': {'diff_points': round(float(hip.mean() - ora.mean()), 3),
+                                                 'per_object_abs_diff_mean': round(float(np.abs(hip - ora).mean()), 3),
+                                                 'per_object_abs_diff_max': round(float(np.abs(hip - ora).max()), 2),
+                                                 'per_object_median_diff': round(float(np.median(hip - ora)), 3)},
+           'per_object_median_diff_to_oracle_mean_per_draw': [round(float(np.median(h - o_mean_obj)), 3) for h in hips],
            'hip_tracking_seconds': round(t_track, 1),
-           'note': 'HIP side tracked here; the oracle side is the recorded fixture.  "stable" = objects on which the float32 oracle runs at '
-                   'different thread counts agree within 1 point of J&F (chaotic objects -- truncated GN/CG fits amplify rounding -- move by '
-                   'several points between two runs of the REFERENCE arithmetic itself).  North star: +-0.1 points.'}
+           'note': 'HIP side tracked here (draws x 1280 frames); the oracle side is the recorded fixture.  North star: +-0.1 points, tested on the '
+                   'means (one dataset-level run of either implementation is a random variable under ulp-level perturbations: a few objects under '
+                   'mutual occlusion take one of two trajectories, in the reference arithmetic as well).'}
     return out
 
 
@@ -1034,7 +1047,7 @@ def main():
             _phase('cpu baseline done')
             if not args.no_jf_fixture and args.backbone == 'resnet101' and os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'g14_jf_float32.npz')):
                 # the DATASET-level parity statement (77 objects) next to the 13-frame sample above
-                out['cpu_baseline']['jf_parity_dataset_level'] = jf_vs_fixture(dev)
+                out['cpu_baseline']['jf_parity_dataset_level'] = jf_vs_fixture(dev, args.jf_draws)
                 _phase('dataset-level J&F vs fixture G14 done')
     if rank == 0:
         print(json.dumps(out))

@@ -47,15 +47,25 @@ def _disk(r):
     return (x * x + y * y) <= r * r
 
 
+def _within(points, of, r):
+    """Which `points` pixels have an `of` pixel within the disk {dy^2 + dx^2 <= r^2}: exactly `points & binary_dilation(of, _disk(r))`
+    (zero border), through one exact Euclidean distance transform instead of a (2r+1)^2-element dilation -- 17x17 at 480p, where the
+    dilation took ~0.1 s per map and made the boundary measure the cost of every dataset evaluation (of needs at least one pixel)."""
+    ys, xs = np.flatnonzero(of.any(1)), np.flatnonzero(of.any(0))
+    y0, y1 = max(int(ys[0]) - r, 0), min(int(ys[-1]) + r + 1, of.shape[0])         # nothing outside the bounding box of `of` grown by r can match
+    x0, x1 = max(int(xs[0]) - r, 0), min(int(xs[-1]) + r + 1, of.shape[1])
+    d = ndimage.distance_transform_edt(~of[y0:y1, x0:x1])   # sqrt of the exact integer squared distance: d <= r  <=>  dy^2 + dx^2 <= r^2
+    out = np.zeros_like(points)
+    out[y0:y1, x0:x1] = points[y0:y1, x0:x1] & (d <= r)
+    return out
+
+
 def db_eval_boundary(foreground_mask, gt_mask, bound_th=0.008):
     fg = np.asarray(foreground_mask).astype(bool)
     gt = np.asarray(gt_mask).astype(bool)
     bound_pix = bound_th if bound_th >= 1 else int(np.ceil(bound_th * np.linalg.norm(fg.shape)))
     fg_b, gt_b = seg2bmap(fg), seg2bmap(gt)
-    k = _disk(max(int(bound_pix), 1))
-    fg_d = ndimage.binary_dilation(fg_b, structure=k)
-    gt_d = ndimage.binary_dilation(gt_b, structure=k)
-    gt_match, fg_match = gt_b & fg_d, fg_b & gt_d
+    r = max(int(bound_pix), 1)
     n_fg, n_gt = fg_b.sum(), gt_b.sum()
     if n_fg == 0 and n_gt > 0:
         precision, recall = 1.0, 0.0
@@ -64,6 +74,7 @@ def db_eval_boundary(foreground_mask, gt_mask, bound_th=0.008):
     elif n_fg == 0 and n_gt == 0:
         precision, recall = 1.0, 1.0
     else:
+        gt_match, fg_match = _within(gt_b, fg_b, r), _within(fg_b, gt_b, r)
         precision, recall = fg_match.sum() / float(n_fg), gt_match.sum() / float(n_gt)
     if precision + recall == 0:
         return 0.0

@@ -34,6 +34,10 @@ def main():
     fx = np.load(os.path.join(G, 'g14_jf_float32.npz'))
     specs = [tuple(int(v) for v in row) for row in fx['specs']]
     trk = _hip_tracker('resnet101', JF.refiner_for('resnet101'))
+    if os.environ.get('JF_PERTURB'):       # the HIP side of the noise-floor runs: stem weights scaled by (1 + K ulp), as oracle/make_golden_jf.py --perturb K
+        ext = trk.feature_extractor
+        ext.resnet.conv1.weight.data.mul_(1.0 + int(os.environ['JF_PERTURB']) * 2.0 ** -23)
+        ext.upload()
     if os.environ.get('JF_NO_WINDOWS'):
         trk.window_tracking = False
     if os.environ.get('JF_NO_WINOGRAD'):
@@ -61,7 +65,8 @@ def main():
            'diff_vs_f32_oracle': 100 * hip.mean() - 100 * ora.mean(), 'label_agreement': float(np.mean(agree)),
            'per_object_abs_diff_mean': 100 * float(np.abs(hip.mean(1) - ora.mean(1)).mean()),
            'per_object_abs_diff_max': 100 * float(np.abs(hip.mean(1) - ora.mean(1)).max()),
-           'per_object_signed_diff': [round(100 * float(v), 3) for v in (hip.mean(1) - ora.mean(1))]}
+           'per_object_signed_diff': [round(100 * float(v), 3) for v in (hip.mean(1) - ora.mean(1))],
+           'per_object_JF': [round(100 * float(v), 4) for v in hip.mean(1)]}
     for name in ('g14_jf_float32_t3.npz', 'g14_jf_float64.npz'):
         f = os.path.join(G, name)
         if os.path.exists(f):

@@ -24,6 +24,19 @@ for e in reversed(ends):
         t1 = e
         break
 t0 = t1 - int(ms * 1e6)
+if len(sys.argv) > 4 and sys.argv[4] == 'init':
+    # anchor on the LAST initialize(): the cluster of k_mask_stats launches that ends the trace's list of them; the sequence starts with the
+    # frame-0 trunk pass just before it (k_normalize_u8 within 4 ms) and lasts `ms`
+    ms_k = sorted(s for s, _, n, _ in tr if 'k_mask_stats' in n)
+    first = [s for s in ms_k if ms_k[-1] - s < 5e6][0]
+    nz = [s for s, _, n, _ in tr if 'k_normalize_u8' in n and 0 <= first - s < 4e6]
+    t0 = min(nz) if nz else first
+    # ... and ends with the last k_track_merge (or `ms` later when the run has none)
+    tm = [e for s, e, n, _ in tr if 'k_track_merge' in n and s > t0]
+    t1 = max(tm) if tm else t0 + int(ms * 1e6)
+    back = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0          # look this many ms before the anchor (early trunk passes)
+    t0 -= int(back * 1e6)
+    ms = (t1 - t0) / 1e6
 tr = sorted(x for x in tr if x[1] > t0 and x[0] < t1)
 
 
