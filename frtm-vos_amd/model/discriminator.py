@@ -510,6 +510,7 @@ class Discriminator(nn.Module):
     # the host's launch rate: initialize() takes 23.4 ms for 2 objects either way, and ~800-node graphs per target model are a
     # memory / driver burden for nothing.
     graph_init = False
+    persistent_first_fit = not __import__('os').environ.get('FRTM_NO_PERSISTENT_FIRST_FIT')
 
     def init(self, x, y):
         """x: (K,Cin,h,w) features of the augmented first frame; y: (K,1,H,W) masks (reference :154-199).
@@ -541,12 +542,17 @@ class Discriminator(nn.Module):
             g = torch.cuda.CUDAGraph()
             with H.capture(g):
                 opt = self._init_body(mem0, memory, None)
-            ent = self._ws['init_graph'] = dict(key=key, graph=g, mem0=mem0, memory=memory, opt=opt, w1T=self._w1T)
+            ent = self._ws['init_graph'] = dict(key=key, graph=g, mem0=mem0, memory=memory, opt=opt, w1T=self._w1T,
+                                                persistent_first_fit=bool(opt.persistent and opt._persistent_launched))
         ent['graph'].replay()
         # host-side state as the eager path leaves it
         memory.current_size = K
         opt = ent['opt']
         opt._has_p = True
+        if ent.get('persistent_first_fit'):            # the replayed resident launches of the filter fit, as _run_persistent books them
+            opt._persistent_launched = True
+            opt._launched.extend(int(v) for v in self.update_iters)
+            del opt._launched[:-64]
         opt.persistent = bool(self.persistent_cg) and not GaussNewtonCG.abort_seen_in_process
         opt.reset_persistent_counts()
         self._w1T, self._w1T_key = ent['w1T'], (self.project.weight.data_ptr(), self.project.weight._version)
@@ -590,6 +596,9 @@ class Discriminator(nn.Module):
             memory.initialize_like(xp, mem0)
         else:
             memory.initialize(xp, y)
+        # (round 4) the filter fit on the fresh memory takes the resident form like every later re-solve (one launch instead of ~60); a launch
+        # that times out is found by recover_from_abort() on the next re-solve frame / at the end of the sequence and re-run there
+        o1.persistent = bool(self.persistent_cg) and self.persistent_first_fit and not GaussNewtonCG.abort_seen_in_process
         o1.rewind().run(self.update_iters)
         return o1
 

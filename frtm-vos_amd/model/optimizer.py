@@ -103,6 +103,9 @@ class GaussNewtonCG:
             need = int(H.lib().frtm_joint_persistent_scratch(int(pr.mem.capacity), int(pr.Cin), int(pr.c), int(pr.h), int(pr.w)))
             if need > 0 and (getattr(self, '_jbuf', None) is None or self._jbuf[0].numel() < need):
                 self._jbuf = (torch.empty(need, device=dev), torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(288, dtype=torch.int32, device=dev))
+        elif hasattr(pr, 'persistent_args') and self._pbuf is None:      # the filter problem's resident form (its exchange slabs)
+            self._pbuf = (torch.empty(256 * 864, device=dev), torch.zeros(864 + 256, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
+                          torch.zeros(288, dtype=torch.int32, device=dev))
 
     @property
     def b(self):

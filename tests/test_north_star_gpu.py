@@ -341,19 +341,23 @@ def _dataset_jf(fixture, spec, name_fmt, perturb_ulps=(0,)):
     # J and F of 24 .. 77 objects x 40 frames on the host: a process pool (the boundary measure is ~10 ms per object and frame), fed while the
     # GPU tracks the next sequence
     with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2))) as ex:
+        seqs = []                    # rendered once, resident on the GPU for all draws
+        for k, (n_frames, n_obj, seed) in enumerate(specs):
+            seqs.append(SyntheticSequence(name_fmt % k, n_frames, JF.SIZE, n_obj, seed=seed))
+            seqs[-1].preload(DEV)
         for di, ulps in enumerate(perturb_ulps):
             ext.resnet.conv1.weight.data.copy_(stem * (1.0 + int(ulps) * 2.0 ** -23))
             ext.upload()
             for k, (n_frames, n_obj, seed) in enumerate(specs):
-                seq = SyntheticSequence(name_fmt % k, n_frames, JF.SIZE, n_obj, seed=seed)
+                seq = seqs[k]
                 trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
-                seq.preload(DEV)
                 labels, _ = trk.run_sequence(seq)
-                seq.release()
                 lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
                 futs[(di, k)] = ex.submit(_jf_job, (k, name_fmt % k, lab, n_frames, n_obj, seed))
                 if di == 0:
                     agree.append(float((lab[1:] == fx['labels_%d' % k][1:]).mean()))
+        for seq in seqs:
+            seq.release()
         res = {key: np.array(f.result()[1]) for key, f in futs.items()}
     ext.resnet.conv1.weight.data.copy_(stem)
     ext.upload()
