@@ -111,7 +111,8 @@ static int ensure(frtm_backbone* bb, float** p, size_t* have, size_t need) {
 static int scanned_tile(const ConvL& c, int B, int Ho, int Wo) {
   const long ntiles = ((long)B * Ho * Wo + 63) / 64;
   if (ntiles < 64 || ntiles > 130 || c.Cin != 256) return 0;
-  if ((c.ks == 3 && c.stride == 1 && c.Cout == 256) || (c.ks == 1 && c.stride == 1 && c.Cout == 1024)) return FRTM_TILE_G32_64x64;
+  if (c.ks == 3 && c.stride == 1 && c.Cout == 256) return FRTM_TILE_G32_64x64;                            // (the batched products: tile counts are padded to 64)
+  if (c.ks == 1 && c.stride == 1 && c.Cout == 1024 && ((long)Ho * Wo) % 4 == 0) return FRTM_TILE_G32_64x64;  // (dwordx4 staging needs H*W % 4 == 0)
   return 0;
 }
 

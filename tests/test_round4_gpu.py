@@ -467,3 +467,25 @@ def test_per_conv_tile_plan_changes_launches_not_results():
         H.call_nostream('frtm_backbone_set_conv_plan', h, i, 0, 0)
     again = ext(img, layers)
     assert all(torch.equal(again[k], ref[k]) for k in layers)
+
+
+def test_scanned_tile_exception_respects_the_kernel_preconditions():
+    """The planner's scanned exception (backbone.hip: scanned_tile -- the 32x32x2-MFMA GEMM kernel for the dominant layer3 GEMMs at 64..130
+    column tiles) must only be taken where that kernel can run: a 272 x 496 frame has 17 x 31 = 527 pixels at stride 16 (not a multiple of
+    4: no dwordx4 staging), and 10 frames put the 1x1 convs into the exception's range.  The batched pass equals the frame-by-frame passes."""
+    from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
+    torch.manual_seed(5)
+    ext = ResnetFeatureExtractor('resnet101').to(DEV)
+    img = torch.randint(0, 256, (10, 3, 272, 496), dtype=torch.uint8, device=DEV)
+    layers = ['layer4', 'layer5']
+    batched = {k: v.clone() for k, v in ext(img, layers).items()}
+    for b in (0, 9):
+        one = ext(img[b:b + 1], layers)
+        for k in layers:
+            scale = float(one[k].abs().max())
+            assert float((batched[k][b:b + 1] - one[k]).abs().max()) <= 3e-5 * scale, (k, b)
+    img2 = torch.randint(0, 256, (5, 3, 480, 854), dtype=torch.uint8, device=DEV)      # 5 x 1620 / 64 = 127 column tiles: the exception applies
+    b5 = {k: v.clone() for k, v in ext(img2, layers).items()}
+    one = ext(img2[3:4], layers)
+    for k in layers:
+        assert float((b5[k][3:4] - one[k]).abs().max()) <= 3e-5 * float(one[k].abs().max()), k
