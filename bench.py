@@ -942,7 +942,7 @@ def main():
     wino4_share = round(form[2] / max(sum(form), 1.0), 4)
     wino6_share = round(form[3] / max(sum(form), 1.0), 4)
     sq_busy = None
-    for cand in ('r03_sq_busy.json', 'r02_sq_busy.json'):
+    for cand in ('r04_sq_busy.json', 'r03_sq_busy.json', 'r02_sq_busy.json'):
         sf = os.path.join(ROOT, 'profiles', cand)
         if os.path.exists(sf):
             try:
