@@ -381,26 +381,31 @@ def jf_vs_fixture(dev, draws=4):
     trk.augment = shift_flip_augment
     ext = trk.feature_extractor
     stem = ext.resnet.conv1.weight.data.clone()
-    futs = {}
+    # Tracking first, evaluation afterwards, in workers of a FORK SERVER: forking this process while it drives the GPU (a ProcessPoolExecutor
+    # forks on demand, inside submit()) cost 170 ms per worker and slowed the tracking loop 15x (copy-on-write faults and the driver's
+    # notifiers on a 30 GB address space: 50 s instead of 3 s per dataset run, tools/jf_leg_timing.py).
+    import multiprocessing as mp
+    jobs = []
+    seqs = []                    # rendered once, resident on the GPU for all draws (1.6 GB)
+    for k, (n_frames, n_obj, seed) in enumerate(specs):
+        seqs.append(SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed))
+        seqs[-1].preload(dev)
     t0 = time.time()
-    with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2))) as ex:
-        seqs = []                    # rendered once, resident on the GPU for all draws (1.6 GB)
+    for di in range(max(1, int(draws))):
+        ext.resnet.conv1.weight.data.copy_(stem * (1.0 + di * 2.0 ** -23))
+        ext.upload()
         for k, (n_frames, n_obj, seed) in enumerate(specs):
-            seqs.append(SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed))
-            seqs[-1].preload(dev)
-        t0 = time.time()
-        for di in range(max(1, int(draws))):
-            ext.resnet.conv1.weight.data.copy_(stem * (1.0 + di * 2.0 ** -23))
-            ext.upload()
-            for k, (n_frames, n_obj, seed) in enumerate(specs):
-                seq = seqs[k]
-                trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
-                labels, _ = trk.run_sequence(seq)
-                futs[(di, k)] = ex.submit(_jf_eval_job, (k, torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy(), n_frames, n_obj, seed))
-        t_track = time.time() - t0
-        for seq in seqs:
-            seq.release()
-        res = {key: np.array(f.result()[1]) for key, f in futs.items()}
+            trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
+            labels, _ = trk.run_sequence(seqs[k])
+            jobs.append(((di, k), 'jg%02d' % k, torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy(), n_frames, n_obj, seed))
+    torch.cuda.synchronize()
+    t_track = time.time() - t0
+    for seq in seqs:
+        seq.release()
+    ext.resnet.conv1.weight.data.copy_(stem)
+    ext.upload()
+    with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2)), mp_context=mp.get_context('forkserver')) as ex:
+        res = {key: np.array(v) for key, v in ex.map(JF.jf_job, jobs)}
     hips = [np.concatenate([res[(di, k)] for k in range(len(specs))]).mean(1) * 100 for di in range(max(1, int(draws)))]
     hip = hips[0]
     ora = np.concatenate([fx['jf_%d' % k] for k in range(len(specs))]).mean(1) * 100
@@ -432,15 +437,6 @@ def jf_vs_fixture(dev, draws=4):
                    'means (one dataset-level run of either implementation is a random variable under ulp-level perturbations: a few objects under '
                    'mutual occlusion take one of two trajectories, in the reference arithmetic as well).'}
     return out
-
-
-def _jf_eval_job(args):
-    k, lab, n_frames, n_obj, seed = args
-    import oracle.make_golden_jf as JF
-    from frtm_vos_amd.lib.synthetic import SyntheticSequence
-    torch.set_num_threads(1)
-    seq = SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed)
-    return k, JF.jf_per_object(lab, seq)
 
 
 def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20, persistent=True):

@@ -77,6 +77,16 @@ def jf_per_object(labels, seq):
     return [(float(np.mean(J[o])), float(np.mean(F[o]))) for o in seq.obj_ids]
 
 
+def jf_job(args):
+    """Worker of the evaluation pools (tests/test_north_star_gpu.py, bench.py's cpu_baseline leg, tools/jf_g14.py): (key, sequence name, label
+    images (frames,H,W) uint8, frames, objects, seed) -> (key, [(J, F) per object]).  Lives here so that spawned / fork-server workers
+    import THIS module and nothing of the caller."""
+    key, name, lab, n_frames, n_obj, seed = args
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_num_threads(1)
+    return key, jf_per_object(lab, SyntheticSequence(name, n_frames, SIZE, n_obj, seed=seed))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--sequences', type=int, default=10)

@@ -337,42 +337,36 @@ def _dataset_jf(fixture, spec, name_fmt, perturb_ulps=(0,)):
     ext = trk.feature_extractor
     stem = ext.resnet.conv1.weight.data.clone()
     ora = [fx['jf_%d' % k] for k in range(len(specs))]
-    agree, futs = [], {}
-    # J and F of 24 .. 77 objects x 40 frames on the host: a process pool (the boundary measure is ~10 ms per object and frame), fed while the
-    # GPU tracks the next sequence
-    with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2))) as ex:
-        seqs = []                    # rendered once, resident on the GPU for all draws
+    agree, jobs = [], []
+    seqs = []                    # rendered once, resident on the GPU for all draws
+    for k, (n_frames, n_obj, seed) in enumerate(specs):
+        seqs.append(SyntheticSequence(name_fmt % k, n_frames, JF.SIZE, n_obj, seed=seed))
+        seqs[-1].preload(DEV)
+    for di, ulps in enumerate(perturb_ulps):
+        ext.resnet.conv1.weight.data.copy_(stem * (1.0 + int(ulps) * 2.0 ** -23))
+        ext.upload()
         for k, (n_frames, n_obj, seed) in enumerate(specs):
-            seqs.append(SyntheticSequence(name_fmt % k, n_frames, JF.SIZE, n_obj, seed=seed))
-            seqs[-1].preload(DEV)
-        for di, ulps in enumerate(perturb_ulps):
-            ext.resnet.conv1.weight.data.copy_(stem * (1.0 + int(ulps) * 2.0 ** -23))
-            ext.upload()
-            for k, (n_frames, n_obj, seed) in enumerate(specs):
-                seq = seqs[k]
-                trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
-                labels, _ = trk.run_sequence(seq)
-                lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
-                futs[(di, k)] = ex.submit(_jf_job, (k, name_fmt % k, lab, n_frames, n_obj, seed))
-                if di == 0:
-                    agree.append(float((lab[1:] == fx['labels_%d' % k][1:]).mean()))
-        for seq in seqs:
-            seq.release()
-        res = {key: np.array(f.result()[1]) for key, f in futs.items()}
+            trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
+            labels, _ = trk.run_sequence(seqs[k])
+            lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
+            jobs.append(((di, k), name_fmt % k, lab, n_frames, n_obj, seed))
+            if di == 0:
+                agree.append(float((lab[1:] == fx['labels_%d' % k][1:]).mean()))
+    torch.cuda.synchronize()
+    for seq in seqs:
+        seq.release()
     ext.resnet.conv1.weight.data.copy_(stem)
     ext.upload()
+    # J and F of 24 .. 77 objects x 40 frames per draw on the host: a process pool (the boundary measure is ~40 ms per object and frame) AFTER
+    # the GPU work and from a fork server -- forking this process while it drives the GPU slowed the tracking loop 15x (bench.py: jf_vs_fixture)
+    import multiprocessing as mp
+    with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2)), mp_context=mp.get_context('forkserver')) as ex:
+        res = {key: np.array(v) for key, v in ex.map(JF.jf_job, jobs)}
     hips = [np.concatenate([res[(di, k)] for k in range(len(specs))]) for di in range(len(perturb_ulps))]
     for k, (n_frames, n_obj, seed) in enumerate(specs):
         print('seq %2d (%d objects): J&F HIP %.2f  oracle %.2f  label agreement %.5f' %
               (k, n_obj, 100 * res[(0, k)].mean(), 100 * fx['jf_%d' % k].mean(), agree[k]), flush=True)
     return (hips if len(perturb_ulps) > 1 else hips[0]), np.concatenate(ora), float(np.mean(agree)), len(specs)
-
-
-def _jf_job(args):
-    k, name, lab, n_frames, n_obj, seed = args
-    from frtm_vos_amd.lib.synthetic import SyntheticSequence
-    torch.set_num_threads(1)
-    return k, JF.jf_per_object(lab, SyntheticSequence(name, n_frames, JF.SIZE, n_obj, seed=seed))
 
 
 def _other_run(fixture, n_seq):

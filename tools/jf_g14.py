@@ -15,15 +15,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def _eval(args):
-    k, lab, n_frames, n_obj, seed = args
-    import oracle.make_golden_jf as JF
-    from frtm_vos_amd.lib.synthetic import SyntheticSequence
-    torch.set_num_threads(1)
-    seq = SyntheticSequence('jg%02d' % k, n_frames, JF.SIZE, n_obj, seed=seed)
-    return k, JF.jf_per_object(lab, seq)
-
-
 def main():
     tag = sys.argv[1]
     import oracle.make_golden_jf as JF
@@ -55,9 +46,10 @@ def main():
         seq.release()
         lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
         agree.append(float((lab[1:] == fx['labels_%d' % k][1:]).mean()))
-        jobs.append((k, lab, n_frames, n_obj, seed))
-    with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
-        res = dict(ex.map(_eval, jobs))
+        jobs.append((k, 'jg%02d' % k, lab, n_frames, n_obj, seed))
+    import multiprocessing as mp
+    with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8), mp_context=mp.get_context('forkserver')) as ex:
+        res = dict(ex.map(JF.jf_job, jobs))
     hip = np.concatenate([np.array(res[k]) for k in range(len(specs))])
     ora = np.concatenate([fx['jf_%d' % k] for k in range(len(specs))])
     out = {'tag': tag, 'env': {k: v for k, v in os.environ.items() if k.startswith(('FRTM_', 'JF_'))}, 'objects': int(len(hip)),
