@@ -7,8 +7,10 @@
   (b) an fp64 ARBITER for the chaotic quantities: the oracle in float64 decides on which side of the fp32 rounding noise the HIP path
       sits -- |HIP - fp64| <= 1.5 x |fp32 oracle - fp64| for the update-problem filter (N = 80, full size), the joint first-frame fit
       (Cin = 1024, full schedule) and free-running masks.
-  (c) J&F at DATASET level: 12 synthetic sequences x 48 frames (24 objects) against the pre-recorded run of the CPU oracle
-      (oracle/make_golden_jf.py -> tests/golden/g12_jf_float32.npz): |dJ&F| <= 0.1 points.
+  (c) J&F at DATASET level: fixture G14 -- 32 synthetic sequences x 40 frames, 77 objects -- against the recorded runs of the CPU oracle
+      (oracle/make_golden_jf.py --spec v2 -> tests/golden/g14_jf_*.npz: float32 at four thread counts and with the stem weights moved by
+      1 / 3 ulp, float64): eight HIP dataset runs against them, |mean - mean| <= 0.1 points, strictly; every single run within the
+      single-run noise floor.  Round 3's 12-sequence fixture G12 stays as a second sample with an explicit secondary bound.
 """
 import copy
 import os
