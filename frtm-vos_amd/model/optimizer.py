@@ -47,6 +47,8 @@ class MinimizationProblem:
 
 class GaussNewtonCG:
 
+    debug_abort = False              # tests (class or instance): the next persistent launches time out at their first barrier
+
     def __init__(self, problem: MinimizationProblem, variable: TensorList, cg_eps=0.0, fletcher_reeves=True,
                  standard_alpha=True, direction_forget_factor=0, step_alpha=1.0):
         # Problems with explicit operators (the target model's: DiscriminatorLoss) run on the fused HIP kernels.  Any other
@@ -78,7 +80,6 @@ class GaussNewtonCG:
         self._committed_seen = 0
         self._shadow = None              # snapshot of the solver state around a chain-form run with a device-side guard
         self._aborts_handled = 0
-        self.debug_abort = False         # tests: the next persistent launches time out at their first barrier
 
     # ---- device state -------------------------------------------------------------------
     def _alloc(self):

@@ -489,3 +489,59 @@ def test_scanned_tile_exception_respects_the_kernel_preconditions():
     one = ext(img2[3:4], layers)
     for k in layers:
         assert float((b5[k][3:4] - one[k]).abs().max()) <= 3e-5 * float(one[k].abs().max()), k
+
+
+def test_first_filter_fit_takes_the_resident_form_and_an_abort_is_made_up():
+    """Round 4: the filter fit on the fresh memory at the end of Discriminator.init (reference discriminator.py:186-199) runs as ONE resident
+    launch like every later re-solve.  Same filter as the chain form up to summation order; with the launch aborted (debug_abort on the class:
+    every persistent launch gives up at its first barrier) the filter stays at the joint fit's result, recover_from_abort() re-runs exactly
+    that solve in the chain form and the target model ends where the chain form ends."""
+    from frtm_vos_amd.model.discriminator import Discriminator, DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    g = torch.Generator().manual_seed(11)
+    cin, c, h, w, Hh, Ww = 64, 16, 24, 40, 96, 160
+    x0 = torch.relu(torch.randn(5, cin, h, w, generator=g)).to(DEV)
+    y0 = torch.zeros(5, 1, Hh, Ww)
+    y0[:, 0, 20:60, 30:90] = 1
+    y0 = y0.to(DEV)
+
+    def make(first_fit):
+        torch.manual_seed(3)
+        # ONE CG step in the fit under test: the two forms then agree to rounding (a longer truncated CG run amplifies summation-order
+        # differences to the per-cent level on random problems -- test_persistent_cg_run_equals_the_multi_kernel_form measures that)
+        d = Discriminator(in_channels=cin, c_channels=c, init_iters=(2, 3), update_iters=(1,), memory_size=8, train_skipping=2,
+                          pixel_weighting=dict(method='hinge', tf=0.1), device=DEV, layer='layer4')
+        d.persistent_first_fit = first_fit
+        return d
+    saved = DiscriminatorLoss.persistent_joint
+    try:
+        DiscriminatorLoss.persistent_joint = False            # (the joint fit in the chain form: this test is about the fit that follows it)
+        GaussNewtonCG.abort_seen_in_process = False
+        ref = make(False)
+        ref.init(x0, y0)
+        res = make(True)
+        res.init(x0, y0)
+        torch.cuda.synchronize()
+        o = res.update_optimizer
+        assert o._persistent_launched and int(o._gstats[3]) == 1 and int(o._gstats[2]) == 0, 'the first fit did not take (or commit) the resident form'
+        fr, fp = ref.filter.weight.detach(), res.filter.weight.detach()
+        assert float((fr - fp).abs().max()) <= 1e-4 * float(fr.abs().max())
+        assert torch.equal(ref.project.weight, res.project.weight)
+        # aborted first fit
+        ab = make(True)
+        GaussNewtonCG.debug_abort = True
+        try:
+            ab.init(x0, y0)
+            torch.cuda.synchronize()
+        finally:
+            GaussNewtonCG.debug_abort = False
+        oa = ab.update_optimizer
+        assert int(oa._gstats[2]) == 1 and int(oa._gstats[3]) == 0
+        assert not torch.equal(ab.filter.weight, res.filter.weight)          # the fit is missing ...
+        assert ab.recover_from_abort() and ab.num_persistent_aborts == 1 and oa.persistent is False
+        fa = ab.filter.weight.detach()
+        assert float((fa - fr).abs().max()) <= 1e-4 * float(fr.abs().max())   # ... and made up in the chain form
+    finally:
+        DiscriminatorLoss.persistent_joint = saved
+        GaussNewtonCG.debug_abort = False
+        GaussNewtonCG.abort_seen_in_process = False
