@@ -108,10 +108,11 @@ static int ensure(frtm_backbone* bb, float** p, size_t* have, size_t need) {
 // than the run-to-run noise (+0.2 % for the whole scanned plan: the concurrent lane fills the tails that separate the tiles when a launch
 // is timed alone, profiles/r03_g32p_bench.txt); at the 4-5 frames per lane of the first-frame pass the 32x32x2-MFMA kernel is ahead on the
 // two dominant layer3 GEMMs (9.08 -> 8.92 ms per 9-frame pass).
-static int scanned_tile(const ConvL& c, int B, int Ho, int Wo) {
+// `products`: the launch is the batched GEMM of a three-launch Winograd form (the tile of a 3x3 conv's DIRECT form is never touched).
+static int scanned_tile(const ConvL& c, int B, int Ho, int Wo, bool products) {
   const long ntiles = ((long)B * Ho * Wo + 63) / 64;
   if (ntiles < 64 || ntiles > 130 || c.Cin != 256) return 0;
-  if (c.ks == 3 && c.stride == 1 && c.Cout == 256) return FRTM_TILE_G32_64x64;                            // (the batched products: tile counts are padded to 64)
+  if (products) return (c.ks == 3 && c.stride == 1 && c.Cout == 256) ? FRTM_TILE_G32_64x64 : 0;            // (tile counts are padded to 64)
   if (c.ks == 1 && c.stride == 1 && c.Cout == 1024 && ((long)Ho * Wo) % 4 == 0) return FRTM_TILE_G32_64x64;  // (dwordx4 staging needs H*W % 4 == 0)
   return 0;
 }
@@ -160,7 +161,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
       if (rc) return rc;
       d.w_layout = best_m == 6 ? FRTM_WLAYOUT_WINO6 : FRTM_WLAYOUT_WINO4;
       d.splitk = 1;
-      d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo);
+      d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo, true);
       d.ws_elems = (int)std::min<size_t>(ln.ws4_elems, 0x7fffffff);
       bb->last_flops_exec += 2.0 * c.Cout * (double)c.Cin * NP * (double)best_T;
       bb->last_flops_form[best_m == 6 ? 3 : 2] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * 9.0;
@@ -179,7 +180,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
   }
   bb->last_flops_exec += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
   bb->last_flops_form[0] += 2.0 * c.Cout * (double)B * (*Ho) * (*Wo) * c.Cin * c.ks * c.ks;
-  d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo);
+  d.tile = c.plan_tile ? c.plan_tile : scanned_tile(c, B, *Ho, *Wo, false);
   d.splitk = c.plan_splitk;
   return frtm_conv2d(&d, in, c.wT, c.ktab, c.scale, c.shift, residual, out, ln.ws, st);
 }

@@ -489,6 +489,14 @@ def test_scanned_tile_exception_respects_the_kernel_preconditions():
     one = ext(img2[3:4], layers)
     for k in layers:
         assert float((b5[k][3:4] - one[k]).abs().max()) <= 3e-5 * float(one[k].abs().max()), k
+    # ... and with the Winograd forms switched off the 3x3 convs of the same range take their DIRECT kernels (the exception is for the
+    # batched products only: `bench.py --no-winograd` died here before the planner told the two apart)
+    for w2, w4 in ((False, False), (True, False)):
+        ext.winograd, ext.winograd4 = w2, w4
+        d5 = ext(img2, layers)
+        for k in layers:
+            assert float((d5[k] - b5[k]).abs().max()) <= 5e-4 * float(b5[k].abs().max()), (k, w2, w4)
+    ext.winograd, ext.winograd4 = True, True
 
 
 def test_first_filter_fit_takes_the_resident_form_and_an_abort_is_made_up():
