@@ -29,13 +29,13 @@ print('  per object: max spread %.2f, mean spread %.2f' % ((per_obj.max(0) - per
 if 'float64' in runs:
     d = 100 * runs['float64'].mean(1) - per_obj.mean(0)
     print('float64 - mean float32 oracle: dataset %+.3f, per object median %+.3f, std %.2f' % (d.mean(), np.median(d), d.std()))
-hip = []
+groups = {}
 for f in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', 'jf_g14', 'ens_p*.json'))):
-    j = json.load(open(f))
-    hip.append(j['JF'])
-    print('%s  J&F %.3f  per-object median vs t4 %+.3f' % (os.path.basename(f), j['JF'], float(np.median(j['per_object_signed_diff']))))
-if hip:
+    tag = os.path.basename(f)[len('ens_pK'):-5] or '(earlier build)'
+    groups.setdefault(tag, []).append(json.load(open(f))['JF'])
+for tag, hip in groups.items():
     hip = np.array(hip)
-    print('HIP: %d draws, mean %.3f std %.3f range %.3f;  mean(HIP) - mean(oracle f32) = %+.3f' % (len(hip), hip.mean(), hip.std(ddof=1), hip.max() - hip.min(), hip.mean() - vals.mean()))
+    print('HIP %-16s %d draws: %s   mean %.3f std %.3f range %.3f;  mean(HIP) - mean(oracle f32) = %+.3f' %
+          (tag, len(hip), ' '.join('%.3f' % v for v in hip), hip.mean(), hip.std(ddof=1), hip.max() - hip.min(), hip.mean() - vals.mean()))
     if 'float64' in runs:
-        print('HIP mean - float64 = %+.3f; oracle f32 mean - float64 = %+.3f' % (hip.mean() - 100 * runs['float64'].mean(), vals.mean() - 100 * runs['float64'].mean()))
+        print('    HIP mean - float64 = %+.3f; oracle f32 mean - float64 = %+.3f' % (hip.mean() - 100 * runs['float64'].mean(), vals.mean() - 100 * runs['float64'].mean()))
