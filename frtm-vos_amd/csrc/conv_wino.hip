@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 
   const int nch = p.nchunks;
   gloadR(0, 0); gloadA(0, fa[0]);
-  if (1 < nch) { gloadR(1, 1); gloadA(1, fa[1]); }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) (expcnt / lgkmcnt untouched): patch 0 of this wave is in LDS
+  if (1 < nch) {
+    gloadR(1, 1); gloadA(1, fa[1]);
+    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);  // vmcnt(NR + 4): patch 0 of this wave is in LDS, the loads of chunk 1 stay in flight
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) (expcnt / lgkmcnt untouched)
+  }
   __syncthreads();
   auto chunk = [&](int k, auto S_) {
     constexpr int S = decltype(S_)::value;                  // k % 3
