@@ -170,34 +170,41 @@ __global__ __launch_bounds__(256) void k_cab_gate(const float* __restrict__ sp, 
 // 2x polyphase bicubic up-sampling, replicate border (seg_network.py:75-126): out = crop1(interleave(conv4x4(pad2(in)))).
 // The taps are the a = -0.75 cubic kernel at d = -0.25 (even phase) / d = -0.75 (odd phase):
 //   even: cubic(1.25), cubic(.25), cubic(.75), cubic(1.75) = -27/256, 225/256, 67/256, -9/256 ; odd: the reverse.
-// One thread produces a 2x2 output quad from the 5x5 input patch both phases share (25 loads for 4 outputs).
-__global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, int h, int w, float* __restrict__ out, size_t quads) {
+// One thread produces a COLUMN STRIP of PYR_Q vertically adjacent 2x2 output quads from the (PYR_Q + 4) x 5 input patch they share: 10 loads per
+// quad instead of 25 and the index arithmetic once per strip (the quad-per-thread form was bound by its loads: 103 us for 64 planes x 10 samples
+// of 120 x 214).  Same expressions per output as before (and as k_project_tail): results unchanged.
+#define PYR_Q 4
+__global__ __launch_bounds__(256) void k_pyrup2x(const float* __restrict__ in, int h, int w, float* __restrict__ out, size_t strips) {
   const float E[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};
   const int H = 2 * h, W = 2 * w;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) {
-    const int qx = (int)(i % w), qy = (int)((i / w) % h);
-    const size_t pl = i / ((size_t)w * h);
+  const int G = (h + PYR_Q - 1) / PYR_Q;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < strips; i += (size_t)gridDim.x * 256) {
+    const int qx = (int)(i % w), qg = (int)((i / w) % G);
+    const size_t pl = i / ((size_t)w * G);
+    const int qy0 = qg * PYR_Q;
     const float* p = in + pl * (size_t)h * w;
-    // output rows 2qy (odd phase at input row qy) and 2qy+1 (even phase at input row qy+1): input rows qy-2 .. qy+2
-    float v[5][5];
+    int cc[5];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int rr = min(max(qy + r - 2, 0), h - 1);
+    for (int c = 0; c < 5; ++c) cc[c] = min(max(qx + c - 2, 0), w - 1);
+    // horizontal pass of the strip's rows qy0-2 .. qy0+PYR_Q+1: column phase odd (taps reversed) uses cols 0..3, even phase uses cols 1..4
+    float hx[PYR_Q + 4][2];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) v[r][c] = p[(size_t)rr * w + min(max(qx + c - 2, 0), w - 1)];
+    for (int r = 0; r < PYR_Q + 4; ++r) {
+      const float* pr = p + (size_t)min(max(qy0 + r - 2, 0), h - 1) * w;
+      const float v0 = pr[cc[0]], v1 = pr[cc[1]], v2 = pr[cc[2]], v3 = pr[cc[3]], v4 = pr[cc[4]];
+      hx[r][0] = E[3] * v0 + E[2] * v1 + E[1] * v2 + E[0] * v3;
+      hx[r][1] = E[0] * v1 + E[1] * v2 + E[2] * v3 + E[3] * v4;
     }
-    // horizontal pass: column phase odd (taps reversed) uses cols 0..3, even phase uses cols 1..4
-    float hx[5][2];
+    float* o = out + pl * (size_t)H * W + (size_t)(2 * qy0) * W + 2 * qx;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      hx[r][0] = E[3] * v[r][0] + E[2] * v[r][1] + E[1] * v[r][2] + E[0] * v[r][3];
-      hx[r][1] = E[0] * v[r][1] + E[1] * v[r][2] + E[2] * v[r][3] + E[3] * v[r][4];
-    }
-    float* o = out + pl * (size_t)H * W + (size_t)(2 * qy) * W + 2 * qx;
+    for (int k = 0; k < PYR_Q; ++k) {
+      if (qy0 + k >= h) break;
+      // output rows 2qy (odd phase at input row qy) and 2qy+1 (even phase at input row qy+1): input rows qy-2 .. qy+2 = hx[k .. k+4]
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      o[c] = E[3] * hx[0][c] + E[2] * hx[1][c] + E[1] * hx[2][c] + E[0] * hx[3][c];
-      o[W + c] = E[0] * hx[1][c] + E[1] * hx[2][c] + E[2] * hx[3][c] + E[3] * hx[4][c];
+      for (int c = 0; c < 2; ++c) {
+        o[(size_t)(2 * k) * W + c] = E[3] * hx[k][c] + E[2] * hx[k + 1][c] + E[1] * hx[k + 2][c] + E[0] * hx[k + 3][c];
+        o[(size_t)(2 * k + 1) * W + c] = E[0] * hx[k + 1][c] + E[1] * hx[k + 2][c] + E[2] * hx[k + 3][c] + E[3] * hx[k + 4][c];
+      }
     }
   }
 }
@@ -433,8 +440,8 @@ int frtm_cab_gate(const float* sp, const float* dp, int dp_group, const float* W
 
 int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_stream_t stream) {
   FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0, "frtm_pyrup2x: bad argument");
-  const size_t quads = (size_t)planes * h * w;
-  k_pyrup2x<<<(int)min((quads + 255) / 256, (size_t)8192), 256, 0, (hipStream_t)stream>>>(in, h, w, out, quads);
+  const size_t strips = (size_t)planes * ((h + PYR_Q - 1) / PYR_Q) * w;
+  k_pyrup2x<<<(int)min((strips + 255) / 256, (size_t)16384), 256, 0, (hipStream_t)stream>>>(in, h, w, out, strips);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
