@@ -5,6 +5,6 @@ python - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/kt/**/k_kernel_stats.csv', recursive=True)
 for r in csv.DictReader(open(f[0])):
-    if any(t in r['Name'] for t in ('k_gemm_sk', 'k_conv', 'k_wino', 'k_joint', 'k_cg', 'k_fit', 'k_aug', 'k_fill')):
+    if any(t in r['Name'] for t in ('k_gemm_sk', 'k_conv', 'k_wino', 'k_joint', 'k_cg', 'k_fit', 'k_aug', 'k_fill', 'k_maxpool', 'k_normalize')):
         print('%-70s calls %5s avg %8.1f us' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
