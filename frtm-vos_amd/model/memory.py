@@ -184,7 +184,12 @@ class Memory:
         if cache is None:
             w = torch.full((K,), 1.0 / K, device=self.device)
             w[:1].fill_(2.0 / K)
-            cache = Memory._init_weights[(K, str(self.device))] = (w / w.sum()).contiguous()
+            cache = (w / w.sum()).contiguous()
+            # formed ONCE per process on whatever stream this object's fit runs on, read by every later fit on ITS stream: objects that start
+            # together are fitted on concurrent streams, and the second one must not read the table before these kernels have run (it did:
+            # non-finite filters for the second object whenever recycled device memory held something else than zeros)
+            torch.cuda.current_stream(cache.device).synchronize()
+            Memory._init_weights[(K, str(self.device))] = cache
         self.weights[:K].copy_(cache)
         lab, pw = self._build_normals(init_labels, pixel_weights, K, None, 0)
         if self.keep_hires:

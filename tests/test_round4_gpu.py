@@ -553,3 +553,37 @@ def test_first_filter_fit_takes_the_resident_form_and_an_abort_is_made_up():
         DiscriminatorLoss.persistent_joint = saved
         GaussNewtonCG.debug_abort = False
         GaussNewtonCG.abort_seen_in_process = False
+
+
+def test_initial_sample_weights_table_is_published_after_it_is_written():
+    """Regression (round 4): Memory.initialize keeps the initial sample weights (2, 1, ..., 1) / (K + 1) in a process-wide table that the first
+    fit forms on ITS stream.  Objects that start together are fitted on concurrent streams: the second fit used to read the table before the
+    first fit's kernels had written it -- garbage sample weights, non-finite filters for the second object whenever the recycled device memory
+    behind the table held something else than zeros (720p / 1080p: the chain-form fits run concurrently; the 480p resident fits run one
+    after the other).  Here stream A is kept busy before it forms the table and stream B reads it at once, over poisoned memory."""
+    from frtm_vos_amd.model.memory import Memory
+    K, cap, c, h, w, Hh, Ww = 5, 8, 16, 12, 20, 48, 80
+    Memory._init_weights.clear()
+    junk = [torch.full((n,), float('nan'), device=DEV) for n in (8, 16, 32, 64, 128) * 64]       # the small blocks the table will come from
+    torch.cuda.synchronize()
+    del junk
+    g = torch.Generator().manual_seed(1)
+    x = torch.relu(torch.randn(K, c, h, w, generator=g)).to(DEV)
+    y = torch.zeros(K, 1, Hh, Ww)
+    y[:, 0, 10:30, 20:60] = 1
+    y = y.to(DEV)
+    mems = [Memory(cap, (c, h, w), (1, Hh, Ww), DEV, 0.1, pixel_weighting=dict(method='hinge', tf=0.1)) for _ in range(2)]
+    big = torch.randn(6144, 6144, device=DEV)
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sA):
+        for _ in range(12):
+            big @ big                               # ~ 50 ms of work ahead of the table's kernels on stream A
+        mems[0].initialize(x, y)
+    with torch.cuda.stream(sB):
+        mems[1].initialize(x, y)
+    torch.cuda.synchronize()
+    want = torch.tensor([2.0, 1.0, 1.0, 1.0, 1.0]) / 6.0
+    for m in mems:
+        got = m.weights[:K].cpu()
+        assert bool(torch.isfinite(got).all()) and float((got - want).abs().max()) < 1e-6, got
