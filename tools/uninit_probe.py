@@ -18,8 +18,9 @@ del blocks
 from test_configs_gpu import _tracker  # noqa: E402
 from frtm_vos_amd.lib.synthetic import SyntheticSequence  # noqa: E402
 from frtm_vos_amd import ops as O_  # noqa: E402
-size = (720, 1280)
-seq = SyntheticSequence('c4', 14, size, 3, seed=6, late_object_at=5)
+size = tuple(int(v) for v in os.environ.get('PROBE_SIZE', '720x1280').split('x'))
+n_obj = int(os.environ.get('PROBE_OBJECTS', '3'))
+seq = SyntheticSequence('c4', int(os.environ.get('PROBE_FRAMES', '14')), size, n_obj, seed=int(os.environ.get('PROBE_SEED', '6')), late_object_at=5 if n_obj == 3 else None)
 seq.preload(DEV)
 
 
