@@ -535,7 +535,8 @@ class Discriminator(nn.Module):
             self.memory, self.update_optimizer = memory, opt
             return
         key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
-               tuple(self.filter_reg), tuple(self.precond), self.direction_forget_factor)
+               tuple(self.filter_reg), tuple(self.precond), self.direction_forget_factor,
+               bool(self.persistent_first_fit and self.persistent_cg and not GaussNewtonCG.abort_seen_in_process))    # (the captured form of the first filter fit)
         ent = self._ws.get('init_graph')
         if ent is None or ent['key'] != key or ent['mem0'] is not mem0 or ent['memory'] is not memory:
             self._init_problems(mem0, memory)                    # buffers of problems / solvers exist before the capture

@@ -634,6 +634,10 @@ class Tracker(nn.Module):
             b0 = 1 if share else 0
             for i, (target, im, msk) in enumerate(fresh):
                 k = im.shape[0] - 1 if share else im.shape[0]
+                # fits that share the GPU on concurrent streams keep their first filter fit in the chain form: resident launches of several
+                # objects next to each other starve one another's grids (measured with the resident joint form switched off and five
+                # objects: two of the first fits timed out and the process fell back to the chain form for good)
+                target.discriminator.persistent_first_fit = type(target.discriminator).persistent_first_fit and not lanes
                 def fit(target=target, msk=msk, b0=b0, k=k):
                     # (the gather of the shared sample runs on the stream of the fit that reads it)
                     feats = ({L: gather((ft_all[L][:1], ft_all[L][b0:b0 + k])) for L in layers} if share
