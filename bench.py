@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-streaming', action='store_true', help='skip the streaming leg (Tracker.track frame by frame: what an online caller gets)')
     ap.add_argument('--no-jf-fixture', action='store_true', help='skip the dataset-level J&F leg (fixture G14 tracked on the HIP path, ~40 s)')
+    ap.add_argument('--init-sweep-counts', default='1,2,5', help='object counts of the initialize() sweep')
     ap.add_argument('--jf-draws', type=int, default=4, help='dataset runs of the HIP path in the J&F leg (stem weights moved by 0 .. n-1 ulp; the gate in tests/ uses 8)')
     ap.add_argument('--no-cg-roofline', action='store_true', help='skip the CG roofline leg (profiling runs: the trace then ends with the timed region)')
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
@@ -1034,7 +1035,7 @@ def main():
             _phase('%s done' % name)
 
         def leg_init_sweep():
-            out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev)
+            out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev, counts=tuple(int(v) for v in args.init_sweep_counts.split(',')))
 
         def leg_dataset():
             # the headline above is ONE sequence; this is the dataset-level figure the reference's run_dataset prints (mean of the per-

@@ -510,6 +510,8 @@ class Discriminator(nn.Module):
     # the host's launch rate: initialize() takes 23.4 ms for 2 objects either way, and ~800-node graphs per target model are a
     # memory / driver burden for nothing.
     graph_init = False
+    graph_init_after = int(__import__('os').environ.get('FRTM_GRAPH_INIT_AFTER', '0'))     # uses of an instance that run eagerly before init() is captured
+    resident_joint = True        # the tracker clears it for objects whose first-frame fits share the GPU on concurrent streams (chain form there)
     persistent_first_fit = not __import__('os').environ.get('FRTM_NO_PERSISTENT_FIRST_FIT')
 
     def init(self, x, y):
@@ -528,7 +530,8 @@ class Discriminator(nn.Module):
         mem0 = self._memory('mem0', K, x.shape[-3:], y.shape[-3:], dev)
         mem0.initialize(x, y)
         memory = self._memory('memory', self.memory_size, (c,) + tuple(x.shape[-2:]), y.shape[-3:], dev)
-        if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing():
+        self._init_calls = getattr(self, '_init_calls', 0) + 1
+        if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing() or self._init_calls <= self.graph_init_after:
             opt = self._init_body(mem0, memory, None if not self.keep_hires else y)
             opt.persistent = bool(self.persistent_cg) and not GaussNewtonCG.abort_seen_in_process
             opt.reset_persistent_counts()
@@ -536,7 +539,8 @@ class Discriminator(nn.Module):
             return
         key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
                tuple(self.filter_reg), tuple(self.precond), self.direction_forget_factor,
-               bool(self.persistent_first_fit and self.persistent_cg and not GaussNewtonCG.abort_seen_in_process))    # (the captured form of the first filter fit)
+               bool(self.persistent_first_fit and self.persistent_cg and not GaussNewtonCG.abort_seen_in_process),     # (the captured form of the first filter fit
+               bool(self.resident_joint))                                                                              #  and of the joint fit)
         ent = self._ws.get('init_graph')
         if ent is None or ent['key'] != key or ent['mem0'] is not mem0 or ent['memory'] is not memory:
             self._init_problems(mem0, memory)                    # buffers of problems / solvers exist before the capture
@@ -561,6 +565,7 @@ class Discriminator(nn.Module):
 
     def _init_problems(self, mem0, memory):
         p0 = self._problem('mem0_problem', mem0, self.filter_reg, self.precond, True)
+        p0.persistent_joint = bool(DiscriminatorLoss.persistent_joint and self.resident_joint)      # (instance attribute: this object's form)
         p1 = self._problem('memory_problem', memory, self.filter_reg[1:], self.precond[1:], False)
         o0 = self._solver('mem0_solver', p0, TensorList([self.project.weight, self.filter.weight]))
         o1 = self._solver('memory_solver', p1, TensorList([self.filter.weight]))
@@ -660,7 +665,7 @@ class Discriminator(nn.Module):
         Such fits each want the whole chip: the tracker then enqueues the objects one after the other instead of on concurrent streams
         (two resident grids cannot be co-resident; measured with five objects on four streams: 51 ms instead of 40, and time-outs)."""
         from .optimizer import GaussNewtonCG
-        if not (DiscriminatorLoss.persistent_joint and GaussNewtonCG.persistent_joint):
+        if not (DiscriminatorLoss.persistent_joint and GaussNewtonCG.persistent_joint and self.resident_joint):
             return False
         return H.lib().frtm_joint_persistent_plan(int(K), int(self.project.in_channels), int(self.project.out_channels), int(h), int(w), None) > 0
 

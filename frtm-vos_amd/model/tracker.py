@@ -97,6 +97,8 @@ class Tracker(nn.Module):
         self.own_stream = True           # run_sequence moves off the framework's default (null) stream
         self.window_tracking = True      # track the frames between two filter re-solves as one batch (track_window)
         self.init_lanes = 4              # objects starting on the same frame are fitted on up to this many concurrent streams
+        # ... in the chain form when exactly this many start together (else: resident fits, one after the other); 0 = never
+        self.concurrent_chain_fits = int(os.environ.get('FRTM_CONCURRENT_CHAIN_FITS', '3'))
         self.share_first_sample = True   # the un-augmented frame (sample 0 of every object's stack) passes the trunk once per frame
         self.early_first_pass = True     # first tracking pass enqueued before initialize(): it runs under the host-bound augmentation
         # ... and initialize()'s own pass could run NEXT TO it on the trunk's second lane set (frtm_backbone_forward_at).  OFF: measured in
@@ -624,6 +626,14 @@ class Tracker(nn.Module):
             # they overlap on the GPU (reference :186-187 runs them one after the other)
             cur = torch.cuda.current_stream()
             lanes = self._init_streams(min(len(fresh), self.init_lanes)) if len(fresh) > 1 and self.init_lanes > 1 else []
+            # THREE objects starting together: their fits in the CHAIN form on three concurrent streams beat the resident fits one after the other
+            # (one fit's kernels run in the other fits' latency gaps): 342-346 -> 348-354 frames/s over 20 frames, alternating runs on one box.
+            # Two objects are faster resident (430-432 against 425-428), and so are one (9.9 against 10.7 ms per initialize()) and four or more
+            # (37.5 against 40.3 ms for five: four chain fits at once oversubscribe the GPU).  The stand-alone initialize() sweep ranks two
+            # objects the other way round (16.1 against 16.6 ms): in a sequence the fits share the GPU with the first tracking pass.
+            concurrent_chain = bool(lanes) and self.concurrent_chain_fits > 0 and len(fresh) == self.concurrent_chain_fits
+            for target, _, _ in fresh:
+                target.discriminator.resident_joint = not concurrent_chain
             if lanes:
                 # resident fits (one launch per Gauss-Newton iteration, all CUs each) go one after the other on this stream
                 fshape = (ft_all if share else ft)[fresh[0][0].disc_layer].shape

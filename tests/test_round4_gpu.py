@@ -587,3 +587,26 @@ def test_initial_sample_weights_table_is_published_after_it_is_written():
     for m in mems:
         got = m.weights[:K].cpu()
         assert bool(torch.isfinite(got).all()) and float((got - want).abs().max()) < 1e-6, got
+
+
+def test_three_objects_starting_together_are_fitted_in_the_chain_form_on_concurrent_streams():
+    """Tracker.initialize(): one, two, four objects -> resident joint fits one after the other; exactly three -> chain-form fits on three concurrent
+    streams (measured faster in a sequence).  Either way every target model ends finite, with a full first memory and the first filter fit done,
+    and the labels of a short sequence stay in range."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    trk = Parameters(None, device=DEV, feature_extractor='resnet50').get_model().eval()
+    assert trk.concurrent_chain_fits == 3
+    for n, want_resident in ((1, True), (2, True), (3, False), (4, True)):
+        seq = SyntheticSequence('p%d' % n, 6, (480, 854), n, seed=70 + n)
+        seq.preload(DEV)
+        out, _ = trk.run_sequence(seq)
+        torch.cuda.synchronize()
+        assert len(out) == 6 and set(int(v) for v in out[-1].unique().tolist()) <= set(range(n + 1))
+        for t in trk.targets.values():
+            d = t.discriminator
+            assert d.resident_joint is want_resident, (n, d.resident_joint)
+            assert bool(torch.isfinite(d.filter.weight).all()) and bool(torch.isfinite(d.project.weight).all())
+            assert d.memory.current_size >= 5
+            assert getattr(d._init_opt, '_joint_launched', False) == want_resident or not want_resident
