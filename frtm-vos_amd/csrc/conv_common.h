@@ -4,6 +4,7 @@
 #include "frtm_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a dwordx4 access at dword alignment
 
 struct ConvParams {
   const float* in; const float* wT; const int* ktab; const float* scale; const float* shift;

@@ -39,6 +39,10 @@ static const bool g_use_g32 = getenv("FRTM_USE_G32") && atoi(getenv("FRTM_USE_G3
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
+// MODE 2 (round 4): 1x1, stride 1, ANY Npix >= 4 (the 15x27 = 405-pixel maps of RN101's last stage at 480p): the same dwordx4 staging at
+//         dword alignment (buffer loads only force dword alignment).  A lane's four columns n .. n+3 of the flattened (image, pixel) axis
+//         either lie in one image row -- one dwordx4 -- or straddle the end of an image: those lanes (one per image boundary) take four
+//         dword loads, the wrapped columns from the next image.  Results are those of MODE 0 / 1 bit for bit (same k order per column).
 template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams p) {
   constexpr int BK = BKT;                                // chunk depth of this instantiation (32 or 64)
@@ -72,12 +76,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   const int acol = (tid % TA) * 4, arow = tid / TA;
   const unsigned a_off = (unsigned)(m0 + acol) * 4u;
   // ---- B geometry (fixed over the K loop) ----
-  unsigned b_base = OOB;        // byte offset of (img, ci=0, iy0, ix0)   [MODE 0] / (img, ci=0, pix) [MODE 1]
+  unsigned b_base = OOB;        // byte offset of (img, ci=0, iy0, ix0)   [MODE 0] / (img, ci=0, pix) [MODE 1, 2]
   int iy0 = 0, ix0 = 0, bcol, brow;
-  if (MODE == 1) {
+  int nfirst = 4;               // MODE 2: how many of this lane's four columns lie in its first image
+  if (MODE != 0) {
     bcol = (tid % TB4) * 4; brow = tid / TB4;
     const int n = n0 + bcol;
-    if (n < p.Ntot) { const int img = n / p.Npix; b_base = (unsigned)(img * p.Cin * HWin + (n - img * p.Npix)) * 4u; }
+    if (n < p.Ntot) {
+      const int img = n / p.Npix, rem = n - img * p.Npix;
+      b_base = (unsigned)(img * p.Cin * HWin + rem) * 4u;
+      if (MODE == 2) nfirst = min(4, p.Npix - rem);
+    }
   } else {
     bcol = tid % BN; brow = __builtin_amdgcn_readfirstlane(tid / BN);
     const int n = n0 + bcol;
@@ -88,10 +97,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       b_base = (unsigned)(img * p.Cin * HWin) * 4u + (unsigned)((iy0 * p.Win + ix0) * 4);
     } else { iy0 = -(1 << 20); }
   }
+  const unsigned wrap = (unsigned)((p.Cin - 1) * HWin) * 4u;      // MODE 2: column j >= nfirst sits at b_base + 4 j + wrap (next image, same channel)
 
   f32x4 ra[PA];
-  f32x4 rb4[MODE == 1 ? PB4 : 1];
-  float rb[MODE == 1 ? 1 : EB];
+  f32x4 rb4[MODE != 0 ? PB4 : 1];
+  float rb[MODE != 0 ? 1 : EB];
   auto gload = [&](int kc) {
     const int kb = kc * BK;
 #pragma unroll
@@ -101,6 +111,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       for (int i = 0; i < PB4; ++i) {
         const int k = kb + brow + i * RB4;
         rb4[i] = buf_ld4(rin, (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4));
+      }
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < PB4; ++i) {
+        const int k = kb + brow + i * RB4;
+        const unsigned o = (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4);
+        if (nfirst == 4) rb4[i] = buf_ld4(rin, o);
+        else {
+          // beyond the last image the wrapped offset lies behind the tensor: the bounds check returns 0 (those columns are never stored)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rb4[i][j] = buf_ld1(rin, o == OOB ? OOB : o + 4u * j + (j >= nfirst ? wrap : 0u));
+        }
       }
     } else {
 #pragma unroll
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) *(f32x4*)&As[buf][arow + i * RA][acol] = ra[i];
-    if (MODE == 1) {
+    if (MODE != 0) {
 #pragma unroll
       for (int i = 0; i < PB4; ++i) *(f32x4*)&Bs[buf][brow + i * RB4][bcol] = rb4[i];
     } else {
@@ -196,6 +218,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       if (p.residual) v += *(const f32x4*)&p.residual[o];
       if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       *(f32x4*)&dst[o] = v;
+    }
+  } else if (MODE == 2 && !p.out_transposed) {
+    // rows of 4 columns at dword alignment; the groups that straddle the end of an image (or of the tensor) go element by element
+    for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      const int mm = m0 + row, nn = n0 + c4;
+      if (mm >= p.M || nn >= p.Ntot) continue;
+      f32x4 v = *(const f32x4*)&Cs[row * LDC + c4];
+      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      if (rem + 4 <= p.Npix) {
+        if (raw) { *(f32x4u*)&dst[(size_t)mm * p.Ntot + nn] = v; continue; }
+        const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
+        if (p.scale) { const float a = p.scale[mm], b = p.shift[mm]; v = v * a + b; }
+        if (p.residual) v += *(const f32x4u*)&p.residual[o];
+        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *(f32x4u*)&dst[o] = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n1 = nn + j;
+          if (n1 >= p.Ntot) break;
+          if (raw) { dst[(size_t)mm * p.Ntot + n1] = v[j]; continue; }
+          const int im1 = n1 / p.Npix;
+          store_out(p, mm, im1, n1 - im1 * p.Npix, v[j]);
+        }
+      }
     }
   } else {
     for (int idx = tid; idx < BM * BN; idx += NT) {
@@ -413,6 +461,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 static inline bool halo_layout_requested(const frtm_conv_desc* d) { return d->w_layout == FRTM_WLAYOUT_HALO3X3; }
 
+template <int BM, int BN, int WGM, int WGN>
+static void launch_tile_u(const ConvParams& p, hipStream_t st) {
+  dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
+  k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
+}
+
 template <int BM, int BN, int WGM, int WGN, int BKT = 32>
 static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
@@ -586,6 +640,11 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");
   const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);
   if (is1x1) p.ktab = nullptr;
+  // round 4: stride-1 1x1 convs on maps whose pixel count is not a multiple of 4 (15x27 at 480p) keep the dwordx4 staging (MODE 2)
+  // instead of the dword gather; FRTM_NO_UVEC=1 restores the gather form (A/B; results are identical bit for bit)
+  static const bool no_uvec = getenv("FRTM_NO_UVEC") && atoi(getenv("FRTM_NO_UVEC"));
+  const bool uvec1x1 = is1x1 && d->stride == 1 && !vec1x1 && p.Npix >= 4 && d->w_layout != FRTM_WLAYOUT_HALO3X3 && !no_uvec &&
+                       (d->tile == 0 || d->tile == FRTM_TILE_64x64 || d->tile == FRTM_TILE_32x64 || d->tile == FRTM_TILE_64x64_8W);
   const bool halo = d->w_layout == FRTM_WLAYOUT_HALO3X3;
   int halo_tw = 8;
   if (halo) {
@@ -631,7 +690,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     if (d->tile == 0 && d->stride == 1 && p.M > 64 && p.M <= 80) tile = FRTM_TILE_80x64;
     frtm_conv_plan(p.M, ptiles * 64, p.nchunks * 2, 0, &tile, &splitk);
   } else {
-    frtm_conv_plan(p.M, p.Ntot, p.nchunks, vec1x1 ? 1 : 0, &tile, &splitk);
+    frtm_conv_plan(p.M, p.Ntot, p.nchunks, (vec1x1 || uvec1x1) ? 1 : 0, &tile, &splitk);
   }
   {  // never let the partial slabs outgrow the caller's workspace
     const size_t out_elems = (size_t)p.M * p.Ntot;
@@ -650,6 +709,13 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
       case FRTM_TILE_64x64: launch_halo<64, 2, 2>(p, halo_tw, st); break;
       case FRTM_TILE_32x64: launch_halo<32, 1, 4>(p, halo_tw, st); break;
       case FRTM_TILE_80x64: launch_halo<80, 1, 4>(p, halo_tw, st); break;
+      default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
+    }
+  } else if (uvec1x1) {
+    switch (tile) {
+      case FRTM_TILE_64x64: launch_tile_u<64, 64, 2, 2>(p, st); break;
+      case FRTM_TILE_32x64: launch_tile_u<32, 64, 1, 4>(p, st); break;
+      case FRTM_TILE_64x64_8W: launch_tile_u<64, 64, 2, 4>(p, st); break;
       default: frtm_set_error("frtm_conv2d: unknown tile %d", tile); return FRTM_ERR_ARG;
     }
   } else

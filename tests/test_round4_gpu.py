@@ -610,3 +610,53 @@ def test_three_objects_starting_together_are_fitted_in_the_chain_form_on_concurr
             assert bool(torch.isfinite(d.filter.weight).all()) and bool(torch.isfinite(d.project.weight).all())
             assert d.memory.current_size >= 5
             assert getattr(d._init_opt, '_joint_launched', False) == want_resident or not want_resident
+
+
+@pytest.mark.parametrize('shape', [
+    (8, 512, 2048, 15, 27),        # RN101 layer4 conv3 at 480p: 405 pixels per image (405 = 101 * 4 + 1), 8 frames
+    (8, 2048, 512, 15, 27),        # layer4 conv1: 64 chunks, few tiles (the planner may split K)
+    (1, 2048, 512, 15, 27),        # one frame (streaming)
+    (9, 1024, 256, 5, 9),          # 45 pixels: a 64-column tile spans two images
+    (3, 40, 72, 5, 7),             # ragged K (40) and Cout (72), 35 pixels
+    (7, 33, 64, 3, 3),             # 9 pixels: every other group of four straddles
+    (6, 16, 32, 1, 5),             # 5 pixels
+    (5, 8, 32, 1, 3),              # 3 pixels: below four, stays on the gather form
+])
+def test_1x1_conv_on_maps_whose_pixel_count_is_not_a_multiple_of_four(shape):
+    """k_conv_igemm MODE 2 (round 4): stride-1 1x1 convs keep the dwordx4 staging when H*W % 4 != 0 (the 15x27 maps of RN101's last stage
+    at 480p; reference model/feature_extractor.py:56-65 runs them through torch's conv).  Against a float64-accumulated reference, and
+    BIT-IDENTICAL to the gather form (MODE 0: same k order per output element) for every tile, epilogue variant and the split-K path."""
+    from frtm_vos_amd import ops
+    B, cin, cout, h, w = shape
+    for variant, (residual, scale, relu) in enumerate([(True, True, True), (False, False, False), (False, True, False)]):
+        x, wt, sc, sh, res, ref = _sk_case(B, cin, cout, h, w, 23 + variant, residual=residual, scale=scale, relu=relu)
+        wT, ktab, layout = ops.pack_weights(wt)
+        kw = dict(scale=sc, shift=sh, residual=res, relu=relu)
+        gather = ops.conv2d(x, wT, cout, tile=3, splitk=1, **kw)               # FRTM_TILE_128x64: not a MODE-2 tile -> gather form
+        assert float((gather.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+        for tile in (0, 1, 2, 4):
+            out = ops.conv2d(x, wT, cout, tile=tile, splitk=1, **kw)
+            assert torch.equal(out, gather), (shape, variant, tile, float((out - gather).abs().max()))
+        auto = ops.conv2d(x, wT, cout, **kw)                                   # the planner's tile and split-K
+        assert float((auto.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+        sk_g = ops.conv2d(x, wT, cout, tile=3, splitk=2, **kw)
+        sk_u = ops.conv2d(x, wT, cout, tile=4, splitk=2, **kw)
+        assert torch.equal(sk_u, sk_g), (shape, variant, 'split-K')
+        tr_g = ops.conv2d(x, wT, cout, tile=3, splitk=1, out_transposed=True, scale=sc, shift=sh, relu=relu)
+        tr_u = ops.conv2d(x, wT, cout, tile=4, splitk=1, out_transposed=True, scale=sc, shift=sh, relu=relu)
+        assert torch.equal(tr_u, tr_g), (shape, variant, 'transposed')
+
+
+def test_1x1_conv_at_the_very_end_of_an_allocation():
+    """MODE 2 reads four columns at a time: the wrapped columns of the LAST image lie behind the tensor and must come back as zeros from
+    the buffer bounds check, never as a fault or as data of a neighbouring allocation (poisoned here)."""
+    from frtm_vos_amd import ops
+    B, cin, cout, h, w = 4, 64, 64, 15, 27
+    x, wt, sc, sh, res, ref = _sk_case(B, cin, cout, h, w, 5)
+    pool = torch.full((x.numel() + 4096,), float('nan'), device=DEV)
+    xs = pool[:x.numel()].view_as(x)
+    xs.copy_(x)
+    wT, ktab, layout = ops.pack_weights(wt)
+    out = ops.conv2d(xs, wT, cout, scale=sc, shift=sh, residual=res, relu=True)
+    assert bool(torch.isfinite(out).all())
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 3e-6
