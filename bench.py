@@ -1013,6 +1013,7 @@ def main():
                     'host_enqueue_ms_per_sequence': [round(r_['enqueue_ms'], 2) for r_ in runs],
                     'mean_iou_vs_synthetic_gt': [None if r_['quality'] != r_['quality'] else round(r_['quality'], 4) for r_ in runs]},
         'host_cpus': ('%d-%d (%d logical CPUs on the NUMA node of the GPU)' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned',
+        'stream_placement': __import__('frtm_vos_amd.model.tracker', fromlist=['STREAM_PROBE']).STREAM_PROBE,
         'valid': bool(ok.item() > 0),
     }
     if shard is not None:

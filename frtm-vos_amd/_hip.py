@@ -74,6 +74,8 @@ SIGNATURES = {
     'frtm_backbone_last_flops_executed': (D, [P]),
     'frtm_backbone_last_flops_form': (D, [P, I]),
     'frtm_backbone_last_conv_launches': (I, [P]),
+    'frtm_backbone_lane_stream': (P, [P, I]),
+    'frtm_spin': (I, [I, P]),
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),
     'frtm_backbone_set_winograd': (I, [P, I]),

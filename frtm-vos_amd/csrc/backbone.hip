@@ -4,6 +4,8 @@
 // buffers stay resident in HBM (288 GB: nothing is ever freed or re-packed per frame).
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
 
@@ -188,6 +190,13 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
 // One sub-batch through the trunk on one stream (reference feature_extractor.py:40-68).
 // Largest activation of one image anywhere in the pass, in elements (stem output, or a stage output when the frame size is
 // odd: 256 x ceil(H/4) x ceil(W/4) can exceed 64 x ceil(H/2) x ceil(W/2)).
+// One wave that keeps its queue slot busy for a given time (constant 100 MHz counter): the stream-independence probe of the tracker
+// (model/tracker.py: _streams_are_independent) -- two streams that the runtime mapped onto ONE hardware queue execute in order.
+__global__ void k_spin(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {
   const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
   size_t need = (size_t)64 * Hs * Ws;
@@ -421,6 +430,19 @@ int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
   return FRTM_OK;
 }
 
+// Stream of lane `lane` (0 .. 2 * lanes - 1; lanes of set 1 follow those of set 0); NULL for lane 0 of set 0 (it runs on the caller's stream)
+void* frtm_backbone_lane_stream(frtm_backbone_t* bb, int lane) {
+  if (!bb || lane <= 0 || lane >= (int)bb->lanes.size()) return nullptr;
+  return (void*)bb->lanes[lane].stream;
+}
+
+int frtm_spin(int microseconds, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "frtm_spin: 0..100000 us");
+  k_spin<<<1, 64, 0, (hipStream_t)stream>>>((long long)microseconds * 100);      // wall_clock64 ticks at 100 MHz
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
 int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                           const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
                           int stop_after_layer, frtm_stream_t stream) {
@@ -461,6 +483,8 @@ int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned c
   float* taps[5] = {layer1, layer2, layer3, layer4, layer5};
   if (L > 1) FRTM_HIP(hipEventRecord(fork, st));
   int b0 = 0;
+  static const bool trace_enqueue = getenv("FRTM_TRUNK_TIMING") && atoi(getenv("FRTM_TRUNK_TIMING"));
+  const auto tq0 = std::chrono::steady_clock::now();
   for (int l = 0; l < L; ++l) {
     Lane& ln = bb->lanes[lbase + l];
     const int Bl = B / L + (l < B % L ? 1 : 0);
@@ -476,6 +500,9 @@ int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned c
     }
     if (l > 0) FRTM_HIP(hipEventRecord(ln.done, ls));
     b0 += Bl;
+    if (trace_enqueue)
+      fprintf(stderr, "[frtm trunk] B=%d lane %d (%d frames) enqueued %.0f us after the call began\n", B, l, Bl,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
   }
   for (int l = 1; l < L; ++l) FRTM_HIP(hipStreamWaitEvent(st, bb->lanes[lbase + l].done, 0));
   return FRTM_OK;

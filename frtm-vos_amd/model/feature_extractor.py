@@ -259,6 +259,18 @@ class ResnetFeatureExtractor:
                        H.ptr(scale), H.ptr(shift))
             torch.cuda.current_stream().synchronize()      # the temporaries above die with this scope
 
+    def lane_streams(self):
+        """The native trunk's internal streams (lanes 1.. of set 0) as torch streams: a caller that runs other work NEXT TO a pass places
+        that work on streams that do not share a hardware queue with these (model/tracker.py: _independent_stream)."""
+        if self._handle is None:
+            return []
+        out = []
+        for l in range(1, self._lanes):
+            p = H.lib().frtm_backbone_lane_stream(self._handle, l)
+            if p:
+                out.append(torch.cuda.ExternalStream(int(p), device=self.device))
+        return out
+
     def __call__(self, input, output_layers=None, lane_set=0):
         """input: (B,3,H,W) or (3,H,W) uint8 -> dict of fp32 NCHW taps 'layer1'..'layer5' (reference :40-68).
         ``lane_set`` (0 / 1): which of the native trunk's two sets of lanes (arenas, scratch, streams) runs the pass; passes on different

@@ -50,6 +50,59 @@ def _process_stream(device, role):
     return _STREAMS[key]
 
 
+def _streams_are_independent(a, b, busy_us=400):
+    """Does work enqueued on stream ``b`` start while stream ``a`` is busy?  The HIP runtime maps the streams of a process onto a few hardware
+    queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that landed on the SAME queue execute in order, whatever their events say.
+    Measured in round 4 (tools/timeline_now.sh, per-queue strip chart): the tracker's main stream shared a queue with the stream of the
+    first tracking pass, so the first-frame augmentation -- a host-bound chain of small kernels that the early pass is there to cover --
+    waited for the whole pass and the GPU then idled through it (2 ms of a 46 ms sequence).  The probe: two dependent 0.4 ms spin
+    kernels on ``a``, a 1 us kernel + event on ``b``; independent streams complete the event within the launch latency."""
+    from time import perf_counter
+    L = H.lib()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        if L.frtm_spin(int(busy_us), a.cuda_stream) != 0:
+            return True
+    L.frtm_spin(1, b.cuda_stream)
+    ev = torch.cuda.Event()
+    ev.record(b)
+    t0 = perf_counter()
+    while not ev.query() and perf_counter() - t0 < 4e-6 * busy_us:
+        pass
+    dt = perf_counter() - t0
+    torch.cuda.synchronize()
+    return dt < 0.6e-6 * busy_us
+
+
+def _independent_stream(device, role, others, tries=6):
+    """The process-wide stream of ``role`` (see _process_stream), chosen at its first use among pool streams such that it shares its
+    hardware queue with none of ``others`` (streams that carry work at the same time).  Falls back to the first candidate when no
+    independent one turns up in ``tries``; FRTM_NO_STREAM_PROBE=1 takes the first candidate unprobed (the behaviour up to round 3)."""
+    key = (torch.device(device).index, role)
+    if os.environ.get('FRTM_PRIVATE_STREAMS') or key in _STREAMS:
+        return _process_stream(device, role)
+    if int(os.environ.get('FRTM_NO_STREAM_PROBE', '0') or 0):
+        STREAM_PROBE[role] = dict(probed=False, independent=False)
+        return _process_stream(device, role)              # (`others` is not even evaluated: stream creation order as up to round 3)
+    others = [o for o in (others() if callable(others) else others) if o is not None]
+    probe = bool(others) and not torch.cuda.is_current_stream_capturing()
+    first, found = None, False
+    with torch.cuda.device(torch.device(device)):
+        for _ in range(tries if probe else 1):
+            c = torch.cuda.Stream(device=device)
+            first = first if first is not None else c
+            if not probe or all(_streams_are_independent(o, c) for o in others):
+                _STREAMS[key], found = c, probe
+                break
+        else:
+            _STREAMS[key] = first
+    STREAM_PROBE[role] = dict(probed=probe, independent=found)
+    return _STREAMS[key]
+
+
+STREAM_PROBE = {}       # role -> {probed, independent}: what the placement found (bench.py reports it)
+
+
 class FrameTaps(dict):
     """Backbone taps of one frame ({layer: (1,C,H,W)}) that remember the trunk batch they are a slice of, so that consecutive
     frames can be handed on as one window without copying."""
@@ -159,8 +212,18 @@ class Tracker(nn.Module):
 
     def _first_pass_stream(self):
         if self._first_stream is None:
-            self._first_stream = _process_stream(self.device, 'first')
+            # next to it run: the stream that called (initialize()'s augmentation and fits) and the trunk's own lane streams
+            self._first_stream = _independent_stream(self.device, 'first', lambda: [torch.cuda.current_stream(self.device)] + self._trunk_lane_streams())
         return self._first_stream
+
+    def _trunk_lane_streams(self):
+        ext = self.feature_extractor
+        fn = getattr(ext, 'lane_streams', None)       # (a caller-supplied extractor need not have lanes)
+        if fn is None:
+            return []
+        if hasattr(ext, 'reuse_outputs'):             # the lane count run_sequence is about to set (the lane streams exist from then on)
+            ext.lanes = max(1, min(int(self.trunk_lanes), max(1, int(self.feature_batch))))
+        return list(fn())
 
     def _init_streams(self, n):
         while len(self._init_pool) < n:
@@ -240,7 +303,7 @@ class Tracker(nn.Module):
         if cur is None or cur != torch.cuda.default_stream(self.device) or not self.own_stream:
             return self._run_sequence(sequence, speedrun, ytvos_merge)
         if self._main_stream is None:
-            self._main_stream = _process_stream(self.device, 'main')
+            self._main_stream = _independent_stream(self.device, 'main', self._trunk_lane_streams)
         self._main_stream.wait_stream(cur)
         with torch.cuda.stream(self._main_stream):
             out = self._run_sequence(sequence, speedrun, ytvos_merge)

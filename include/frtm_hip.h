@@ -350,6 +350,13 @@ int frtm_backbone_forward(frtm_backbone_t* bb, const unsigned char* image_u8, in
 int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
                              const float* norm_bias3, float* layer1, float* layer2, float* layer3, float* layer4, float* layer5,
                              int stop_after_layer, frtm_stream_t stream);
+/* hipStream_t of lane `lane` of the trunk (1 .. 2 * lanes - 1: the lanes of set 1 follow those of set 0); NULL for lane 0, which runs on
+ * the caller's stream.  For the caller's stream placement (model/tracker.py: the first tracking pass of a sequence must not share a
+ * hardware queue with the stream that runs Tracker.initialize, reference tracker.py:165-191). */
+void* frtm_backbone_lane_stream(frtm_backbone_t* bb, int lane);
+/* One wave that occupies `stream` for `microseconds` (0..100000): the probe with which the tracker finds out whether two streams share a
+ * hardware queue (the runtime maps streams onto GPU_MAX_HW_QUEUES queues; streams of one queue run in order). */
+int frtm_spin(int microseconds, frtm_stream_t stream);
 /* FLOPs (2*MAC over all convs) of the last forward() call. */
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */

@@ -660,3 +660,36 @@ def test_1x1_conv_at_the_very_end_of_an_allocation():
     out = ops.conv2d(xs, wT, cout, scale=sc, shift=sh, residual=res, relu=True)
     assert bool(torch.isfinite(out).all())
     assert float((out.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+
+
+def test_stream_probe_and_placement_of_the_first_tracking_pass():
+    """The probe itself (a stream is never independent of ITSELF; two streams of which one was found independent of the other stay so), and
+    the placement it drives: after a sequence the tracker's main stream, the stream of the first tracking pass and the trunk's lane stream
+    are pairwise on different hardware queues (Tracker.initialize's augmentation, reference tracker.py:165-191, then runs UNDER the first
+    tracking pass instead of behind it)."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model import tracker as T_
+    torch.set_grad_enabled(False)
+    s = torch.cuda.Stream()
+    assert not T_._streams_are_independent(s, s)
+    trk = Parameters(None, device=DEV, feature_extractor='resnet50').get_model().eval()
+    seq = SyntheticSequence('probe', 6, (480, 854), 2, seed=3)
+    seq.preload(DEV)
+    out, _ = trk.run_sequence(seq)
+    torch.cuda.synchronize()
+    assert len(out) == 6
+    lanes = trk.feature_extractor.lane_streams()
+    assert len(lanes) == trk.feature_extractor.lanes - 1
+    if trk._main_stream is None or trk._first_stream is None:
+        pytest.skip('the tracker did not take its own streams in this configuration')
+    if int(os.environ.get('FRTM_NO_STREAM_PROBE', '0') or 0) or os.environ.get('FRTM_PRIVATE_STREAMS'):
+        pytest.skip('placement switched off')
+    # (in a process that has run other trackers the roles were placed at THEIR first use, against the lanes of the first extractor: the
+    # main / first pair is what every tracker of the process shares)
+    found = T_.STREAM_PROBE.get('first', {})
+    print('stream placement:', T_.STREAM_PROBE)
+    if not found.get('independent'):
+        pytest.skip('no independent candidate among the pool streams tried (a performance property of this process, not a result)')
+    assert T_._streams_are_independent(trk._main_stream, trk._first_stream)
+    assert T_._streams_are_independent(trk._first_stream, trk._main_stream)

@@ -93,3 +93,29 @@ for s, e, n, q in tr:
 for b in range(nb):
     tot = sum(busy[b].values())
     print('  %3d  x%.2f  %s' % (b, tot / 1e6, ' '.join('%s:%.2f' % (k, v / 1e6) for k, v in busy[b].most_common(5))), file=out)
+# per hardware queue: which kernel families it carried and when (streams beyond GPU_MAX_HW_QUEUES share a queue: a short chain enqueued
+# behind a whole trunk pass in the SAME queue waits for that pass however idle the GPU is)
+print('queues: id, kernels, first start ms, last end ms, families by time', file=out)
+byq = collections.defaultdict(list)
+for s, e, n, q in tr:
+    byq[q].append((s, e, n))
+for q, ks in sorted(byq.items(), key=lambda kv: kv[1][0][0]):
+    fams = collections.Counter()
+    for s, e, n in ks:
+        fams[fam(n)] += e - s
+    print('  q%-4s %5d  %7.2f  %7.2f  %s' % (q, len(ks), (min(s for s, _, _ in ks) - t0) / 1e6, (max(e for _, e, _ in ks) - t0) / 1e6,
+                                             ' '.join('%s:%.2f' % (k, v / 1e6) for k, v in fams.most_common(6))), file=out)
+aug = [(s, e, n, q) for s, e, n, q in tr if fam(n) in ('aug', 'k_mask_stats', 'k_pp_down', 'k_pp_up', 'k_blur2d', 'k_label_mask')]
+if aug:
+    print('first-frame augmentation kernels: %d on queues %s, first start %.2f ms, last end %.2f ms' %
+          (len(aug), sorted({q for *_, q in aug}), (aug[0][0] - t0) / 1e6, (max(e for _, e, _, _ in aug) - t0) / 1e6), file=out)
+print('strip chart per queue (busy ms per 1-ms row: queue=busy dominant family)', file=out)
+qb = collections.defaultdict(lambda: [collections.Counter() for _ in range(nb)])
+for s, e, n, q in tr:
+    s = max(s, t0)
+    b0, b1 = int((s - t0) / 1e6), int((e - t0) / 1e6)
+    for b in range(b0, min(b1, nb - 1) + 1):
+        lo, hi = t0 + b * 1e6, t0 + (b + 1) * 1e6
+        qb[q][b][fam(n)] += max(0, min(e, hi) - max(s, lo))
+for b in range(nb):
+    print('  %3d  %s' % (b, '   '.join('q%s=%.2f %s' % (q, sum(qb[q][b].values()) / 1e6, (qb[q][b].most_common(1) or [('-', 0)])[0][0]) for q in sorted(qb))), file=out)

@@ -27,5 +27,18 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / N
+if 'sync' in sys.argv[3:]:
+    # every pass from an IDLE GPU (as the first pass of a sequence starts): synchronise, then time one pass
+    import time
+    each = []
+    for _ in range(8):
+        torch.cuda.synchronize()
+        time.sleep(0.002)
+        e0.record()
+        ext(img)
+        e1.record()
+        torch.cuda.synchronize()
+        each.append(e0.elapsed_time(e1))
+    print('  passes from an idle GPU: ' + ' '.join('%.2f' % t for t in each) + ' ms (back to back: %.3f)' % ms)
 print('trunk pass B=%d lanes=%d graph=%d: %.3f ms, %.1f GFLOP, %.1f TFLOP/s, %d conv launches, %.1f us per conv launch' %
       (B, LANES, ext.use_graph, ms, ext.last_flops / 1e9, ext.last_flops / ms / 1e9, ext.last_conv_launches, 1e3 * ms / ext.last_conv_launches))
