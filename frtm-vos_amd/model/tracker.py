@@ -228,7 +228,9 @@ class Tracker(nn.Module):
     def _init_streams(self, n):
         while len(self._init_pool) < n:
             # (default priority: high-priority streams measured 2.4x SLOWER for these chains on MI355X / ROCm 7.2: 41 vs 17 ms)
-            self._init_pool.append(_process_stream(self.device, 'init%d' % len(self._init_pool)))
+            # each on a hardware queue of its own as far as the runtime's queues go: fits that share a queue run one after the other
+            prev = list(self._init_pool)
+            self._init_pool.append(_independent_stream(self.device, 'init%d' % len(self._init_pool), lambda: prev))
         return self._init_pool[:n]
 
     def clear(self):
