@@ -1001,6 +1001,10 @@ def main():
                      'pass_intervals_ms': [[round(ext.pass_events[0][0].elapsed_time(a), 3), round(ext.pass_events[0][0].elapsed_time(b), 3)]
                                            for a, b, _, _ in ext.pass_events] if ext.pass_events else []},
         'stage_ms_total': {k: round(v[0], 2) for k, v in tot.items()},
+        # event spans on the tracker's stream.  Since the streams are placed on hardware queues of their own (stream_placement below)
+        # initialize()'s augmentation RUNS UNDER the first tracking pass and its own trunk call then waits for that pass: 'initialize_total'
+        # spans the first tracking pass as well (what initialize() costs on its own is initialize_ms_by_objects)
+        'stage_ms_note': 'initialize_total overlaps the first tracking pass (trunk) when stream_placement.first.independent',
         'path_counters': counters,
         'mean_iou_vs_synthetic_gt': None if quality != quality else round(quality, 4),
         'device_mallocs_in_timed_region': mallocs,

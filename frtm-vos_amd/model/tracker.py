@@ -539,7 +539,7 @@ class Tracker(nn.Module):
         if pipelined:
             side = self._first_pass_stream()
         elif persistent and self.prefetch_stream and torch.cuda.is_available():
-            side = _process_stream(self.device, 'prefetch')
+            side = _independent_stream(self.device, 'prefetch', lambda: [torch.cuda.current_stream(self.device)] + self._trunk_lane_streams())
         # trunk batches [first, last) over the tracked frames 1..; pipelined: a short first batch (it has to be through the trunk
         # before initialize()'s own pass can start)
         n_tracked = len(frames) - 1
