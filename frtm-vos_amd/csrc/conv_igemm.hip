@@ -628,7 +628,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if (d->w_layout == FRTM_WLAYOUT_WINO3X3) {
     FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
                    "frtm_conv2d: the Winograd layout needs 3x3, stride 1, pad 1, NCHW output");
-    FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 3, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8)");
+    FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 5, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8; 4 / 5: 8x16 / 16x8 with 64 output channels per workgroup)");
     return frtm_wino_launch(p, d->tile, (hipStream_t)stream);
   }
   if (d->w_layout == FRTM_WLAYOUT_WINO4 || d->w_layout == FRTM_WLAYOUT_WINO6) {

@@ -693,3 +693,54 @@ def test_stream_probe_and_placement_of_the_first_tracking_pass():
         pytest.skip('no independent candidate among the pool streams tried (a performance property of this process, not a result)')
     assert T_._streams_are_independent(trk._main_stream, trk._first_stream)
     assert T_._streams_are_independent(trk._first_stream, trk._main_stream)
+
+
+@pytest.mark.parametrize('B,Cin,H,W,Cout', [(10, 64, 120, 214, 64),      # the refiner's level-2 convs (5 frames x 2 objects) / layer1
+                                             (2, 64, 30, 54, 64), (1, 8, 8, 8, 64), (1, 16, 9, 21, 64), (2, 24, 17, 16, 64),
+                                             (1, 65, 21, 37, 64),        # ragged last chunk of input channels
+                                             (1, 40, 33, 47, 128)])      # two 64-channel blocks
+def test_winograd_64_channel_blocks_equal_the_32_channel_form(B, Cin, H, W, Cout):
+    """k_conv3x3_wino64 (round 4: 64 output channels x 32 tiles per workgroup, single weight register set, reference convs
+    model/seg_network.py:176-189 and the trunk's layer1): BIT-IDENTICAL to k_conv3x3_wino<2, TALL, 3> (same summation order per output
+    element) for both block orientations and every epilogue variant, and within fp32 rounding of F.conv2d."""
+    import torch.nn.functional as F
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(B * Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    res = torch.randn(ref.shape, generator=g).to(DEV)
+    wT, ktab, lay = ops.pack_weights(w, wino=True)
+    for old, new in ((2, 4), (3, 5)):
+        a = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=old)
+        b = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=new)
+        assert torch.equal(a, b), (old, new, float((a - b).abs().max()))
+        assert float((b.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+        a2 = ops.conv2d(x, wT, Cout, 3, 1, 1, scale=scale, shift=shift, residual=res, relu=True, w_layout=lay, tile=old)
+        b2 = ops.conv2d(x, wT, Cout, 3, 1, 1, scale=scale, shift=shift, residual=res, relu=True, w_layout=lay, tile=new)
+        assert torch.equal(a2, b2), (old, new, 'epilogue')
+    auto = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay)
+    assert float((auto.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    # repeated under load from a second stream: the counted waits of the single weight register set must never let a stale fragment through
+    side = torch.cuda.Stream()
+    noise = torch.randn(32, 1 << 20, device=DEV)
+    first = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=4)
+    bad = 0
+    for it in range(20):
+        if it % 2 == 0:
+            with torch.cuda.stream(side):
+                noise.mul_(1.0000001)
+        bad += int(not torch.equal(ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=4), first))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
+def test_winograd_64_channel_blocks_refuse_other_channel_counts():
+    from frtm_vos_amd import ops
+    x = torch.randn(1, 16, 16, 16, device=DEV)
+    w = torch.randn(96, 16, 3, 3, device=DEV)
+    wT, ktab, lay = ops.pack_weights(w, wino=True)
+    with pytest.raises(RuntimeError, match='64'):
+        ops.conv2d(x, wT, 96, 3, 1, 1, w_layout=lay, tile=4)
