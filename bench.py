@@ -559,7 +559,7 @@ def run_dataset_shard(tracker, seqs, dev, prefetch=True):
     t0 = time.time()
     # (the reference's sequence.preload(device), tracker.py:91, inside the dataset loop -- here for the NEXT sequence on a copy stream while
     # this one is tracked, exactly as Tracker.run_dataset does it; --no-prefetch: one after the other)
-    for seq in SequencePrefetcher(seqs, dev, enabled=prefetch):
+    for seq in SequencePrefetcher(seqs, dev, enabled=prefetch, avoid=getattr(tracker, 'busy_streams', None)):
         out, f = tracker.run_sequence(seq)
         run_dataset_shard.enqueue_ms += 1e3 * getattr(tracker, 'last_enqueue_seconds', 0.0)
         c = path_counters(tracker, seq, len(out))

@@ -84,13 +84,17 @@ class SequencePrefetcher:
             tracker.run_sequence(sequence)
     """
 
-    def __init__(self, sequences, device, enabled=True):
+    def __init__(self, sequences, device, enabled=True, avoid=None):
+        """``avoid``: callable returning the streams that carry the tracking work (Tracker.busy_streams): the copy stream is then chosen so
+        that it shares a hardware queue with none of them (model/tracker.py: _independent_stream) -- a copy that sits in the queue of the
+        tracker's main stream holds up the kernels enqueued behind it."""
         d = torch.device(device)
         if d.type == 'cuda' and d.index is None:              # 'cuda' -> the current device, with its index (set_device / Stream need one)
             d = torch.device('cuda', torch.cuda.current_device())
         self.sequences, self.device = sequences, d
         self.enabled = bool(enabled) and self.device.type == 'cuda'
         self._stream = None
+        self._avoid = avoid
 
     def _start(self, seq):
         import threading
@@ -120,7 +124,12 @@ class SequencePrefetcher:
                         seq.release()
             return
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
+            import os
+            if self._avoid is not None and int(os.environ.get('FRTM_COPY_STREAM_PROBE', '1') or 0):
+                from ..model.tracker import _independent_stream
+                self._stream = _independent_stream(self.device, 'copy', self._avoid)
+            else:
+                self._stream = torch.cuda.Stream(device=self.device)
         it = iter(self.sequences)
         cur = next(it, None)
         pending = self._start(cur) if cur is not None else None

@@ -216,6 +216,17 @@ class Tracker(nn.Module):
             self._first_stream = _independent_stream(self.device, 'first', lambda: [torch.cuda.current_stream(self.device)] + self._trunk_lane_streams())
         return self._first_stream
 
+    def busy_streams(self):
+        """The streams a sequence's GPU work runs on (main, first tracking pass, the trunk's lanes): what a copy stream should keep off."""
+        if not torch.cuda.is_available() or torch.device(self.device).type != 'cuda':
+            return []
+        if self._main_stream is None and self.own_stream:
+            self._main_stream = _independent_stream(self.device, 'main', self._trunk_lane_streams)
+        main = self._main_stream if self._main_stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(main):
+            first = self._first_pass_stream()
+        return [main, first] + self._trunk_lane_streams()
+
     def _trunk_lane_streams(self):
         ext = self.feature_extractor
         fn = getattr(ext, 'lane_streams', None)       # (a caller-supplied extractor need not have lanes)
@@ -259,7 +270,7 @@ class Tracker(nn.Module):
                     restarted = True
                 yield sequence
         # sequence.preload(device) of the reference (:91) -- for the NEXT sequence, on a copy stream, while this one is tracked
-        for sequence in SequencePrefetcher(todo(), self.device, enabled=self.prefetch_sequences):
+        for sequence in SequencePrefetcher(todo(), self.device, enabled=self.prefetch_sequences, avoid=self.busy_streams):
             self.clear()
             outputs, seq_fps = self.run_sequence(sequence, speedrun)
             dset_fps.update(seq_fps)
