@@ -194,7 +194,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
 // (model/tracker.py: _streams_are_independent) -- two streams that the runtime mapped onto ONE hardware queue execute in order.
 __global__ void k_spin(long long ticks) {
   const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+  for (int it = 0; it < (1 << 20) && wall_clock64() - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(16);      // (bounded whatever the counter does)
 }
 
 static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {

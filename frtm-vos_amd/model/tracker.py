@@ -50,6 +50,9 @@ def _process_stream(device, role):
     return _STREAMS[key]
 
 
+STREAM_PROBE = {}       # role -> {probed, independent}: what the placement found (bench.py reports it)
+
+
 def _streams_are_independent(a, b, busy_us=400):
     """Does work enqueued on stream ``b`` start while stream ``a`` is busy?  The HIP runtime maps the streams of a process onto a few hardware
     queues (GPU_MAX_HW_QUEUES, 4 by default); two streams that landed on the SAME queue execute in order, whatever their events say.
@@ -90,17 +93,17 @@ def _independent_stream(device, role, others, tries=6):
     with torch.cuda.device(torch.device(device)):
         for _ in range(tries if probe else 1):
             c = torch.cuda.Stream(device=device)
+            if any(c == s_ for s_ in _STREAMS.values()):     # (the pool has wrapped around: this one already serves another role)
+                continue
             first = first if first is not None else c
             if not probe or all(_streams_are_independent(o, c) for o in others):
                 _STREAMS[key], found = c, probe
                 break
         else:
-            _STREAMS[key] = first
+            _STREAMS[key] = first if first is not None else torch.cuda.Stream(device=device)
     STREAM_PROBE[role] = dict(probed=probe, independent=found)
     return _STREAMS[key]
 
-
-STREAM_PROBE = {}       # role -> {probed, independent}: what the placement found (bench.py reports it)
 
 
 class FrameTaps(dict):

@@ -27,6 +27,12 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / N
+if 'queues' in sys.argv[3:]:
+    # which of the streams of this pass share a hardware queue (streams of one queue run in order: lanes on one queue do not overlap)
+    from frtm_vos_amd.model.tracker import _streams_are_independent
+    st = [torch.cuda.current_stream()] + ext.lane_streams()
+    print('  stream independence (caller, lane 1, ..): ' + ' '.join('%d-%d:%s' % (i, j, 'y' if _streams_are_independent(st[i], st[j]) else 'N')
+                                                                  for i in range(len(st)) for j in range(i + 1, len(st))))
 if 'sync' in sys.argv[3:]:
     # every pass from an IDLE GPU (as the first pass of a sequence starts): synchronise, then time one pass
     import time
