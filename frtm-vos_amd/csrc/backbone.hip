@@ -65,27 +65,27 @@ __global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __res
   }
 }
 
-// 3x3 stride-2 pad-1 max pool (feature_extractor.py:53)
-__global__ __launch_bounds__(256) void k_maxpool3s2(const float* __restrict__ in, int Hin, int Win, int Ho, int Wo, float* __restrict__ out,
-                                                     size_t total) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int ox = (int)(i % Wo);
-    const int oy = (int)((i / Wo) % Ho);
-    const size_t plane = i / ((size_t)Wo * Ho);
-    const float* ip = in + plane * (size_t)Hin * Win;
-    float m = -INFINITY;
+// 3x3 stride-2 pad-1 max pool (feature_extractor.py:53).  A 64 x 4 block of threads owns a 64-column x 4-row tile of one output plane
+// (no index divisions: the element-wise form spent its time in three 64-bit divisions per output, 1.4 TB/s); per input row one dword at
+// 2 ox - 1 and one 8-byte load at (2 ox, 2 ox + 1) -- dword-aligned (the stem's 427-column rows alternate), which global loads allow.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__global__ __launch_bounds__(256) void k_maxpool3s2(const float* __restrict__ in, int Hin, int Win, int Ho, int Wo, float* __restrict__ out) {
+  const int ox = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y;
+  if (ox >= Wo || oy >= Ho) return;
+  const float* ip = in + (size_t)blockIdx.z * Hin * Win;
+  const int x0 = ox * 2;                                    // columns x0 - 1, x0, x0 + 1
+  const bool left = x0 >= 1, pair = x0 + 1 < Win;           // (x0 < Win always: Wo = (Win - 1) / 2 + 1)
+  float m = -INFINITY;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = oy * 2 - 1 + dy;
-      if ((unsigned)yy >= (unsigned)Hin) continue;
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = ox * 2 - 1 + dx;
-        if ((unsigned)xx < (unsigned)Win) m = fmaxf(m, ip[(size_t)yy * Win + xx]);
-      }
-    }
-    out[i] = m;
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = oy * 2 - 1 + dy;
+    if ((unsigned)yy >= (unsigned)Hin) continue;
+    const float* row = ip + (size_t)yy * Win + x0;
+    if (pair) { const f32x2u v = *(const f32x2u*)row; m = fmaxf(m, fmaxf(v[0], v[1])); }
+    else m = fmaxf(m, row[0]);
+    if (left) m = fmaxf(m, row[-1]);
   }
+  out[((size_t)blockIdx.z * Ho + oy) * Wo + ox] = m;
 }
 
 static int add_conv(frtm_backbone* bb, int Cout, int Cin, int ks, int stride) {
@@ -232,8 +232,7 @@ static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_
   if (rc) return rc;
   const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
   float* x = layer1 ? layer1 : ln.buf[2];
-  const size_t np = (size_t)B * 64 * Hp * Wp;
-  k_maxpool3s2<<<(int)min((np + 255) / 256, (size_t)4096), 256, 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x, np);
+  k_maxpool3s2<<<dim3(ceil_div(Wp, 64), ceil_div(Hp, 4), B * 64), dim3(64, 4), 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x);
   FRTM_LAUNCH_CHECK();
   int ch = Hp, cw = Wp;
   float* taps[4] = {layer2, layer3, layer4, layer5};
