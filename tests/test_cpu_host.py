@@ -665,3 +665,53 @@ def test_aug_ref_properties():
     assert torch.equal(ims[1][:, known], im[:, known])
     assert torch.equal(labs[2][0, 17:38, 35:60], lb[0, 20:41, 30:55]) and int(labs[2].sum()) == int(lb.sum())      # shifted by (+5, -3)
     assert torch.equal(ims[2][:, 17:38, 35:60], im[:, 20:41, 30:55])
+
+
+def test_stream_placement_picks_the_first_independent_candidate(monkeypatch):
+    """model/tracker.py: _independent_stream -- host logic only (the probe and torch's stream pool are faked): candidates are drawn until one is
+    independent of every stream it is to run next to; none within `tries` -> the first candidate; FRTM_NO_STREAM_PROBE=1 -> no probing and the
+    `others` callable is not even evaluated (stream creation order as before); a role is placed once per process and device."""
+    import contextlib
+    from frtm_vos_amd.model import tracker as T_
+
+    class FakeStream:
+        n = 0
+
+        def __init__(self, device=None):
+            FakeStream.n += 1
+            self.id = FakeStream.n
+
+    monkeypatch.setattr(T_.torch.cuda, 'Stream', FakeStream)
+    monkeypatch.setattr(T_.torch.cuda, 'is_current_stream_capturing', lambda: False)
+    monkeypatch.setattr(T_.torch.cuda, 'device', lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(T_, '_STREAMS', {})
+    monkeypatch.setattr(T_, 'STREAM_PROBE', {})
+    monkeypatch.delenv('FRTM_NO_STREAM_PROBE', raising=False)
+    monkeypatch.delenv('FRTM_PRIVATE_STREAMS', raising=False)
+    main = FakeStream()
+    probes = []
+
+    def fake_probe(a, b, busy_us=400):
+        probes.append((a.id, b.id))
+        return b.id % 3 == 0                       # every third pool stream sits on a queue of its own
+
+    monkeypatch.setattr(T_, '_streams_are_independent', fake_probe)
+    s = T_._independent_stream('cuda:0', 'first', lambda: [main])
+    assert s.id == 3 and T_.STREAM_PROBE['first'] == dict(probed=True, independent=True)
+    assert probes == [(main.id, 2), (main.id, 3)]
+    assert T_._independent_stream('cuda:0', 'first', lambda: 1 / 0) is s            # placed once; `others` not evaluated again
+    # nothing independent within the tries: the first candidate, reported as such
+    monkeypatch.setattr(T_, '_streams_are_independent', lambda a, b, busy_us=400: False)
+    t = T_._independent_stream('cuda:0', 'prefetch', [main], tries=4)
+    assert t.id == 4 and T_.STREAM_PROBE['prefetch'] == dict(probed=True, independent=False)
+    # nothing to run next to: no probe at all
+    u = T_._independent_stream('cuda:0', 'init0', lambda: [])
+    assert T_.STREAM_PROBE['init0'] == dict(probed=False, independent=False) and u.id == 8
+    # switched off: `others` must not be touched
+    monkeypatch.setenv('FRTM_NO_STREAM_PROBE', '1')
+    v = T_._independent_stream('cuda:0', 'copy', lambda: 1 / 0)
+    assert T_.STREAM_PROBE['copy'] == dict(probed=False, independent=False) and v is T_._STREAMS[(0, 'copy')]
+    monkeypatch.setenv('FRTM_NO_STREAM_PROBE', '0')                                 # '0' means ON (a string is not a flag)
+    monkeypatch.setattr(T_, '_streams_are_independent', lambda a, b, busy_us=400: True)
+    w = T_._independent_stream('cuda:0', 'init1', [u])
+    assert T_.STREAM_PROBE['init1'] == dict(probed=True, independent=True) and w is not u
