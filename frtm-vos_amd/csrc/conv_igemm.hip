@@ -29,6 +29,9 @@ int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, int m, hip
 int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, int m, hipStream_t st);
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
+// conv_stem.hip (end of round 4): the 7x7 / stride-2 / 3 -> 64 stem with its patch and weights in LDS
+bool frtm_stem_eligible(const ConvParams& p, int ksize, int tile, int splitk);
+int frtm_stem_launch(const ConvParams& p, hipStream_t st);
 // conv_gemm_sk.hip (round 4): persistent stream-K GEMM; plan returns 0 when the launch is not eligible (small, odd shapes, no scratch)
 int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems, bool forced);
 int frtm_sk_launch(const ConvParams& p, float* ws, size_t ws_elems, int G, hipStream_t st);
@@ -638,6 +641,10 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");
+  if (d->w_layout == FRTM_WLAYOUT_GEMM && d->w_pitch == 0 && frtm_stem_eligible(p, d->ksize, d->tile, d->splitk)) {
+    p.splitk = 1; p.chunks_per_split = p.nchunks;
+    return frtm_stem_launch(p, (hipStream_t)stream);       // the ResNet stem kernel (opt-in: FRTM_TILE_STEM or FRTM_STEM=1)
+  }
   const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);
   if (is1x1) p.ktab = nullptr;
   // round 4: stride-1 1x1 convs on maps whose pixel count is not a multiple of 4 (15x27 at 480p) keep the dwordx4 staging (MODE 2)

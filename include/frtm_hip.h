@@ -296,6 +296,7 @@ typedef struct {
 #define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
 #define FRTM_TILE_128x128_16W 9
 #define FRTM_TILE_80x64 10       /* halo (3x3) kernel only: 65..80 output channels in one M tile */
+#define FRTM_TILE_STEM 11        /* 7x7 / stride 2 / pad 3, 3 -> 64 channels only (csrc/conv_stem.hip): patch and weights in LDS; measured behind the generic form, opt-in */
 /* 1x1 / stride-1 convs on v_mfma_f32_32x32x2_f32 (csrc/conv_gemm32.hip; NCHW output, H*W % 4 == 0, no split-K): Cout x pixel tile */
 #define FRTM_TILE_G32_128x128 20 /* 4 waves of 64x64 */
 #define FRTM_TILE_G32_64x128 21  /* 4 waves of 32x64 */

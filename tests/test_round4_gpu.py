@@ -744,3 +744,30 @@ def test_winograd_64_channel_blocks_refuse_other_channel_counts():
     wT, ktab, lay = ops.pack_weights(w, wino=True)
     with pytest.raises(RuntimeError, match='64'):
         ops.conv2d(x, wT, 96, 3, 1, 1, w_layout=lay, tile=4)
+
+
+@pytest.mark.parametrize('B,H,W', [(8, 480, 854), (1, 480, 854), (2, 96, 128), (1, 75, 101), (3, 33, 47), (1, 720, 1280)])
+def test_stem_kernel_equals_the_gather_form_bit_for_bit(B, H, W):
+    """k_stem7x7 (7x7 / stride 2 / pad 3, 3 -> 64 channels: the ResNet stem, reference model/feature_extractor.py:46-50) against the generic
+    gather form of k_conv_igemm (opt-in kernel: measured behind that form, csrc/conv_stem.hip): same k order, same instruction, same epilogue -> equal bits;
+    and both against a float64 convolution.  Ragged blocks (240 x 427 outputs: 427 = 13 x 32 + 11), tiny and odd frames."""
+    import torch.nn.functional as F
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(B * H + W)
+    x = (torch.randn(B, 3, H, W, generator=g) * 1.2).to(DEV)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(DEV)
+    sc = (torch.rand(64, generator=g) + 0.5).to(DEV)
+    sh = torch.randn(64, generator=g).to(DEV)
+    wT, ktab, lay = ops.pack_weights(w)
+    assert lay == 0 and ktab is not None
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    for kw in (dict(), dict(scale=sc, shift=sh, relu=True)):
+        old = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=1, splitk=1, **kw)        # FRTM_TILE_64x64: the generic kernel
+        new = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=11, **kw)                 # FRTM_TILE_STEM: the stem kernel
+        assert torch.equal(old, new), float((old - new).abs().max())
+        r = ref if not kw else torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        assert float((new.double() - r).abs().max() / r.abs().max()) < 3e-6
+    res = torch.randn(ref.shape, generator=g).to(DEV)
+    old = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=1, splitk=1, scale=sc, shift=sh, residual=res, relu=True)
+    new = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=11, scale=sc, shift=sh, residual=res, relu=True)
+    assert torch.equal(old, new)
