@@ -691,8 +691,9 @@ def test_stream_probe_and_placement_of_the_first_tracking_pass():
     print('stream placement:', T_.STREAM_PROBE)
     if not found.get('independent'):
         pytest.skip('no independent candidate among the pool streams tried (a performance property of this process, not a result)')
-    assert T_._streams_are_independent(trk._main_stream, trk._first_stream)
-    assert T_._streams_are_independent(trk._first_stream, trk._main_stream)
+    # (the probe can only err towards "dependent" -- a host thread descheduled while it polls --, never towards "independent": retry)
+    assert any(T_._streams_are_independent(trk._main_stream, trk._first_stream) for _ in range(4))
+    assert any(T_._streams_are_independent(trk._first_stream, trk._main_stream) for _ in range(4))
 
 
 @pytest.mark.parametrize('B,Cin,H,W,Cout', [(10, 64, 120, 214, 64),      # the refiner's level-2 convs (5 frames x 2 objects) / layer1
