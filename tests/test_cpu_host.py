@@ -715,3 +715,27 @@ def test_stream_placement_picks_the_first_independent_candidate(monkeypatch):
     monkeypatch.setattr(T_, '_streams_are_independent', lambda a, b, busy_us=400: True)
     w = T_._independent_stream('cuda:0', 'init1', [u])
     assert T_.STREAM_PROBE['init1'] == dict(probed=True, independent=True) and w is not u
+
+
+def test_mode2_column_addressing_restated():
+    """The address arithmetic of k_conv_igemm MODE 2 (csrc/conv_igemm.hip), restated in numpy: a lane's four columns n .. n+3 of the flattened
+    (image, pixel) axis of a 1x1 conv live at b_base + 4j (+ wrap for the columns that belong to the next image), wrap = (Cin - 1) * HW words.
+    Checked against the plain NCHW index for every group of four, every k, shapes whose pixel count is not a multiple of four."""
+    rng = np.random.RandomState(0)
+    for B, Cin, HW in ((8, 5, 405), (3, 2, 35), (7, 3, 9), (6, 4, 5), (2, 7, 6)):
+        x = rng.randn(B, Cin, HW).astype(np.float32)
+        flat = x.reshape(-1)
+        ntot = B * HW
+        for n in range(0, ntot, 4):
+            img, rem = divmod(n, HW)
+            b_base = img * Cin * HW + rem
+            nfirst = min(4, HW - rem)
+            wrap = (Cin - 1) * HW
+            for k in range(Cin):
+                for j in range(4):
+                    if n + j >= ntot:
+                        assert b_base + k * HW + j + (wrap if j >= nfirst else 0) >= flat.size or j < nfirst      # behind the tensor: the bounds check returns 0
+                        continue
+                    off = b_base + k * HW + j + (wrap if j >= nfirst else 0)
+                    i2, r2 = divmod(n + j, HW)
+                    assert flat[off] == x[i2, k, r2], (B, Cin, HW, n, k, j)
