@@ -352,6 +352,35 @@ class DiscriminatorLoss(MinimizationProblem):
         return x / self.diag_M
 
 
+_START_WEIGHTS = {}     # (Cin, c, device, generator state before the draw) -> (project.weight, filter.weight, generator state after it)
+
+
+def _start_weights(cin, c, device):
+    """The weights the reference's ``Discriminator.__init__`` leaves in ``project`` / ``filter`` (model/discriminator.py:86-87 through
+    lib/utils.py:25-26): nn.Conv2d's default kaiming_uniform_(a=sqrt(5)) = U(+-1/sqrt(fan_in)), drawn ON THE HOST from the
+    process-global CPU generator, project first, then filter, and moved to ``device`` afterwards (:100).  The draw is repeated here with
+    the same modules on the same generator, so the generator ends up where the reference leaves it and the numbers are the reference's
+    bit for bit -- whatever state the caller seeded for the process's first target model, and the state right after ``manual_seed(0)``
+    for every later one (tracker.py:179-180 seeds it at the end of every object's turn and nothing on the path draws from it; fixture
+    G15 records this from the reference's own Tracker).
+    Draws are cached on the device by the generator state they start from: the fixed seed-0 draw is made and uploaded once per process,
+    later objects cost one state comparison and the generator is advanced by restoring the state recorded after the draw."""
+    dev = torch.device('cpu' if device is None else device)
+    pre = torch.random.get_rng_state()
+    key = (int(cin), int(c), str(dev), pre.numpy().tobytes())
+    hit = _START_WEIGHTS.get(key)
+    if hit is None:
+        w1 = nn.Conv2d(cin, c, 1, bias=False).weight.detach()
+        w2 = nn.Conv2d(c, 1, 3, padding=1, bias=False).weight.detach()
+        hit = (w1.to(dev), w2.to(dev), torch.random.get_rng_state())
+        if len(_START_WEIGHTS) >= 8:
+            _START_WEIGHTS.pop(next(iter(_START_WEIGHTS)))
+        _START_WEIGHTS[key] = hit
+    else:
+        torch.random.set_rng_state(hit[2])
+    return hit[0], hit[1]
+
+
 class Discriminator(nn.Module):
 
     def __init__(self, in_channels=1024, c_channels=96, out_channels=1,
@@ -369,14 +398,14 @@ class Discriminator(nn.Module):
         self.keep_hires = keep_hires     # also store full-resolution labels / pixel weights (DiscriminatorLoss.__call__)
         if out_channels != 1:
             raise ValueError('the target model scores one channel (reference evaluate.py:78)')
-        # Layers of the reference (:86-87).  Their weights are drawn ON THE DEVICE from the distribution nn.Conv2d's default
-        # initialisation uses, kaiming_uniform_(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)): the reference draws them before
-        # it seeds anything (tracker.py:174-180), so there is no stream to reproduce, and a host-side draw would have to be
-        # uploaded (a blocking copy, or pinned staging) for every new object.
+        # Layers of the reference (:86-87) with the reference's START WEIGHTS (_start_weights below): nn.Conv2d's default initialisation
+        # drawn on the HOST from the process-global CPU generator, which the reference's Tracker.initialize re-seeds with 0 after every
+        # object (tracker.py:179-180) -- every target model but a process's first starts from one fixed draw (fixture G15).
         dev_ok = device is not None and torch.device(device).type == 'cuda'
         kw = dict(device=device) if dev_ok else {}
-        self.project = nn.Conv2d(in_channels, c_channels, 1, bias=False, **kw)
-        self.filter = nn.Conv2d(c_channels, out_channels, 3, padding=1, bias=False, **kw)
+        self.project = torch.nn.utils.skip_init(nn.Conv2d, in_channels, c_channels, 1, bias=False, **kw)
+        self.filter = torch.nn.utils.skip_init(nn.Conv2d, c_channels, out_channels, 3, padding=1, bias=False, **kw)
+        self._draw_start_weights()
         self.layer = layer
         self.init_iters = init_iters
         self.update_iters = update_iters
@@ -443,11 +472,15 @@ class Discriminator(nn.Module):
     def num_early_outs(self, v):
         self._early_outs_host = v - self._device_counts()[1]
 
+    def _draw_start_weights(self):
+        w1, w2 = _start_weights(self.project.in_channels, self.project.out_channels, self.project.weight.device)
+        self.project.weight.data.copy_(w1)
+        self.filter.weight.data.copy_(w2)
+
     def recycle(self):
         """Prepares this instance for a NEW object: fresh weights drawn like a newly constructed Discriminator, counters reset; the memories / problem buffers (~150 MB at 480p)
         stay allocated and are reused by the next init().  Nothing is freed or allocated on the device."""
-        self.project.reset_parameters()        # in place, on the device
-        self.filter.reset_parameters()
+        self._draw_start_weights()             # in place; a device-to-device copy when the generator state has been seen before
         self.frame_num = 0
         self._solves_host = 0
         self._early_outs_host = 0

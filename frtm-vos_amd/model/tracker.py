@@ -193,9 +193,11 @@ class Tracker(nn.Module):
         self.current_masks = None
         self.num_objects = 0
         self.targets = dict()
-        # Optional callable(obj_id) -> (project.weight, filter.weight): the weights a new target model STARTS from.  The reference
-        # draws them un-seeded when the object appears (tracker.py:174-180, before its "HACK for debugging" seeds anything), so two
-        # runs of the reference never start alike; reproducible runs and parity tests against a CPU run inject them here.
+        # Optional callable(obj_id) -> (project.weight, filter.weight): weights a new target model STARTS from INSTEAD of the default.
+        # The default is the reference's: drawn from the process-global CPU generator when the object appears, which initialize() seeds
+        # with 0 after every object like the reference does (tracker.py:174-180) -- so every target model but a process's first starts
+        # from one fixed draw (model/discriminator.py: _start_weights, fixture G15).  Parity tests that want DIFFERENT weights per
+        # object (fixtures G12 / G14) inject them here on both sides.
         self.start_weights = None
         self.frame_views = not os.environ.get('FRTM_NO_FRAME_VIEW')     # consecutive pre-loaded frames reach the trunk as a view (no gather)
         self.fuse_merge = not os.environ.get('FRTM_NO_FUSE_MERGE')    # sigmoid + merge + pixel counts + label decoding of a window as ONE kernel (ops.track_merge)

@@ -739,3 +739,46 @@ def test_mode2_column_addressing_restated():
                     off = b_base + k * HW + j + (wrap if j >= nfirst else 0)
                     i2, r2 = divmod(n + j, HW)
                     assert flat[off] == x[i2, k, r2], (B, Cin, HW, n, k, j)
+
+
+# ---------------------------------------------------------------------------------------------------------------- G15
+def _sha(t):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).digest(), dtype=np.uint8)
+
+
+def test_g15_default_start_weights_are_the_references(golden):
+    """The weights a target model starts its first-frame fit from, DEFAULT path (no injection): G15 was recorded from the reference's own
+    Tracker (oracle/make_golden_init_weights.py: five target models over two sequences, `project.weight` / `filter.weight` at the entry
+    of Discriminator.init).  The package's Discriminator, driven in the order Tracker.initialize drives it (construct -> seed 0,
+    reference tracker.py:174-180), must hold exactly those tensors: bit-identical, for a new instance and for a recycled one."""
+    from frtm_vos_amd.model import discriminator as D
+    G = golden('g15_init_weights')
+    for tag in ('small', 'full'):
+        cin, c = (int(v) for v in G[tag + '_dims'])
+        D._START_WEIGHTS.clear()
+        torch.manual_seed(int(G['user_seed']))              # the state the fixture's "caller" left the generator in
+        made = []
+        for k in range(len(G['order'])):
+            if k == 3:
+                d = made[0].recycle()                        # a pooled instance serving a new object (Tracker.release_targets)
+            else:
+                d = D.Discriminator(in_channels=cin, c_channels=c, device='cpu', layer='layer4')
+            w1, w2 = d.project.weight.detach().clone(), d.filter.weight.detach().clone()
+            torch.random.manual_seed(0)                      # Tracker.initialize, after the target model has been built
+            made.append(d)
+            assert w1.shape == (c, cin, 1, 1) and w2.shape == (1, c, 3, 3)
+            if tag == 'small':
+                assert np.array_equal(w1.numpy(), G['small_w1_%d' % k]) and np.array_equal(w2.numpy(), G['small_w2_%d' % k]), k
+            else:
+                assert np.array_equal(_sha(w1), G['full_w1_sha_%d' % k]) and np.array_equal(_sha(w2), G['full_w2_sha_%d' % k]), k
+                assert np.array_equal(w1.reshape(-1)[:64].numpy(), G['full_w1_head_%d' % k])
+        # one cached draw per generator state: the user-seeded one and the seed-0 one
+        assert len(D._START_WEIGHTS) == 2
+        # the generator is left where the reference leaves it: a cache hit advances it like the draw itself
+        torch.random.manual_seed(0)
+        D.Discriminator(in_channels=cin, c_channels=c, device='cpu')
+        after_hit = torch.random.get_rng_state()
+        torch.random.manual_seed(0)
+        torch.nn.Conv2d(cin, c, 1, bias=False), torch.nn.Conv2d(c, 1, 3, padding=1, bias=False)
+        assert torch.equal(after_hit, torch.random.get_rng_state())
