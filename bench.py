@@ -244,9 +244,9 @@ def cpu_baseline(args, size, seq_cpu, aug_stacks, n_frames, gpu_labels=None):
     start_w = []
     for k in range(n_obj):                                  # the draws of the GPU leg, repeated (same seeds, same order: project, filter)
         torch.manual_seed(4242 if k == 0 else 0)
-        pj = torch.nn.Conv2d(cin, 96, 1, bias=False, device='cuda:0')
-        fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False, device='cuda:0')
-        start_w.append((pj.weight.detach().cpu(), fl.weight.detach().cpu()))
+        pj = torch.nn.Conv2d(cin, 96, 1, bias=False)       # on the host, from the global CPU generator: the reference's draw (discriminator.py:86-87)
+        fl = torch.nn.Conv2d(96, 1, 3, padding=1, bias=False)
+        start_w.append((pj.weight.detach().clone(), fl.weight.detach().clone()))
     def leg(budget_s):
         """initialize() + tracked frames of the oracle; returns (labels, frames done, memory inserts, seconds)."""
         t0 = time.time()
@@ -822,8 +822,8 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        # target-model start weights are drawn on the device from torch's generator (the first object from this seed, every later one
-        # after initialize()'s manual_seed(0), reference tracker.py:174-180): seeded so that the CPU leg can start from the same weights
+        # target-model start weights are the reference's: drawn from torch's global CPU generator (the first object of the process from this
+        # seed, every later one after initialize()'s manual_seed(0), reference tracker.py:174-180; fixture G15): the CPU leg repeats them
         torch.manual_seed(4242 + rank)
         dev_allocs0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
         if args.debug_allocs:

@@ -24,8 +24,8 @@
 //   dots, and every workgroup forms F' = F_z + beta F locally afterwards: no fifth barrier.
 // 4 grid barriers (3 on the last iteration) per operator application, XCD-hierarchical as in cg_persistent.hip; same exchange protocol
 // (sc1 payloads, every storing wave drains, sc1 reads; polled words zeroed by memset nodes per launch; bounded spins).  A launch that
-// times out writes NOTHING back (every workgroup checks the launch's abort word behind a final barrier) and bumps the sticky abort
-// counter; the host then falls back to the chain form (model/optimizer.py).
+// times out writes NOTHING back (commit XOR abort: workgroup 0 claims the launch's abort word behind a final barrier, see grid_sync) and
+// bumps the sticky abort counter; the host then falls back to the chain form (model/optimizer.py).
 // Results: the same algorithm as the chain form; dot products and slab sums have another (fixed) summation order and the new direction's
 // composed kernel is formed as F_z + beta F instead of from p' itself: rounding-level differences, gated like the filter problem's
 // persistent form (tests/test_round4_gpu.py).
@@ -60,6 +60,19 @@ struct JParams {
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_l2(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The launch's abort word has three states, every transition a compare-and-swap from 0:
+//   0 running   1 ABORTED (a workgroup gave up waiting; counted once in stats[2]; nobody writes anything back)
+//   2 COMMITTED (workgroup 0 claimed it behind the final barrier: every workgroup has arrived there and every workgroup writes its slices)
+// COMMIT XOR ABORT: a workgroup whose spin runs out in the very barrier the others have just passed either wins the word
+// (-> 1: nobody writes, workgroup 0's claim fails) or finds it committed (-> it has been waited for, the barrier is complete: it passes and
+// writes like everybody else).  A launch is never both counted as aborted and partially written.
+__device__ __forceinline__ bool give_up_or_committed(unsigned* abort_flag, unsigned* stats) {
+  unsigned expected = 0u;
+  const bool won = __hip_atomic_compare_exchange_strong(abort_flag, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (won && stats) __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return !won && expected == 2u;        // true: committed meanwhile (only possible in the final barrier, which is then complete)
+}
+
 __device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_flag, unsigned* stats, unsigned target, long long limit, int* sh_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY wave drains its write-through stores before the workgroup is counted
   __syncthreads();
@@ -69,13 +82,8 @@ __device__ __forceinline__ bool grid_sync(unsigned* counter, unsigned* abort_fla
     int ok = 1;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-      if (wall_clock64() - t0 > limit) {
-        if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
-          __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
+      if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 0; break; }
+      if (wall_clock64() - t0 > limit) { ok = give_up_or_committed(abort_flag, stats) ? 1 : 0; break; }
     }
     *sh_flag = ok;
   }
@@ -92,24 +100,20 @@ __device__ __forceinline__ bool hier_sync(unsigned* hbar, unsigned* abort_flag, 
   if (threadIdx.x == 0) {
     int ok = 1;
     const long long t0 = wall_clock64();
-    auto give_up = [&]() {
-      if (__hip_atomic_exchange(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && stats)
-        __hip_atomic_fetch_add(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
     const unsigned old = __hip_atomic_fetch_add(hbar + HB_ARR + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1u == epoch * n_x) {
       __hip_atomic_fetch_add(hbar + HB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       while (__hip_atomic_load(hbar + HB_TOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * n_active) {
         __builtin_amdgcn_s_sleep(1);
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { ok = give_up_or_committed(abort_flag, stats) ? 1 : 0; break; }
       }
       if (ok) __hip_atomic_store(hbar + HB_GEN + 16 * xcc, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       while (__hip_atomic_load(hbar + HB_GEN + 16 * xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-        if (wall_clock64() - t0 > limit) { give_up(); ok = 0; break; }
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 0; break; }
+        if (wall_clock64() - t0 > limit) { ok = give_up_or_committed(abort_flag, stats) ? 1 : 0; break; }
       }
     }
     *sh_flag = ok;
@@ -498,9 +502,26 @@ __global__ __launch_bounds__(NT) void k_joint_run_persistent(const JParams P) {
     }
     __syncthreads();
   }
-  // ---- write back: every workgroup its owned slices, behind a final barrier, and only if the launch has not been aborted ----
+  // ---- write back: every workgroup its owned slices, behind a final barrier, and only if the launch COMMITS (protocol at grid_sync) ----
   if (!gsync()) return;
-  if (tid == 0) sh_flag_p[0] = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u ? 1 : 0;
+  if (tid == 0) {
+    unsigned st;
+    if (bid == 0) {
+      // the claim: 0 -> 2 (committed; stats[3] counts committed launches), or somebody gave up first (1)
+      unsigned expected = 0u;
+      const bool won = __hip_atomic_compare_exchange_strong(abort_flag, &expected, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      st = won ? 2u : expected;
+      if (won && P.stats) __hip_atomic_fetch_add(P.stats + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // wait for workgroup 0's decision (it is resident and a few instructions away) -- bounded like every other wait
+      const long long t0 = wall_clock64();
+      while ((st = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > P.spin_limit) { st = give_up_or_committed(abort_flag, P.stats) ? 2u : 1u; break; }
+      }
+    }
+    sh_flag_p[0] = st == 2u ? 1 : 0;
+  }
   __syncthreads();
   if (!sh_flag_p[0]) return;
   const size_t n = (size_t)n1 + c * 9;
@@ -520,7 +541,6 @@ __global__ __launch_bounds__(NT) void k_joint_run_persistent(const JParams P) {
     P.state[4] = rho_cur;
     P.state[1] = alpha;
     P.state[2] = beta_last;
-    if (P.stats) __hip_atomic_fetch_add(P.stats + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -562,6 +562,12 @@ class Discriminator(nn.Module):
         c = self.project.out_channels
         mem0 = self._memory('mem0', K, x.shape[-3:], y.shape[-3:], dev)
         mem0.initialize(x, y)
+        self._init_y = y if self.keep_hires else None
+        if self.resident_init(K, x.shape[-2], x.shape[-1]) or (self.persistent_first_fit and self.persistent_cg):
+            # a resident launch may time out on a shared GPU: refit_in_chain_form() restarts the fit from these
+            self._start_w = (self.project.weight.detach().clone(), self.filter.weight.detach().clone())
+        else:
+            self._start_w = None
         memory = self._memory('memory', self.memory_size, (c,) + tuple(x.shape[-2:]), y.shape[-3:], dev)
         self._init_calls = getattr(self, '_init_calls', 0) + 1
         if not self.graph_init or self.keep_hires or torch.cuda.is_current_stream_capturing() or self._init_calls <= self.graph_init_after:
@@ -573,15 +579,18 @@ class Discriminator(nn.Module):
         key = (K, tuple(x.shape), tuple(y.shape), str(dev), tuple(self.init_iters), tuple(self.update_iters),
                tuple(self.filter_reg), tuple(self.precond), self.direction_forget_factor,
                bool(self.persistent_first_fit and self.persistent_cg and not GaussNewtonCG.abort_seen_in_process),     # (the captured form of the first filter fit
-               bool(self.resident_joint))                                                                              #  and of the joint fit)
+               bool(self.resident_joint and DiscriminatorLoss.persistent_joint and GaussNewtonCG.persistent_joint))    #  and of the joint fit: the
+        #                                 process-wide switches are part of it -- a graph captured with resident launches must not be replayed after they timed out)
         ent = self._ws.get('init_graph')
         if ent is None or ent['key'] != key or ent['mem0'] is not mem0 or ent['memory'] is not memory:
             self._init_problems(mem0, memory)                    # buffers of problems / solvers exist before the capture
             g = torch.cuda.CUDAGraph()
             with H.capture(g):
                 opt = self._init_body(mem0, memory, None)
+            booked = bool(opt.persistent and opt._persistent_launched)
+            del opt._launched[:]                         # the capture booked the launches it RECORDED; the replays below book the ones that run
             ent = self._ws['init_graph'] = dict(key=key, graph=g, mem0=mem0, memory=memory, opt=opt, w1T=self._w1T,
-                                                persistent_first_fit=bool(opt.persistent and opt._persistent_launched))
+                                                persistent_first_fit=booked)
         ent['graph'].replay()
         # host-side state as the eager path leaves it
         memory.current_size = K
@@ -703,16 +712,42 @@ class Discriminator(nn.Module):
         return H.lib().frtm_joint_persistent_plan(int(K), int(self.project.in_channels), int(self.project.out_channels), int(h), int(w), None) > 0
 
     def init_aborted(self):
-        """True if a resident launch of the first-frame fit (csrc/joint_persistent.hip) timed out since the last call: that Gauss-Newton
-        iteration is MISSING from this target model.  SYNCHRONISES (4 bytes); the tracker asks after the final synchronise of a sequence and
-        then re-runs the sequence with the chain form (the resident form is switched off for the process)."""
+        """True if a resident launch of the first-frame fit timed out since the last call -- a Gauss-Newton iteration of the joint fit
+        (csrc/joint_persistent.hip) or the first filter fit on the fresh memory (csrc/cg_persistent.hip) is MISSING from this target model.
+        SYNCHRONISES (a few bytes).  The caller restarts the fit: refit_in_chain_form() while no frame has been tracked with the model
+        (Tracker.track on its first call after initialize()), otherwise the whole sequence (Tracker.run_sequence)."""
+        hit = False
         o = getattr(self, '_init_opt', None)
-        if o is None:
-            return False
-        n = o.joint_aborts()
-        seen = getattr(o, '_joint_aborts_seen', 0)
-        o._joint_aborts_seen = n
-        return n > seen
+        if o is not None:
+            n = o.joint_aborts()
+            hit = n > getattr(o, '_joint_aborts_seen', 0)
+            o._joint_aborts_seen = n
+        u = self.update_optimizer
+        if u is not None and not hit and self.frame_num == 0 and u._persistent_launched:
+            hit = bool(u.poll_persistent_abort())
+        return hit
+
+    def refit_in_chain_form(self):
+        """Restarts the first-frame fit of init() from the weights it started from, every solver in the chain form (the resident forms are
+        switched off for the process: a shared GPU does not become unshared).  Valid as long as nothing has been inserted into the memory
+        since init(): the joint problem's memory of raw samples is still this instance's."""
+        if getattr(self, '_start_w', None) is None or self._ws.get('mem0') is None:
+            raise RuntimeError('refit_in_chain_form: init() has not run (or not in a resident form)')
+        DiscriminatorLoss.persistent_joint = False
+        GaussNewtonCG.persistent_joint = False
+        GaussNewtonCG.abort_seen_in_process = True
+        self.project.weight.data.copy_(self._start_w[0])
+        self.filter.weight.data.copy_(self._start_w[1])
+        self._invalidate()
+        self._ws.pop('init_graph', None)
+        mem0, memory = self._ws['mem0'], self._ws['memory']
+        memory.reset()
+        opt = self._init_body(mem0, memory, self._init_y)
+        opt.persistent = False
+        opt.reset_persistent_counts()
+        self.frame_num = 0
+        self.num_persistent_aborts += 1
+        self.memory, self.update_optimizer = memory, opt
 
     def recover_from_abort(self):
         """A persistent launch of the update solver timed out (its workgroups did not all become resident: the GPU is shared): it left
@@ -738,12 +773,12 @@ class Discriminator(nn.Module):
         if not self.update_filters or self.current_sample is None:
             return
         solve = self.frame_num % self.train_skipping == 0
+        opt = self.update_optimizer
+        if opt.peek_persistent_abort():             # (a look at a pinned host word: every frame, so that a missed re-solve is made up on the next one)
+            self.recover_from_abort()
         if num_positive is None and count_dev is not None and not solve:
             self.memory.update(self.current_sample, train_y, count_dev=count_dev)
             return
-        opt = self.update_optimizer
-        if solve and opt.peek_persistent_abort():
-            self.recover_from_abort()
         if num_positive is None and count_dev is not None and self.device_early_out and opt.can_guard():
             # re-solve frame, the early-out decided on the device as well: guarded insert + guarded solve, no device->host read
             self.memory.update(self.current_sample, train_y, count_dev=count_dev)

@@ -143,6 +143,7 @@ class GaussNewtonCG:
         H.fill(self._state[:1], 1.0)
         self._has_p = False
         self.step_alpha = self._step_alpha0
+        self._joint_launched = False     # (a pooled solver: joint_aborts() reads 0 until THIS object's fit has launched in the resident form)
         return self
 
     def reset_state(self):

@@ -296,7 +296,9 @@ class SegNetwork(nn.Module):
             t = self.TSE[L]
             w0 = t.transform[0].weight.data
             oc = w0.shape[1] - 1
-            base = nn.Conv2d(oc, w0.shape[0], 3, padding=1, bias=False).to(dev)
+            # (skip_init: this runs lazily on the first forward, i.e. in the middle of a sequence -- a default-initialised module would draw from the
+            #  process-global CPU generator that the next target model's start weights come from, reference tracker.py:179 / fixture G15)
+            base = torch.nn.utils.skip_init(nn.Conv2d, oc, w0.shape[0], 3, padding=1, bias=False, device=dev)
             base.weight.data.copy_(w0[:, :oc])
             c = self.CAB[L].convreluconv
             P[L] = dict(r0=cv(t.reduce[0], relu_=True), r2=cv(t.reduce[2]), base=cv(base), ws=w0[:, oc].reshape(w0.shape[0], 9).contiguous(),

@@ -363,6 +363,13 @@ class Tracker(nn.Module):
         self.object_ids = sequence.obj_ids
         self.current_frame = 0
         self.release_targets()
+        self._in_run_sequence, self._unchecked_fits = True, []
+        try:
+            return self._run_sequence_frames(sequence, speedrun, ytvos_merge)
+        finally:
+            self._in_run_sequence, self._unchecked_fits = False, []
+
+    def _run_sequence_frames(self, sequence, speedrun, ytvos_merge):
         N = 0
         object_ids = H.upload(torch.tensor([0] + list(sequence.obj_ids), dtype=torch.uint8), self.device)
         self._lut, self._single = object_ids, len(sequence.obj_ids) == 1
@@ -422,17 +429,21 @@ class Tracker(nn.Module):
             outputs = self._ytvos_labels(sequence, outputs, object_ids)
         self.last_enqueue_seconds = time() - t0              # host done; the GPU may still be working (no host wait while tracking)
         torch.cuda.synchronize()
-        for t in self.targets.values():                      # (a 4-byte read per object, after the synchronise above)
-            d = t.discriminator
-            if d is not None and d.recover_from_abort():     # a timed-out persistent launch: its solve is re-run now (multi-kernel form)
-                torch.cuda.synchronize()
-        if any(t.discriminator is not None and t.discriminator.init_aborted() for t in self.targets.values()) and not getattr(self, '_rerun', False):
-            # a resident launch of a first-frame fit timed out (another process holds CUs): the target model lacks a Gauss-Newton iteration.
-            # Switch the resident form of the joint problem off for the process and track the sequence again in the chain form.
+        # Resident launches that timed out (another process holds CUs; a few bytes read per object, after the synchronise above).  A missed
+        # filter re-solve has been made up on a later frame at best, a missed Gauss-Newton iteration of a first-frame fit not at all: frames
+        # were tracked with a model the reference would not have had.  Every check is EVALUATED (each books its counters), then the sequence
+        # is tracked again -- once: the resident forms are off for the rest of the process after the first time-out.
+        discs = [t.discriminator for t in self.targets.values() if t.discriminator is not None]
+        late = [d.recover_from_abort() for d in discs]
+        if any(late):
+            torch.cuda.synchronize()
+        missing = [d.init_aborted() for d in discs]
+        if (any(missing) or any(late) or any(d.num_persistent_aborts > 0 for d in discs)) and not getattr(self, '_rerun', False):
             from .discriminator import DiscriminatorLoss
             from .optimizer import GaussNewtonCG
             DiscriminatorLoss.persistent_joint = False
             GaussNewtonCG.persistent_joint = False
+            GaussNewtonCG.abort_seen_in_process = True
             self._rerun = True
             try:
                 self.release_targets()
@@ -653,13 +664,19 @@ class Tracker(nn.Module):
         Hh, Ww = image.shape[-2:]
         self.current_masks = H.fill(torch.empty((len(self.targets) + len(new_objects) + 1, Hh, Ww), device=self.device), 0.0)
         lab8 = labels.reshape(Hh, Ww)
-        lab8 = (lab8 if lab8.dtype == torch.uint8 else lab8.to(torch.uint8)).contiguous()
+        # the one-kernel mask path reads uint8 label maps; any other integer type (object ids beyond 255 exist in such maps, and a narrowing
+        # cast would wrap them onto small ids) takes the reference's literal comparison below
+        lab8 = lab8.contiguous() if lab8.dtype == torch.uint8 else None
         fresh = []
         for obj_id in new_objects:
             # mask = (labels == obj_id) as uint8 and as the object's plane of current_masks: one kernel (reference :170-172,188)
-            mask = torch.empty(1, Hh, Ww, dtype=torch.uint8, device=self.device)
-            H.call('frtm_label_mask', lab8.data_ptr(), int(obj_id), Hh * Ww, mask.data_ptr(),
-                   self.current_masks[len(self.targets) + 1].data_ptr())
+            if lab8 is not None and 0 <= int(obj_id) < 256:
+                mask = torch.empty(1, Hh, Ww, dtype=torch.uint8, device=self.device)
+                H.call('frtm_label_mask', lab8.data_ptr(), int(obj_id), Hh * Ww, mask.data_ptr(),
+                       self.current_masks[len(self.targets) + 1].data_ptr())
+            else:
+                mask = (labels.reshape(1, Hh, Ww) == obj_id).to(torch.uint8)
+                self.current_masks[len(self.targets) + 1].copy_(mask[0])
             target = TargetObject(obj_id=obj_id, index=len(self.targets) + 1, disc_params=self.disc_params,
                                   discriminator=self._disc_pool.pop() if self._disc_pool else None,
                                   start_frame=self.current_frame, start_mask=mask)
@@ -742,7 +759,19 @@ class Tracker(nn.Module):
                 b0 += k
             for st in lanes:
                 cur.wait_stream(st)
+            self._unchecked_fits = getattr(self, '_unchecked_fits', []) + [t for t, _, _ in fresh]
         return self.current_masks
+
+    def _check_first_frame_fits(self):
+        """Callers that own the frame loop (initialize() / track(), the reference's contract): before the first frame is tracked with a new
+        target model, ask whether a resident launch of its first-frame fit timed out (Discriminator.init_aborted: waits for the fit, a few
+        bytes read) and restart the fit in the chain form right away -- no frame is ever scored with a half-fitted model.  run_sequence
+        does not wait here (its host runs whole sequences ahead of the GPU): it asks after the sequence and tracks it again."""
+        fits, self._unchecked_fits = self._unchecked_fits, []
+        for t in fits:
+            d = t.discriminator
+            if d is not None and self.targets.get(t.object_id) is t and d.init_aborted():
+                d.refit_in_chain_form()
 
     @torch.no_grad()
     @H.roctx('track_window')
@@ -827,6 +856,8 @@ class Tracker(nn.Module):
     def track(self, image, features=None):
         """Reference tracker.py:193-227.  ``features``: optional pre-computed taps of this frame (frames_with_features)."""
         im_size = image.shape[-2:]
+        if getattr(self, '_unchecked_fits', None) and not getattr(self, '_in_run_sequence', False):
+            self._check_first_frame_fits()
         if features is None:
             features = self.feature_extractor(image)
         active = [t for t in self.targets.values() if t.start_frame < self.current_frame]

@@ -125,3 +125,96 @@ def test_free_running_parity_without_weight_injection(golden):
         trk.current_frame += 1
         cpu.current_frame += 1
     trk._raw_log = None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# resident first-frame fits that time out
+# ------------------------------------------------------------------------------------------------------------------
+
+def test_resident_joint_fit_commits_or_aborts_never_both():
+    """csrc/joint_persistent.hip's three-state abort word (0 running / 1 aborted / 2 committed, every transition a compare-and-swap from 0).
+    200 launches alternating a normal spin limit with the debug one (the first workgroup that waits gives up at once -- in every barrier of
+    the launch, the final one included): after every launch commits + aborts == launches, an aborted launch left weights / solver state
+    bit-identical, a committed one changed them."""
+    from test_round4_gpu import _joint_case
+    mem, prob, opt, w1, w2 = _joint_case(256, 32, 24, 40, 96, 160, 7, True)
+    prob.initialize()
+    assert opt._persistent_joint_plan() is not None
+    opt._alloc()
+    commits = aborts = 0
+    for k in range(200):
+        w1_0, w2_0, buf0 = w1.detach().clone(), w2.detach().clone(), opt._buf.clone()
+        opt.debug_abort = bool(k % 3 == 1)
+        opt.run((2,))
+        opt.debug_abort = False
+        torch.cuda.synchronize()
+        _, _, n_abort, n_commit = opt._gstats.tolist()
+        assert n_abort + n_commit == k + 1, (k, n_abort, n_commit)
+        if n_abort > aborts:
+            assert n_commit == commits
+            assert torch.equal(w1.detach(), w1_0) and torch.equal(w2.detach(), w2_0) and torch.equal(opt._buf, buf0), 'launch %d: counted as aborted AND written' % k
+        else:
+            assert n_commit == commits + 1 and not torch.equal(w2.detach(), w2_0)
+        commits, aborts = n_commit, n_abort
+    assert aborts >= 60 and commits >= 120, (commits, aborts)
+
+
+def test_online_caller_gets_an_aborted_first_frame_fit_redone_before_the_first_frame():
+    """Tracker.initialize() / track() driven by the caller (the reference's contract): when a resident launch of the
+    first-frame fit times out, the first track() after it restarts the fit in the chain form -- the frame is scored with the model a
+    process that never had the resident forms would have (bit for bit: same start weights, same chain kernels)."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    from frtm_vos_amd.model.optimizer import GaussNewtonCG
+    torch.set_grad_enabled(False)
+    seq = SyntheticSequence('abort', 3, (192, 256), 2, seed=31)
+    refiner = JF.refiner_for('resnet18')
+    saved = (DiscriminatorLoss.persistent_joint, GaussNewtonCG.persistent_joint)
+    outs = {}
+    try:
+        for mode in ('chain', 'resident_aborted'):
+            DiscriminatorLoss.persistent_joint = GaussNewtonCG.persistent_joint = mode != 'chain'
+            GaussNewtonCG.abort_seen_in_process = mode == 'chain'
+            trk = _tracker('resnet18', refiner, init_iters=(3, 4, 4), update_iters=(3,), memory_size=8, train_skipping=2)
+            image, labels, new = seq[0]
+            trk.current_frame, trk.targets = 0, dict()
+            torch.manual_seed(0)
+            GaussNewtonCG.debug_abort = mode != 'chain'
+            try:
+                trk.initialize(image.to(DEV), labels.to(DEV), new)
+                torch.cuda.synchronize()
+            finally:
+                GaussNewtonCG.debug_abort = False
+            d0 = trk.targets[new[0]].discriminator
+            if mode != 'chain':
+                assert d0._init_opt.joint_aborts() >= 1, 'the resident fit did not run (or did not abort)'
+            trk.current_frame = 1
+            m1 = trk.track(seq[1][0].to(DEV)).clone()
+            outs[mode] = (m1, [trk.targets[o].discriminator.filter.weight.detach().clone() for o in new],
+                          [trk.targets[o].discriminator.project.weight.detach().clone() for o in new])
+            if mode != 'chain':
+                assert GaussNewtonCG.persistent_joint is False and d0.num_persistent_aborts >= 1
+        for a, b in zip(outs['chain'][1] + outs['chain'][2], outs['resident_aborted'][1] + outs['resident_aborted'][2]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs['chain'][0], outs['resident_aborted'][0])
+    finally:
+        DiscriminatorLoss.persistent_joint, GaussNewtonCG.persistent_joint = saved
+        GaussNewtonCG.debug_abort = False
+        GaussNewtonCG.abort_seen_in_process = False
+
+
+def test_label_maps_with_wide_object_ids():
+    """Tracker.initialize with an int32 label map whose ids exceed 255 (the reference's `labels == obj_id` works for any integer):
+    the object's start mask and its plane of current_masks are the literal comparison, not a wrapped uint8 cast."""
+    torch.set_grad_enabled(False)
+    trk = _tracker('resnet18', init_iters=(2, 2), update_iters=(2,), memory_size=8)
+    Hh, Ww = 96, 128
+    labels = torch.zeros(1, Hh, Ww, dtype=torch.int32)
+    labels[0, 10:50, 10:60] = 300
+    labels[0, 40:90, 70:120] = 44            # 300 wraps to 44 in a uint8 cast
+    image = torch.randint(0, 256, (3, Hh, Ww), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    trk.current_frame, trk.targets = 0, dict()
+    masks = trk.initialize(image.to(DEV), labels.to(DEV), [300, 44])
+    assert torch.equal(masks[1].cpu(), (labels[0] == 300).float()) and torch.equal(masks[2].cpu(), (labels[0] == 44).float())
+    assert torch.equal(trk.targets[300].start_mask.cpu(), (labels == 300).to(torch.uint8))
+    assert torch.equal(trk.targets[44].start_mask.cpu(), (labels == 44).to(torch.uint8))
