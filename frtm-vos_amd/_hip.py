@@ -54,6 +54,9 @@ SIGNATURES = {
     'frtm_filter_scores_split': (I, [P, P, I, I, I, I, I, P, P]),
     'frtm_stencil_sum': (I, [P, P, P, P, I, I, I, I, P, P]),
     'frtm_joint_scores_composed': (I, [P, P, I, P, P, I, I, I, I, I, P, P]),
+    'frtm_wide_parts': (I, [I, I]),
+    'frtm_scores_wide': (I, [P, P, I, P, P, I, I, I, I, I, P, P]),
+    'frtm_wgrad_wide': (I, [P, P, I, I, I, I, P, P]),
     'frtm_joint_q_pq_composed': (I, [P, I, I, I, P, F, P, I, I, I, F, P, P, F, P, P, P, P]),
     'frtm_memory_update_window': (I, [P, I, F, I, P, P, I, I, I, P, P, P, I, P, ctypes.c_size_t, I, I, I, I, F, P, P, P, P]),
     'frtm_joint_compose': (I, [P, P, I, I, P, P]),

@@ -40,13 +40,29 @@ int frtm_sk_launch(const ConvParams& p, float* ws, size_t ws_elems, int G, hipSt
 // pass 9.59 vs 9.56 ms) -- at these sizes neither the MFMA form nor the staging path bounds the kernel.
 static const bool g_use_g32 = getenv("FRTM_USE_G32") && atoi(getenv("FRTM_USE_G32"));
 
+#ifdef FRTM_DEBUG_TRACE
+// tools/ktrace.py only (never in the shipped library): every workgroup of k_conv_igemm records where it ran and when its phases began --
+// {HW_ID, XCC_ID, enter, K loop start, K loop end, exit} on the 100 MHz constant clock -- into a caller's buffer.
+__device__ unsigned long long* g_kt_buf = nullptr;
+__device__ unsigned g_kt_cap = 0;
+__device__ unsigned g_kt_n[288];          // records per CU (xcc * 36 + se * 9 + cu): ONE counter for the chip serialised the workgroups' exits
+                                          // (3248 returning atomics on one word = 37 us, four times the kernel)
+#define KT_STAMP(i) do { if (threadIdx.x == 0) kt[i] = wall_clock64(); } while (0)
+#else
+#define KT_STAMP(i) do { } while (0)
+#endif
+
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
 // MODE 2 (round 4): 1x1, stride 1, ANY Npix >= 4 (the 15x27 = 405-pixel maps of RN101's last stage at 480p): the same dwordx4 staging at
 //         dword alignment (buffer loads only force dword alignment).  A lane's four columns n .. n+3 of the flattened (image, pixel) axis
 //         either lie in one image row -- one dwordx4 -- or straddle the end of an image: those lanes (one per image boundary) take four
 //         dword loads, the wrapped columns from the next image.  Results are those of MODE 0 / 1 bit for bit (same k order per column).
-template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32>
+// PIPE = 1 (round 5): the K loop as ONE software pipeline across chunk boundaries -- fragment reads run two k-steps ahead of their MFMAs in a
+//         ring of four register sets, and the next chunk is staged into LDS (and the barrier taken) before the LAST TWO k-steps of the
+//         current chunk, whose MFMAs then cover the first fragment reads of the next chunk: the per-chunk drain (ds_write, barrier, a full LDS
+//         round trip before the first MFMA) of PIPE = 0 disappears.  Same k order per output element: results are bit-identical.
+template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32, int PIPE = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams p) {
   constexpr int BK = BKT;                                // chunk depth of this instantiation (32 or 64)
   constexpr int NT = 64 * WGM * WGN;
@@ -64,6 +80,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WGN, wn = wid % WGN;
+#ifdef FRTM_DEBUG_TRACE
+  unsigned long long kt[4] = {0, 0, 0, 0};
+#endif
+  KT_STAMP(0);
   int m_tile, n_tile;
   tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, n_tile);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -158,12 +178,57 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int lk = lane >> 4, li = lane & 15;
+  if constexpr (PIPE) {
+    constexpr int KS = BK / 4;                             // k-steps per chunk
+    static_assert(KS >= 4 && KS % 4 == 0, "ring of four");
+    float af[4][FM], bf[4][FN];
+    auto rd = [&](int buf, int ks, int slot) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[slot][i] = As[buf][ks * 4 + lk][wm * TM + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[slot][j] = Bs[buf][ks * 4 + lk][wn * TN + j * 16 + li];
+    };
+    if (kc0 < kc1) {
+      gload(kc0);
+      lstore(0);
+    }
+    __syncthreads();
+    KT_STAMP(1);
+    if (kc0 < kc1) {
+      if (kc0 + 1 < kc1) gload(kc0 + 1);
+      rd(0, 0, 0);
+      rd(0, 1, 1);
+    }
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const int cur = (kc - kc0) & 1;
+      const bool more = (kc + 1) < kc1;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        if (kk == KS - 2) {
+          // every fragment read of this chunk has been issued (steps KS-2, KS-1 at kk = KS-4, KS-3): the other buffer takes the next chunk,
+          // one barrier, and the loads of the chunk after it start
+          if (more) lstore(cur ^ 1);
+          __syncthreads();
+          if (kc + 2 < kc1) gload(kc + 2);
+        }
+        if (kk + 2 < KS) rd(cur, kk + 2, (kk + 2) & 3);
+        else if (more) rd(cur ^ 1, kk + 2 - KS, (kk + 2) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 3][i], bf[kk & 3][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
   if (kc0 < kc1) {
     gload(kc0);
     lstore(0);
   }
   __syncthreads();
-  const int lk = lane >> 4, li = lane & 15;
+  KT_STAMP(1);
   for (int kc = kc0; kc < kc1; ++kc) {
     const int cur = (kc - kc0) & 1;
     const bool more = (kc + 1) < kc1;
@@ -194,9 +259,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     __syncthreads();
   }
 
+  }
+
   // ---- epilogue.  The accumulators (C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg) go through an LDS
   // tile so that global memory sees whole rows: one dwordx4 per lane, 256 contiguous bytes per 16 lanes, instead of four 64-byte
   // fragments per store instruction.  BN scale/shift, residual (dwordx4 read) and ReLU are applied on the way out.
+  KT_STAMP(2);
   float* Cs = smem;                                    // the K loop ended with a barrier: the staging buffers are free
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -264,6 +332,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       else p.out[o] = v;
     }
   }
+#ifdef FRTM_DEBUG_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && g_kt_buf) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xccid = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    const unsigned key = (xccid & 7u) * 36u + ((hwid >> 13) & 3u) * 9u + min((hwid >> 8) & 15u, 8u);
+    const unsigned per = g_kt_cap / 288u;
+    const unsigned local = atomicAdd(&g_kt_n[key], 1u);
+    if (local < per) {
+      unsigned long long* r = g_kt_buf + ((size_t)key * per + local) * 8;
+      r[0] = hwid;                                            // HW_REG_HW_ID
+      r[1] = xccid;                                           // HW_REG_XCC_ID
+      r[2] = kt[0]; r[3] = kt[1]; r[4] = kt[2]; r[5] = wall_clock64();
+      r[6] = ((unsigned long long)blockIdx.x << 32) | (unsigned)gridDim.x;
+      r[7] = ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | ((unsigned long long)p.K << 8) | (unsigned)MODE;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -464,16 +549,23 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 static inline bool halo_layout_requested(const frtm_conv_desc* d) { return d->w_layout == FRTM_WLAYOUT_HALO3X3; }
 
+// FRTM_KPIPE=0: the stride-1 1x1 launches (dwordx4 staging, MODE 1 / 2) of the 8-wave 64x64 and the 32x64 tile keep round 4's K loop (A/B switch)
+static const bool g_kpipe = !(getenv("FRTM_KPIPE") && atoi(getenv("FRTM_KPIPE")) == 0);
+
 template <int BM, int BN, int WGM, int WGN>
 static void launch_tile_u(const ConvParams& p, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
-  k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  constexpr bool piped = (BM == 64 && BN == 64 && WGM == 2 && WGN == 4) || (BM == 32 && BN == 64 && WGM == 1 && WGN == 4);
+  if (piped && g_kpipe) k_conv_igemm<BM, BN, WGM, WGN, 2, 32, piped ? 1 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT = 32>
 static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
-  if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  constexpr bool piped = BKT == 32 && ((BM == 64 && BN == 64 && WGM == 2 && WGN == 4) || (BM == 32 && BN == 64 && WGM == 1 && WGN == 4));
+  if (vec1x1 && piped && g_kpipe) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT, piped ? 1 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  else if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv_igemm<BM, BN, WGM, WGN, 0, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
@@ -748,3 +840,21 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
 }
 
 }  // extern "C"
+
+#ifdef FRTM_DEBUG_TRACE
+// tools/ktrace.py: hands the trace buffer (cap records of 8 x u64) to the kernels above and resets the record count; buf = NULL switches it off.
+extern "C" int frtm_debug_ktrace(unsigned long long* buf, unsigned cap) {
+  static const unsigned zero[288] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kt_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kt_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_kt_n), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+// counts[288] <- records per CU slot; returns their sum (records of CU k: buf[(k * (cap / 288) + i) * 8], i < min(counts[k], cap / 288))
+extern "C" int frtm_debug_ktrace_counts(unsigned* counts) {
+  if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_kt_n), 288 * sizeof(unsigned)) != hipSuccess) return -1;
+  int n = 0;
+  for (int k = 0; k < 288; ++k) n += (int)counts[k];
+  return n;
+}
+#endif

@@ -74,6 +74,10 @@ class DiscriminatorLoss(MinimizationProblem):
         self.t = torch.empty(cap, self.hw, device=dev)
         self.partial = torch.empty(cap * 8, self.c * 9, device=dev)      # per-sample (x up to 8 pixel parts) weight-gradient slabs
         self.N = 0
+        # maps wider than a wavefront (720p / 1080p): the strip forms of the two passes over the features (csrc/wide_maps.hip), if the map takes
+        # them and their row blocks fit the 8 slabs per sample the partial buffers hold
+        wp = int(H.lib().frtm_wide_parts(h, w)) if self.wide_forms else 0
+        self.wide_parts = wp if 0 < wp <= 8 else 0
         if self.joint:
             self.Cin = C
             self.Z = torch.empty(cap, self.c, h, w, device=dev)
@@ -94,6 +98,10 @@ class DiscriminatorLoss(MinimizationProblem):
             # can (720p: 3 groups, 1080p: 2)
             row_blocks = ((h + 2) // 3) * ((w + 63) // 64)
             self.CS = max(1, min(8, round(450.0 / max(1, row_blocks * 5))))
+            if self.wide_parts:
+                # strip form: a workgroup is (sample, row block, channel group) and its four waves split the group's channels -- the channel
+                # groups are where the parallelism comes from (about four workgroups per CU at five samples; 1080p: 41 groups of 25 channels)
+                self.CS = max(1, min(64, -(-1024 // (5 * self.wide_parts))))
             self._sp_all = torch.empty((self.CS + 1) * cap * self.hw, device=dev)   # their partial score maps (+ one for the filter-direction term)
 
     def rebind(self, filter_regs, precond, filter_weight, project_weight=None):
@@ -137,9 +145,19 @@ class DiscriminatorLoss(MinimizationProblem):
         H.call('frtm_stencil', H.ptr(m.normal_B), H.ptr(m.normal_c) if with_c else None, H.ptr(m.weights),
                H.ptr(self.s), self.N, self.h, self.w, H.ptr(self.t))
 
+    wide_forms = not __import__('os').environ.get('FRTM_NO_WIDE')
+
+    def _wgrad(self, feats, C, partial):
+        """3x3 weight gradient of `feats` (N, C, h, w) against self.t as per-sample slabs; returns the number of slabs per sample."""
+        if self.wide_parts:
+            H.call('frtm_wgrad_wide', H.ptr(feats), H.ptr(self.t), self.N, C, self.h, self.w, H.ptr(partial))
+            return self.wide_parts
+        parts = H.lib().frtm_filter_wgrad_parts_hw(self.N, C, self.hw)
+        H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, C, self.h, self.w, parts, H.ptr(partial))
+        return parts
+
     def _filter_grad(self, feats, lam2, pvec, sign, out):
-        parts = H.lib().frtm_filter_wgrad_parts_hw(self.N, self.c, self.hw)
-        H.call('frtm_filter_wgrad', H.ptr(feats), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
+        parts = self._wgrad(feats, self.c, self.partial)
         H.call('frtm_vec_reduce_slabs', H.ptr(self.partial), self.N * parts, self.c * 9, self.c * 9, lam2, pvec, sign, out)
 
     def apply_A_partials(self, p):
@@ -149,8 +167,7 @@ class DiscriminatorLoss(MinimizationProblem):
             return None
         ops.filter_scores(self.mem.samples, p, out=self.s, n=self.N)
         self._stencil(False)          # separate 4.6 us kernel: fusing it into the weight-gradient kernel measured slower (+8 us)
-        parts = H.lib().frtm_filter_wgrad_parts_hw(self.N, self.c, self.hw)
-        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), self.N, self.c, self.h, self.w, parts, H.ptr(self.partial))
+        parts = self._wgrad(self.mem.samples, self.c, self.partial)
         return self.partial, self.N * parts, self.c * 9, self.filter_regs[0] ** 2
 
     # joint problem: a whole Gauss-Newton iteration as ONE resident launch (csrc/joint_persistent.hip) where the shape fits
@@ -196,17 +213,15 @@ class DiscriminatorLoss(MinimizationProblem):
 
     def _composed_scores(self, p2):
         """Partial score maps: the raw features under the composed kernel in CS channel groups, Z under p2 as one more map."""
-        H.call('frtm_joint_scores_composed', H.ptr(self.mem.samples), H.ptr(self.Kp), self.Cin, H.ptr(self.Z), H.ptr(p2), self.c,
-               self.N, self.h, self.w, self.CS, H.ptr(self.sp))
+        H.call('frtm_scores_wide' if self.wide_parts else 'frtm_joint_scores_composed', H.ptr(self.mem.samples), H.ptr(self.Kp), self.Cin,
+               H.ptr(self.Z), H.ptr(p2), self.c, self.N, self.h, self.w, self.CS, H.ptr(self.sp))
 
     def _composed_tail(self, p1, p2, sign, q, r, partial):
         """The two 3x3 weight gradients against t (raw features: Cin x 9 slabs, projected features: c x 9 slabs), then q = sign *
         [ expand(raw slabs) through w2 + lam1 p1 | projected slabs + lam2 p2 ] and the partials of <p,q> (and <p,r>)."""
         N, c = self.N, self.c
-        px = H.lib().frtm_filter_wgrad_parts_hw(N, self.Cin, self.hw)
-        pz = H.lib().frtm_filter_wgrad_parts_hw(N, c, self.hw)
-        H.call('frtm_filter_wgrad', H.ptr(self.mem.samples), H.ptr(self.t), N, self.Cin, self.h, self.w, px, H.ptr(self.partialX))
-        H.call('frtm_filter_wgrad', H.ptr(self.Z), H.ptr(self.t), N, c, self.h, self.w, pz, H.ptr(self.partial))
+        px = self._wgrad(self.mem.samples, self.Cin, self.partialX)
+        pz = self._wgrad(self.Z, c, self.partial)
         H.call('frtm_joint_q_pq_composed', H.ptr(self.partialX), N * px, self.Cin, c, H.ptr(self.w2.data), self.filter_regs[0] ** 2,
                H.ptr(self.partial), N * pz, c * 9, c * 9, self.filter_regs[1] ** 2, p1, p2, float(sign), H.ptr(q),
                None if r is None else H.ptr(r), None if partial is None else H.ptr(partial))
@@ -740,6 +755,9 @@ class Discriminator(nn.Module):
         self.filter.weight.data.copy_(self._start_w[1])
         self._invalidate()
         self._ws.pop('init_graph', None)
+        u = self.update_optimizer
+        if u is not None and u._persistent_launched:
+            u.poll_persistent_abort()               # (books the timed-out first filter fit: the fit below replaces it, update() must not "make it up")
         mem0, memory = self._ws['mem0'], self._ws['memory']
         memory.reset()
         opt = self._init_body(mem0, memory, self._init_y)

@@ -158,6 +158,16 @@ int frtm_joint_q_pq(const float* g1, int n1, float lam1, const float* slabs, int
  * the FRTM_CG_BLOCKS per-block partials of <p,q> (and <p,r> if r != NULL) that frtm_cg_update sums. */
 int frtm_joint_scores_composed(const float* X, const float* K, int Cx, const float* Z, const float* p2, int Cz, int N, int h, int w,
                                int splits, float* partial, frtm_stream_t stream);
+
+/* Wide feature maps (64 < w <= 256, w % 4 == 0: the 45 x 80 / 68 x 120 maps of 720p / 1080p), csrc/wide_maps.hip (round 5): the two HBM-bound
+ * passes of an operator application in strip form (a lane owns 4 columns x 8 rows, dwordx4 rows, neighbours by DPP).
+ *   frtm_wide_parts       row blocks the strip forms cut an h x w map into (= slabs per sample of frtm_wgrad_wide); 0 = maps the forms do not take
+ *   frtm_scores_wide      frtm_joint_scores_composed's contract (reference discriminator.py:45-50 through the composed kernel)
+ *   frtm_wgrad_wide       frtm_filter_wgrad's contract with parts = frtm_wide_parts(h, w): partial float[N*parts][C*9] */
+int frtm_wide_parts(int h, int w);
+int frtm_scores_wide(const float* X, const float* K, int Cx, const float* Z, const float* p2, int Cz, int N, int h, int w,
+                     int splits, float* partial, frtm_stream_t stream);
+int frtm_wgrad_wide(const float* X, const float* t, int N, int C, int h, int w, float* partial, frtm_stream_t stream);
 int frtm_joint_q_pq_composed(const float* GX, int nslabX, int Cin, int c, const float* w2, float lam1, const float* slabs, int nslab,
                              int stride, int n2, float lam2, const float* p1, const float* p2, float sign, float* q, const float* r,
                              float* partial, frtm_stream_t stream);

@@ -9,8 +9,8 @@
       (Cin = 1024, full schedule) and free-running masks.
   (c) J&F at DATASET level: fixture G14 -- 32 synthetic sequences x 40 frames, 77 objects -- against the recorded runs of the CPU oracle
       (oracle/make_golden_jf.py --spec v2 -> tests/golden/g14_jf_*.npz: float32 at four thread counts and with the stem weights moved by
-      1 / 3 ulp, float64): eight HIP dataset runs against them, |mean - mean| <= 0.1 points, strictly; every single run within the
-      single-run noise floor.  Round 3's 12-sequence fixture G12 stays as a second sample with an explicit secondary bound.
+      1 / 3 ulp, float64; G16: sixteen more draws of the two sequences that carry the spread): sixteen HIP dataset runs against them, |mean - mean|
+      <= 0.1 points, strictly; every single run within the ORACLE's own 3 sigma; sigma_HIP <= 1.5 sigma_oracle.  Round 3's 12-sequence fixture G12 stays as a second sample with an explicit secondary bound.
 """
 import copy
 import os
@@ -381,67 +381,89 @@ def _other_run(fixture, n_seq):
     return np.concatenate([fx['jf_%d' % k] for k in range(n_seq)])
 
 
-HIP_DRAWS = (0, 1, 2, 3, 4, 5, 6, 7)
+HIP_DRAWS = tuple(range(16))
+
+
+def _oracle_draws_per_sequence(n_seq, n_obj_per_seq):
+    """Every float32 run of the oracle the fixtures hold, per SEQUENCE: {k: (draws, objects of k) J&F in points}.  Full-dataset runs:
+    g14_jf_float32{,_t2,_t3,_t6,_p1,_p3}.npz (thread counts 4 / 2 / 3 / 6, stem weights moved by 1 / 3 ulp).  Extra draws of single sequences:
+    g16_jf_draws_seq<k>.npz (oracle/make_golden_jf_draws.py: stem weights moved by 0..15 ulp) for the sequences that carry the run-to-run spread."""
+    per = {k: [] for k in range(n_seq)}
+    full = []
+    for tag in ('', '_t2', '_t3', '_t6', '_p1', '_p3'):
+        f = os.path.join(GOLDEN, 'g14_jf_float32%s.npz' % tag)
+        if not os.path.exists(f):
+            continue
+        fx = np.load(f)
+        if not all(('jf_%d' % k) in fx for k in range(n_seq)):
+            continue
+        rows = [100 * fx['jf_%d' % k].mean(1) for k in range(n_seq)]
+        full.append(np.concatenate(rows))
+        for k in range(n_seq):
+            per[k].append(rows[k])
+    for k in range(n_seq):
+        f = os.path.join(GOLDEN, 'g16_jf_draws_seq%d.npz' % k)
+        if os.path.exists(f):
+            fx = np.load(f)
+            assert fx['jf'].shape[1] == n_obj_per_seq[k]
+            per[k] += [100 * row.mean(1) for row in fx['jf']]
+    return {k: np.array(v) for k, v in per.items()}, np.array(full)
 
 
 def test_dataset_level_jf_within_0p1_of_the_cpu_oracle():
-    """THE north-star J&F gate (round-3 VERDICT "Next" #1): BASELINE config 3's shape -- 32 synthetic sequences x 40 frames, 1-5 objects
-    (mean 2.4; 77 objects), ResNet-101, full (5,10,10,10,10)/(10,) schedule, memory 80 -- through the product path against fixture G14, the
-    float32 CPU oracle's label images (oracle/make_golden_jf.py --spec v2).
+    """THE north-star J&F gate: BASELINE config 3's shape -- 32 synthetic sequences x 40 frames, 1-5 objects (mean 2.4; 77 objects), ResNet-101,
+    full (5,10,10,10,10)/(10,) schedule, memory 80 -- through the product path against fixture G14, the float32 CPU oracle's runs.
 
-    What round 4 measured: the dataset-level J&F of ONE run is a random variable under rounding-level perturbations, on BOTH sides -- the
-    float32 oracle at other thread counts or with its stem weights moved by 1 / 3 ulp (recorded: tests/golden/g14_jf_float32_{t2,t3,t6,p1,p3}),
-    the HIP path with its stem weights moved by 0..7 ulp (measured here, eight dataset runs): standard deviation ~0.05 points each, range
-    0.08-0.17.  A few objects under mutual occlusion (sequence jg04) take one of two trajectories, in the reference arithmetic as well.
-    The +-0.1 bar is therefore tested where it is defined, on the EXPECTATIONS, strictly:
+    The dataset-level J&F of ONE run is a random variable under rounding-level perturbations on BOTH sides (round 4); round 5 located it: two
+    sequences carry it -- jg04 (five objects; object 1 is fully occluded on frames 7-15 and how much of it is recovered on frame 16 is decided at
+    rounding level: 39-50 points over 22 runs of the ORACLE, 41-49 over 16 of the HIP path) and jg30 -- the other thirty contribute a tenth of
+    the variance.  Sequences are tracked independently, so a side's single-run variance is the SUM of its per-sequence variances, each estimated
+    from all the draws that side has for that sequence (oracle: six full runs + sixteen extra draws of jg04 / jg30, fixture G16; HIP: the sixteen
+    dataset runs made here, stem weights moved by 0..15 ulp, the oracle's own perturbation family).  Gates -- every bound is the ORACLE's:
 
-        | mean over the HIP draws  -  mean over the float32 oracle's draws |  <=  0.1 points        (no escape clause)
-
-    and every single HIP run -- the unperturbed default build first -- must lie within max(0.1, single-run noise floor) of the oracle's
-    mean, the floor being the largest dataset-level difference between two runs of the SAME implementation (oracle: recorded; HIP: measured
-    here), both printed; the typical object (median per-object difference) within 0.1 in every draw."""
+      (A) | mean over the HIP runs - mean over the oracle's full runs |            <= 0.1 points            (the north star's +-0.1, strictly)
+      (B) every single HIP run, the unperturbed default build first:  | x - oracle mean | <= 3 sigma_oracle  (the oracle's own single-run spread)
+      (C) sigma_HIP <= 1.5 sigma_oracle      (a build that became noisier than the reference arithmetic fails)
+      (D) the typical object: | median per-object difference to the oracle's mean | <= 0.1 in every run; label agreement > 0.995."""
     hips, ora, agree, n_seq = _dataset_jf('g14_jf_float32.npz', 'v2', 'jg%02d', HIP_DRAWS)
     hip = hips[0]
     assert n_seq >= 30 and len(hip) >= 70
-    jf_h, jf_o = 100 * hip.mean(), 100 * ora.mean()
-    print('G14 (%d sequences, %d objects): default build J&F HIP %.3f (J %.3f F %.3f)  CPU oracle (4 threads) %.3f (J %.3f F %.3f)  diff %+.3f  mean label agreement %.5f'
-          % (n_seq, len(hip), jf_h, 100 * hip[:, 0].mean(), 100 * hip[:, 1].mean(), jf_o, 100 * ora[:, 0].mean(), 100 * ora[:, 1].mean(),
-             jf_h - jf_o, agree))
-    # every float32 run of the oracle the fixture holds: thread counts 4 / 2 / 3 / 6 (another blocking of its convolutions and reductions)
-    # and the stem weights scaled by 1 and 3 ulp -- rounding-level perturbations of the REFERENCE arithmetic
-    draws = {'t4': ora.mean(1) * 100}
-    for tag in ('t2', 't3', 't6', 'p1', 'p3'):
-        v = _other_run('g14_jf_float32_%s.npz' % tag, n_seq)
-        if v is not None:
-            draws[tag] = v.mean(1) * 100
-    assert len(draws) >= 3, 'the fixture must hold at least three float32 runs of the oracle'
+    fx = np.load(os.path.join(GOLDEN, 'g14_jf_float32.npz'))
+    nobj = [int(v[1]) for v in fx['specs']]
+    starts = np.cumsum([0] + nobj)
+    o_seq, o_full = _oracle_draws_per_sequence(n_seq, nobj)
+    assert len(o_full) >= 3, 'the fixture must hold at least three full float32 runs of the oracle'
+    n_tot = float(sum(nobj))
+    h_obj = np.array([100 * h.mean(1) for h in hips])                                   # (draws, 77)
+    h_vals, o_vals = h_obj.mean(1), o_full.mean(1)
+    # single-run variance = sum of the per-sequence variances (independent sequences), in dataset points
+    var_h = sum(h_obj[:, starts[k]:starts[k + 1]].sum(1).var(ddof=1) for k in range(n_seq)) / n_tot ** 2
+    var_o = sum(o_seq[k].sum(1).var(ddof=1) for k in range(n_seq)) / n_tot ** 2
+    sig_h, sig_o = float(np.sqrt(var_h)), float(np.sqrt(var_o))
+    print('G14 (%d sequences, %d objects): default build J&F HIP %.3f (J %.3f F %.3f)  CPU oracle (4 threads) %.3f  diff %+.3f  mean label agreement %.5f'
+          % (n_seq, len(hip), h_vals[0], 100 * hip[:, 0].mean(), 100 * hip[:, 1].mean(), 100 * ora.mean(), h_vals[0] - 100 * ora.mean(), agree))
+    print('float32 oracle, full runs: ' + ' '.join('%.3f' % v for v in o_vals) + '   mean %.3f;  single-run sigma from per-sequence variances %.3f '
+          '(draws per sequence: %s)' % (o_vals.mean(), sig_o, ' '.join('%d:%d' % (k, len(o_seq[k])) for k in range(n_seq) if len(o_seq[k]) > len(o_full))))
+    print('HIP runs, stem weights moved by K ulp: ' + ' '.join('%.3f' % v for v in h_vals) + '   mean %.3f, sigma %.3f (per-sequence) / %.3f (plain)'
+          % (h_vals.mean(), sig_h, h_vals.std(ddof=1)))
+    top = sorted(range(n_seq), key=lambda k: -h_obj[:, starts[k]:starts[k + 1]].sum(1).var(ddof=1))[:3]
+    for k in top:
+        print('   sequence %2d (%d objects): sigma HIP %.3f, oracle %.3f dataset points (%d / %d draws)' %
+              (k, nobj[k], h_obj[:, starts[k]:starts[k + 1]].sum(1).std(ddof=1) / n_tot, o_seq[k].sum(1).std(ddof=1) / n_tot, len(h_obj), len(o_seq[k])))
     f64 = _other_run('g14_jf_float64.npz', n_seq)
-    names = sorted(draws)
-    o_vals = np.array([draws[n_].mean() for n_ in names])
-    h_vals = np.array([100 * h.mean() for h in hips])
-    floor_o, floor_h = float(o_vals.max() - o_vals.min()), float(h_vals.max() - h_vals.min())
-    print('float32 oracle runs (dataset J&F): ' + '  '.join('%s %.3f' % (n_, draws[n_].mean()) for n_ in names) +
-          '   mean %.3f, std %.3f, range %.3f' % (o_vals.mean(), o_vals.std(ddof=1), floor_o))
-    print('HIP runs, stem weights moved by K ulp:    ' + '  '.join('K%d %.3f' % (k, v) for k, v in zip(HIP_DRAWS, h_vals)) +
-          '   mean %.3f, std %.3f, range %.3f' % (h_vals.mean(), h_vals.std(ddof=1), floor_h))
     if f64 is not None:
         print('float64 oracle: %.3f; HIP mean - fp64 %+.3f, fp32 oracle mean - fp64 %+.3f points' %
               (100 * f64.mean(), h_vals.mean() - 100 * f64.mean(), o_vals.mean() - 100 * f64.mean()))
-    o_mean_obj = np.mean([draws[n_] for n_ in names], axis=0)
-    meds = [float(np.median(100 * h.mean(1) - o_mean_obj)) for h in hips]
-    d = hip.mean(1) * 100 - ora.mean(1) * 100
-    print('default build - oracle (4 threads) per object: mean %+.3f, median %+.3f, mean |d| %.3f, max |d| %.2f; median per-object difference '
-          'to the oracle mean, per draw: %s' % (d.mean(), np.median(d), np.abs(d).mean(), np.abs(d).max(), ' '.join('%+.3f' % m for m in meds)))
-    diff_means = float(h_vals.mean() - o_vals.mean())
-    floor = max(floor_o, floor_h)
-    print('GATE: mean(HIP draws) - mean(oracle draws) = %+.3f points (bar 0.1);  single-run noise floor: oracle %.3f, HIP %.3f;  '
-          'largest |single HIP run - oracle mean| = %.3f (bound %.3f)' % (diff_means, floor_o, floor_h, float(np.abs(h_vals - o_vals.mean()).max()), max(0.1, floor)))
-    # THE GATE (VERDICT r3 "Next" #1), strict and unconditional, on the expectations:
-    assert abs(diff_means) <= 0.1, (h_vals, o_vals)
-    # every single run within the single-run noise floor (or 0.1 where that is larger) of the oracle's mean ...
-    assert float(np.abs(h_vals - o_vals.mean()).max()) <= max(0.1, floor), (h_vals, o_vals.mean(), floor)
-    # ... and, whatever the floor, the TYPICAL object within 0.1 in every draw
-    assert max(abs(m) for m in meds) <= 0.1, meds
+    o_mean_obj = o_full.mean(0)
+    meds = [float(np.median(row - o_mean_obj)) for row in h_obj]
+    worst = float(np.abs(h_vals - o_vals.mean()).max())
+    print('GATES: (A) mean(HIP) - mean(oracle) = %+.3f (bar 0.1)   (B) largest |single HIP run - oracle mean| = %.3f, default build %+.3f (bound 3 sigma_oracle = %.3f)'
+          '   (C) sigma_HIP / sigma_oracle = %.2f (bound 1.5)   (D) median per-object differences %s'
+          % (h_vals.mean() - o_vals.mean(), worst, h_vals[0] - o_vals.mean(), 3 * sig_o, sig_h / sig_o, ' '.join('%+.3f' % m for m in meds)))
+    assert abs(h_vals.mean() - o_vals.mean()) <= 0.1, (h_vals, o_vals)                     # (A)
+    assert worst <= 3 * sig_o, (h_vals, o_vals.mean(), sig_o)                              # (B): the oracle's floor only
+    assert sig_h <= 1.5 * sig_o, (sig_h, sig_o)                                            # (C)
+    assert max(abs(m) for m in meds) <= 0.1, meds                                          # (D)
     assert agree > 0.995
 
 

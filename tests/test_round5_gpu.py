@@ -218,3 +218,86 @@ def test_label_maps_with_wide_object_ids():
     assert torch.equal(masks[1].cpu(), (labels[0] == 300).float()) and torch.equal(masks[2].cpu(), (labels[0] == 44).float())
     assert torch.equal(trk.targets[300].start_mask.cpu(), (labels == 300).to(torch.uint8))
     assert torch.equal(trk.targets[44].start_mask.cpu(), (labels == 44).to(torch.uint8))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# wide maps (720p / 1080p): strip forms of the two passes over the features (csrc/wide_maps.hip)
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('N,C,c,h,w,CS', [(2, 40, 16, 45, 80, 3), (3, 70, 8, 68, 120, 5), (1, 33, 5, 9, 68, 64), (2, 17, 4, 23, 256, 2), (5, 1024, 96, 68, 120, 41)])
+def test_wide_map_strip_forms_against_the_explicit_operators(N, C, c, h, w, CS):
+    """frtm_scores_wide / frtm_wgrad_wide (maps wider than a wavefront, w % 4 == 0) against the explicit operators in float64 on the CPU --
+    s = conv3x3(X, K) + conv3x3(Z, p2) summed over the partial maps, g[c][dy][dx] = sum X[y][x] t[y-dy+1][x-dx+1] summed over the slabs -- and
+    against round 4's forms of the same passes (frtm_joint_scores_composed, frtm_filter_wgrad): map edges, a last row block that is not full
+    (68 = 4 x 16 + 4, 45 = 24 + 21), idle lanes (30 and 20 lanes per row), channel groups that do not divide the channels, and the BASELINE size
+    of config 5 (1080p, 1024 channels, five samples)."""
+    import torch.nn.functional as F
+    from frtm_vos_amd import _hip as H
+    g = torch.Generator().manual_seed(1000 + h + w + C)
+    X = torch.relu(torch.randn(N, C, h, w, generator=g))
+    Z = torch.randn(N, c, h, w, generator=g)
+    K = torch.randn(C, 9, generator=g) * 0.1
+    p2 = torch.randn(c, 9, generator=g) * 0.1
+    t = torch.randn(N, h, w, generator=g)
+    parts = H.lib().frtm_wide_parts(h, w)
+    assert parts > 0 and H.lib().frtm_wide_parts(h, 64) == 0 and H.lib().frtm_wide_parts(h, w + 2) == 0
+    Xd, Zd, Kd, pd, td = (v.to(DEV).contiguous() for v in (X, Z, K, p2, t))
+    # forward
+    sp = torch.full((CS + 1, N, h * w), float('nan'), device=DEV)
+    H.call('frtm_scores_wide', H.ptr(Xd), H.ptr(Kd), C, H.ptr(Zd), H.ptr(pd), c, N, h, w, CS, H.ptr(sp))
+    ref = F.conv2d(X.double(), K.double().view(1, C, 3, 3), padding=1) + F.conv2d(Z.double(), p2.double().view(1, c, 3, 3), padding=1)
+    got = sp.sum(0).view(N, 1, h, w).cpu().double()
+    assert torch.isfinite(sp).all()
+    e = float((got - ref).abs().max() / ref.abs().max())
+    old = torch.empty(4, N, h * w, device=DEV)
+    H.call('frtm_joint_scores_composed', H.ptr(Xd), H.ptr(Kd), C, H.ptr(Zd), H.ptr(pd), c, N, h, w, 3, H.ptr(old))
+    e_old = float((old.sum(0).view(N, 1, h, w).cpu().double() - ref).abs().max() / ref.abs().max())
+    print('scores  %dx%d C=%d: strip form %.2e, round-4 form %.2e (relative max-abs vs float64)' % (h, w, C, e, e_old))
+    assert e < 1e-5 and e <= 4 * e_old + 1e-6
+    # transposed
+    slabs = torch.full((N * parts, C * 9), float('nan'), device=DEV)
+    H.call('frtm_wgrad_wide', H.ptr(Xd), H.ptr(td), N, C, h, w, H.ptr(slabs))
+    tp = F.pad(t.double(), (1, 1, 1, 1))
+    refg = torch.stack([torch.stack([(X.double() * tp[:, None, 2 - dy:2 - dy + h, 2 - dx:2 - dx + w]).sum(dim=(2, 3)) for dx in range(3)], -1)
+                        for dy in range(3)], -2)          # (N, C, 3, 3): X[y][x] * t[y - dy + 1][x - dx + 1]
+    gotg = slabs.view(N, parts, C, 3, 3).sum(1).cpu().double()
+    assert torch.isfinite(slabs).all()
+    eg = float((gotg - refg).abs().max() / refg.abs().max())
+    p_old = int(H.lib().frtm_filter_wgrad_parts_hw(N, C, h * w))
+    if 4 * (h + 2) * (w + 2) <= 64 * 1024:
+        so = torch.empty(N * p_old, C * 9, device=DEV)
+        H.call('frtm_filter_wgrad', H.ptr(Xd), H.ptr(td), N, C, h, w, p_old, H.ptr(so))
+        eg_old = float((so.view(N, p_old, C, 3, 3).sum(1).cpu().double() - refg).abs().max() / refg.abs().max())
+    else:
+        eg_old = float('nan')
+    print('wgrad   %dx%d C=%d: strip form %.2e, round-4 form %.2e' % (h, w, C, eg, eg_old))
+    assert eg < 5e-6
+
+
+def test_joint_fit_on_wide_maps_takes_the_strip_forms_and_agrees_with_the_narrow_forms():
+    """A first-frame fit on a 45 x 80 map (720p) through DiscriminatorLoss / GaussNewtonCG with the strip forms and with FRTM_NO_WIDE's forms:
+    b and one operator application agree to rounding (1e-7); the weights after run((3, 4)) only loosely -- seven truncated CG iterations on random
+    data amplify the summation-order difference to the per-cent level, as they do between any two forms of these operators."""
+    from test_round4_gpu import _joint_case
+    from frtm_vos_amd.model.discriminator import DiscriminatorLoss
+    out = {}
+    try:
+        for wide in (True, False):
+            DiscriminatorLoss.wide_forms = wide
+            mem, prob, opt, w1, w2 = _joint_case(128, 16, 45, 80, 180, 320, 7, False)
+            assert bool(prob.wide_parts) == wide
+            prob.initialize()
+            opt._alloc()
+            b = torch.empty_like(opt._buf[0])
+            prob.linearize(opt.x, b)
+            q = torch.empty_like(b)
+            prob.apply_A(b, q)
+            opt.run((3, 4))
+            out[wide] = (b.clone(), q.clone(), w1.detach().clone(), w2.detach().clone())
+    finally:
+        DiscriminatorLoss.wide_forms = True
+    rel = lambda a, b_: float((a - b_).abs().max() / b_.abs().max())
+    eb, eq = rel(out[True][0], out[False][0]), rel(out[True][1], out[False][1])
+    e1, e2 = rel(out[True][2], out[False][2]), rel(out[True][3], out[False][3])
+    print('wide vs narrow forms: b %.2e, A b %.2e, weights after run((3, 4)): project %.2e filter %.2e' % (eb, eq, e1, e2))
+    assert eb < 2e-5 and eq < 2e-5 and e1 < 0.1 and e2 < 0.1
