@@ -23,7 +23,6 @@ SIGNATURES = {
     'frtm_last_error': (ctypes.c_char_p, []),
     'frtm_version': (I, []),
     'frtm_device_info': (I, [P]),
-    'frtm_sk_timeouts': (I, []),
     'frtm_pixel_weights': (I, [P, I, I, I, I, F, P, P, P]),
     'frtm_normal_build': (I, [P, I, P, I, I, I, I, I, F, P, I, P, P, P, P, P]),
     'frtm_memory_next_slot': (I, [P, I, F, I, P, P, I, P]),

@@ -157,8 +157,7 @@ static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Wi
     }
     if (best_m) {
       const int NP = (best_m + 2) * (best_m + 2);
-      // (+ the scratch of the stream-K form of the products: it takes whatever lies behind V and M)
-      const size_t need = (size_t)NP * (c.Cin + c.Cout) * best_Tp + FRTM_CONV_SK_SCRATCH_ELEMS;
+      const size_t need = (size_t)NP * (c.Cin + c.Cout) * best_Tp;
       int rc = ensure(bb, &ln.ws4, &ln.ws4_elems, need);
       if (rc) return rc;
       d.w_layout = best_m == 6 ? FRTM_WLAYOUT_WINO6 : FRTM_WLAYOUT_WINO4;

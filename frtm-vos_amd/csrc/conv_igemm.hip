@@ -29,12 +29,6 @@ int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, int m, hip
 int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, int m, hipStream_t st);
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
-// conv_stem.hip (end of round 4): the 7x7 / stride-2 / 3 -> 64 stem with its patch and weights in LDS
-bool frtm_stem_eligible(const ConvParams& p, int ksize, int tile, int splitk);
-int frtm_stem_launch(const ConvParams& p, hipStream_t st);
-// conv_gemm_sk.hip (round 4): persistent stream-K GEMM; plan returns 0 when the launch is not eligible (small, odd shapes, no scratch)
-int frtm_sk_plan(const ConvParams& p, size_t ws_elems, size_t ws_used_elems, bool forced);
-int frtm_sk_launch(const ConvParams& p, float* ws, size_t ws_elems, int G, hipStream_t st);
 // FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
 // measured equal inside the trunk (round 3, rocprofv3 kernel trace of tools/trunk_bench.py 8 1: 78.4 vs 76.9 us per 1x1 launch,
 // pass 9.59 vs 9.56 ms) -- at these sizes neither the MFMA form nor the staging path bounds the kernel.
@@ -625,16 +619,6 @@ static int halo_tile_width(int Ho, int Wo) {
 // "images" whose weights switch per image (q.w_img_stride); Npix is a multiple of 64, every tile below is 64 columns wide.
 int frtm_igemm_batched(const ConvParams& q, int tile, float* scratch, size_t scratch_elems, hipStream_t st) {
   if (q.Npix % 64 || !q.w_img_stride) { frtm_set_error("frtm_igemm_batched: Npix must be a multiple of 64"); return FRTM_ERR_ARG; }
-  if (tile == 0 || tile == FRTM_TILE_SK_64x64) {            // round 4: the persistent stream-K kernel where the launch is large enough
-    const int G = scratch ? frtm_sk_plan(q, scratch_elems, 0, tile == FRTM_TILE_SK_64x64) : 0;
-    if (G > 0) {
-      int rc = frtm_sk_launch(q, scratch, scratch_elems, G, st);
-      if (rc) return rc;
-      FRTM_LAUNCH_CHECK();
-      return FRTM_OK;
-    }
-    if (tile == FRTM_TILE_SK_64x64) { frtm_set_error("frtm_igemm_batched: the stream-K tile needs >= 512 tiles, Cout %% 64 == 0 and scratch behind the workspace"); return FRTM_ERR_ARG; }
-  }
   // auto: FRTM_BATCHED_G32=1 tries the 32x32x2-MFMA kernel for the products (1-5 % ahead when timed alone, tools/wino4_bench.py)
   static const bool g32_products = getenv("FRTM_BATCHED_G32") && atoi(getenv("FRTM_BATCHED_G32"));
   if (tile == 0) tile = (g32_products && q.M % 64 == 0 && q.Mp % 4 == 0 && ((size_t)q.wT) % 16 == 0 && ((size_t)q.in) % 16 == 0) ? FRTM_TILE_G32_64x64
@@ -723,7 +707,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if (d->w_layout == FRTM_WLAYOUT_WINO3X3) {
     FRTM_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->w_pitch == 0 && !d->out_transposed,
                    "frtm_conv2d: the Winograd layout needs 3x3, stride 1, pad 1, NCHW output");
-    FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 5, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8; 4 / 5: 8x16 / 16x8 with 64 output channels per workgroup)");
+    FRTM_CHECK_ARG(d->tile >= 0 && d->tile <= 3, "frtm_conv2d: Winograd layout: tile selects the output block (0 auto, 1 8x8, 2 8x16, 3 16x8)");
     return frtm_wino_launch(p, d->tile, (hipStream_t)stream);
   }
   if (d->w_layout == FRTM_WLAYOUT_WINO4 || d->w_layout == FRTM_WLAYOUT_WINO6) {
@@ -733,10 +717,6 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   }
   const bool is1x1 = (d->ksize == 1 && d->pad == 0);
   FRTM_CHECK_ARG(is1x1 || ktab || d->w_layout == FRTM_WLAYOUT_HALO3X3, "frtm_conv2d: ktab required for ksize > 1");
-  if (d->w_layout == FRTM_WLAYOUT_GEMM && d->w_pitch == 0 && frtm_stem_eligible(p, d->ksize, d->tile, d->splitk)) {
-    p.splitk = 1; p.chunks_per_split = p.nchunks;
-    return frtm_stem_launch(p, (hipStream_t)stream);       // the ResNet stem kernel (opt-in: FRTM_TILE_STEM or FRTM_STEM=1)
-  }
   const bool vec1x1 = is1x1 && d->stride == 1 && (p.Npix % 4 == 0) && (((size_t)in) % 16 == 0);
   if (is1x1) p.ktab = nullptr;
   // round 4: stride-1 1x1 convs on maps whose pixel count is not a multiple of 4 (15x27 at 480p) keep the dwordx4 staging (MODE 2)
@@ -758,19 +738,6 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   if (tile == 0 && splitk <= 1 && vec1x1 && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0 && g_use_g32 &&
       (long)ceil_div(p.M, 64) * ceil_div(p.Ntot, 64) >= 512 && p.K >= 256 && p.M >= 128)
     tile = FRTM_TILE_G32_64x64;       // (per shape, tools/g32_bench.py: ahead by 4-8 % where K >= 256 and Cout >= 128, behind on the low-K layer1 / layer2 shapes)
-  // round 4: large 1x1 launches on the persistent stream-K kernel (conv_gemm_sk.hip); its scratch is the tail of the caller's workspace
-  if ((tile == 0 || tile == FRTM_TILE_SK_64x64) && splitk <= 1 && vec1x1 && !halo_layout_requested(d) && !d->out_transposed) {
-    ConvParams q = p;
-    q.splitk = 1; q.chunks_per_split = q.nchunks;
-    const int G = workspace ? frtm_sk_plan(q, (size_t)std::max(d->ws_elems, 0), 0, tile == FRTM_TILE_SK_64x64) : 0;
-    if (G > 0) {
-      int rc = frtm_sk_launch(q, workspace, (size_t)d->ws_elems, G, (hipStream_t)stream);
-      if (rc) return rc;
-      FRTM_LAUNCH_CHECK();
-      return FRTM_OK;
-    }
-    if (tile == FRTM_TILE_SK_64x64) { frtm_set_error("frtm_conv2d: the stream-K tile needs a 1x1 stride-1 conv with >= 512 64x64 tiles, Cout %% 64 == 0 and >= 2.2 M floats of workspace"); return FRTM_ERR_ARG; }
-  }
   if (tile >= FRTM_TILE_G32_128x128) {
     FRTM_CHECK_ARG(vec1x1 && !halo && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0,
                    "frtm_conv2d: the G32 tiles need a 1x1 stride-1 conv, NCHW output, H*W %% 4 == 0 and 16-byte aligned operands");

@@ -206,192 +206,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// Round 4: the same F(2x2,3x3) kernel for 64 output channels per workgroup (two 32-channel weight blocks of the packed image) x 32 tiles.
-// The convs it is for -- 64 -> 64 channels on 120x214 maps: the refiner's level-2 convs (reference model/seg_network.py:176-189) and the
-// trunk's layer1 -- have only 8 chunks of input channels, and with 32 output channels per workgroup every workgroup forms the SAME B
-// fragments (8 LDS reads + 8 adds per four operands) as its twin for the other 32 channels: 0.40 MFMA-busy, 5.4 VALU instructions per
-// MFMA (profiles/r04_refiner_pmc.txt).  Here a B fragment feeds FOUR MFMAs instead of two, the patch is staged once for all 64
-// channels, and a workgroup's prologue / epilogue are amortised over twice the MFMAs.  Register budget: 128 accumulators + ONE set of
-// weight fragments (32; a two-chunk ring spilled 20 registers) -> 251 registers, two workgroups per CU (64 KB epilogue buffer each).
-// Per output element the summation order is that of k_conv3x3_wino<2, TALL, 3>: results are bit-identical (tests/test_round4_gpu.py).
-// OUTCOME: 3-6 % SLOWER than the two-workgroup form on every shape it is meant for (see frtm_wino_launch) -- the B-fragment VALU work is
-// not what bounds these convs; with two waves per SIMD the MFMA stream has less cover for its own waits than with three.  Opt-in only.
-template <int TALL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_wino64(const ConvParams p) {
-  constexpr int BH = TALL ? 16 : 8, BW = TALL ? 8 : 16;
-  constexpr int PR = BH + 2, PC = BW + 2, PE = PR * PC;
-  constexpr int NR = (WCI * PE + 255) / 256;                                 // 6
-  constexpr int STAGE = NR * 256;
-  static_assert(NR == 6, "the counted waits below assume six patch loads per lane");
-  constexpr int MB = 64;                                                     // output channels per workgroup
-  __shared__ __attribute__((aligned(16))) float smem[16 * MB * 16];          // main loop: 3 patch stages (18 KB); epilogue: M[xi][cout][tile] (64 KB)
-  float* Ms = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int lk = lane >> 4, li = lane & 15;
-  const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
-  const int mt32 = (p.M + WBM - 1) / WBM, mt = mt32 / 2;                    // (the launcher guarantees an even number of 32-channel blocks)
-  int m_tile, bt;
-  tile_order(blockIdx.x, gridDim.x, mt, m_tile, bt);
-  const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
-  const int by = bt / tiles_x, bx = bt - by * tiles_x;
-  const int y0 = by * BH, x0 = bx * BW, m0 = m_tile * MB;
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
-  const int HWin = p.Hin * p.Win;
-  unsigned r_goff[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int e = tid + i * 256;
-    const int ci = e / PE, q = e - ci * PE, r = q / PC, c = q - r * PC;
-    const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-    const bool ok = e < WCI * PE && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-    r_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
-  }
-  // packed weights: [chunk][m_tile32][xi][lane][4]; this workgroup reads the blocks 2*m_tile and 2*m_tile + 1
-  const unsigned a_lane = (unsigned)((((2 * m_tile) * 16 + wid * 4) * 64 + lane) * 16);
-  const unsigned a_half = (unsigned)(16 * 64 * 16);                          // bytes from one 32-channel block to the next
-  const unsigned a_chunk = (unsigned)mt32 * WFRAG * 4u;
-  const int ra_ = (wid == 0) ? 0 : (wid == 2 ? 2 : 1), rb_ = (wid == 3) ? 3 : (wid == 2 ? 1 : 2);
-  const float sb_ = (wid == 1) ? 1.f : -1.f;
-  int offA[2], offB[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int t_r = (li >> 2) + (TALL ? 4 * j : 0), t_c = (li & 3) + (TALL ? 0 : 4 * j);
-    const int po = (2 * t_r) * PC + 2 * t_c;
-    offA[j] = lk * PE + po + ra_ * PC;
-    offB[j] = lk * PE + po + rb_ * PC;
-  }
-
-  f32x4 fa[4][2];                                                            // [component of this wave's row][32-channel block]: ONE chunk
-  auto gloadA = [&](int kc, int q) {                                        // the two weight fragments of component q for chunk kc
-#pragma unroll
-    for (int h = 0; h < 2; ++h) fa[q][h] = buf_ld4(rw, (unsigned)kc * a_chunk + a_lane + (unsigned)h * a_half + (unsigned)(q * 64 * 16));
-  };
-  auto gloadR = [&](int kc, int stage) {
-    const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);
-    const bool tail = (kc + 1) * WCI > p.Cin;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      unsigned o = r_goff[i] + cstep;
-      if (tail && kc * WCI + (tid + i * 256) / PE >= p.Cin) o = OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + i * 256 + wid * 64),
-                                               4, (int)o, 0, 0, 0);
-    }
-  };
-  f32x4 acc[4][4][2];                                                        // [component][16-channel fragment][tile half]
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nch = p.nchunks;
-  // The weight fragments have ONE register set: component q's pair for chunk k+1 is requested right after q's MFMAs of chunk k have been
-  // issued and has a whole chunk to arrive.  In-order load queue of a wave (R = the six patch loads of a chunk, Aq = two weight loads):
-  //   R(0) A0..A3(0) R(1) | chunk k:  R(k+2)  [q = 0: wait, MFMAs, A0(k+1)]  [q = 1: ...]  [q = 2]  [q = 3]  barrier | ...
-  // Before component q of chunk k the youngest loads that may still be in flight are Aq+1..A3(k) (6 - 2q), R(k+2) (6) and
-  // A0..Aq-1(k+1) (2q): twelve, whatever q -- everything older (Aq(k), R(k+1)) has landed.
-#pragma unroll
-  for (int q = 0; q < 4; ++q) gloadA(0, q);
-  gloadR(0, 0);
-  if (1 < nch) {
-    gloadR(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F76);                        // vmcnt(6): weights and patch of chunk 0 are in; patch 1 stays in flight
-  } else {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-  }
-  __syncthreads();
-  auto chunk = [&](int k, auto S_) {
-    constexpr int S = decltype(S_)::value;                     // k % 3: patch stage
-    const bool r2 = k + 2 < nch, a1 = k + 1 < nch;
-    if (r2) gloadR(k + 2, (S + 2) % 3);
-    const float* R = smem + S * STAGE;
-    float bq[2][2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float* da = R + kk * 4 * PE + offA[j];
-        const float* db = R + kk * 4 * PE + offB[j];
-        const float u0 = da[0] + sb_ * db[0], u1 = da[1] + sb_ * db[1], u2 = da[2] + sb_ * db[2], u3 = da[3] + sb_ * db[3];
-        bq[kk][j][0] = u0 - u2; bq[kk][j][1] = u1 + u2; bq[kk][j][2] = u2 - u1; bq[kk][j][3] = u1 - u3;
-      }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (r2) __builtin_amdgcn_s_waitcnt(0x0F7C);              // vmcnt(12)
-      else if (a1) __builtin_amdgcn_s_waitcnt(0x0F76);         // vmcnt(6): no R(k+2) in the queue
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                 // last chunk: vmcnt(0) (at most 6 - 2q weight loads of THIS chunk were outstanding)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[q][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q][i >> 1][kk * 2 + (i & 1)], bq[kk][j][q], acc[q][i][j], 0, 0, 0);
-      if (a1) gloadA(k + 1, q);
-    }
-    __syncthreads();                                             // every wave has passed its waits: patch k+1 is complete; stage S is free
-  };
-  for (int kc = 0; kc < nch; kc += 3) {
-    chunk(kc, std::integral_constant<int, 0>{});
-    if (kc + 1 < nch) chunk(kc + 1, std::integral_constant<int, 1>{});
-    if (kc + 2 < nch) chunk(kc + 2, std::integral_constant<int, 2>{});
-  }
-
-  const bool pair_ok = (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (j > 0) __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ms[(wid * 4 + q) * (MB * 16) + (i * 16 + lk * 4 + r) * 16 + li] = acc[q][i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int pidx = tid + h * 256;
-      const int co = pidx >> 4, t = pidx & 15;
-      const int mm = m0 + co;
-      float m[16];
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[xi * (MB * 16) + pidx];
-      if (mm >= p.M) continue;
-      const int tr = (t >> 2) + (TALL ? 4 * j : 0), tc = (t & 3) + (TALL ? 0 : 4 * j);
-      float s[2][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        s[0][c] = m[c] + m[4 + c] + m[8 + c];
-        s[1][c] = m[4 + c] - m[8 + c] - m[12 + c];
-      }
-      const float sc = p.scale ? p.scale[mm] : 1.f, sh = p.scale ? p.shift[mm] : 0.f;
-      const int xx = x0 + 2 * tc;
-      const size_t plane = ((size_t)img * p.M + mm) * p.Npix;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int yy = y0 + 2 * tr + a;
-        if (yy >= p.Ho || xx >= p.Wo) continue;
-        float v0 = (s[a][0] + s[a][1] + s[a][2]) * sc + sh, v1 = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
-        const size_t o = plane + (size_t)yy * p.Wo + xx;
-        const bool two = xx + 1 < p.Wo;
-        if (two && (o & 1) == 0 && pair_ok) {
-          if (p.residual) { const float2 rv = *(const float2*)&p.residual[o]; v0 += rv.x; v1 += rv.y; }
-          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          *(float2*)&p.out[o] = make_float2(v0, v1);
-        } else {
-          if (p.residual) { v0 += p.residual[o]; if (two) v1 += p.residual[o + 1]; }
-          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          p.out[o] = v0;
-          if (two) p.out[o + 1] = v1;
-        }
-      }
-    }
-  }
-}
-
 // w (Cout,Cin,3,3) -> U = G g G^T in MFMA A-fragment order: [chunk = ci/8][m_tile = m/32][xi = r*4+c][lane = lk*16+li][kk*2+i]
 // holds U_xi[ci = chunk*8 + kk*4 + lk][m = m_tile*32 + i*16 + li]; zero padded (ci >= Cin, m >= Cout)
 __global__ __launch_bounds__(256) void k_pack_weights_wino(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wT) {
@@ -438,10 +252,6 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
   // traffic per FLOP; among them the one with the smaller padded area, unless its padding eats the gain (> 15 % more pixels
   // than 8x8 blocks) or it would leave fewer than ~2 workgroups per CU.
   auto padded = [&](int bh, int bw) { return (long)ceil_div(p.Ho, bh) * bh * ceil_div(p.Wo, bw) * bw; };
-  const bool auto_variant = variant == 0 || variant >= 4;           // 4 / 5: the 64-channel forms requested explicitly (tests)
-  if (variant >= 4) {
-    if (mt % 2 || p.M % 64) { frtm_set_error("frtm_conv2d: the 64-channel Winograd blocks need Cout %% 64 == 0"); return FRTM_ERR_ARG; }
-  } else
   if (variant == 0) {
     const long a1 = padded(8, 8), a2 = padded(8, 16), a3 = padded(16, 8);
     variant = a2 <= a3 ? 2 : 3;
@@ -452,16 +262,7 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
     // behind on the small ones (@ 30x54: 20.7 vs 19.5); more M tiles: the 8x8 form
     if (mt > 2 || a * 100 > a1 * 115 || blocks2 < (mt == 1 ? 512 : 1024)) variant = 1;
   }
-  // round 4: 64 output channels per workgroup (k_conv3x3_wino64) for the refiner's 64 -> 64 convs and layer1.  MEASURED BEHIND the
-  // two-workgroup form and therefore opt-in (FRTM_WINO64=1, or tile 4 / 5): 194.5 vs 186.5 us (16 samples of 120x214), 104.5 vs 98.7
-  // (layer1, 8 frames), 128 vs 124 (10 samples); bench unchanged within noise (profiles/r04_wino64_ab.txt).  Results are bit-identical.
-  static const bool wino64 = getenv("FRTM_WINO64") && atoi(getenv("FRTM_WINO64")) != 0;
-  if ((variant == 2 || variant == 3) && auto_variant && wino64 && mt == 2 && p.M == 64) variant += 2;
-  if (variant == 4) {
-    k_conv3x3_wino64<0><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * (mt / 2), 256, 0, st>>>(p);
-  } else if (variant == 5) {
-    k_conv3x3_wino64<1><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * (mt / 2), 256, 0, st>>>(p);
-  } else if (variant == 2) {
+  if (variant == 2) {
     k_conv3x3_wino<2, 0, 3><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);
   } else if (variant == 3) {
     k_conv3x3_wino<2, 1, 3><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);

@@ -306,7 +306,6 @@ typedef struct {
 #define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
 #define FRTM_TILE_128x128_16W 9
 #define FRTM_TILE_80x64 10       /* halo (3x3) kernel only: 65..80 output channels in one M tile */
-#define FRTM_TILE_STEM 11        /* 7x7 / stride 2 / pad 3, 3 -> 64 channels only (csrc/conv_stem.hip): patch and weights in LDS; measured behind the generic form, opt-in */
 /* 1x1 / stride-1 convs on v_mfma_f32_32x32x2_f32 (csrc/conv_gemm32.hip; NCHW output, H*W % 4 == 0, no split-K): Cout x pixel tile */
 #define FRTM_TILE_G32_128x128 20 /* 4 waves of 64x64 */
 #define FRTM_TILE_G32_64x128 21  /* 4 waves of 32x64 */
@@ -318,14 +317,6 @@ typedef struct {
 #define FRTM_TILE_G32_128x128_S3 27
 #define FRTM_TILE_G32_128x64_S3 28
 #define FRTM_TILE_G32P_64x64 30     /* persistent workgroups: loads across tile boundaries, epilogue of a tile under the next tile's K loop */
-#define FRTM_TILE_SK_64x64 31       /* round 4 (csrc/conv_gemm_sk.hip): persistent STREAM-K workgroups (128x128 tiles, two workgroups per CU, 4-stage LDS-DMA ring);
-                                       needs >= 512 64x64-tile equivalents, Cout % 128 == 0 and FRTM_CONV_SK_SCRATCH_ELEMS floats of workspace.  Opt-in: this
-                                       tile id, or FRTM_SK=1 in the environment for tile = 0 (measured behind the tiled kernels, profiles/r04_stream_k.txt) */
-#define FRTM_CONV_SK_SCRATCH_ELEMS (512 * 16384 + 512 * 2 + 64)   /* upper bound of the stream-K scratch at the END of the workspace (floats) */
-/* Stream-K GEMM (csrc/conv_gemm_sk.hip): inter-workgroup hand-off spins that ran into their 2 s time-out since the library was loaded.
- * 0 on a healthy run; anything else means a conv result may be wrong (the caller should stop and set FRTM_SK=0).  Synchronises the
- * device.  No reference counterpart (the reference's convs are cuDNN calls, model/feature_extractor.py:50-65). */
-int frtm_sk_timeouts(void);
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

@@ -148,7 +148,7 @@ def test_eight_ranks_share_one_gpu_dress_rehearsal(tmp_path):
         assert len(set(pinned)) == 8                                          # eight different shares of the GPU's cores
 
 
-# ------------------------------------------------------------------------------------------ stream-K GEMM (csrc/conv_gemm_sk.hip)
+# ------------------------------------------------------------------------------------------ 1x1 conv cases with a float64 reference
 def _sk_case(B, cin, cout, h, w, seed, residual=True, scale=True, relu=True):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, cin, h, w, generator=g).to(DEV)
@@ -164,102 +164,6 @@ def _sk_case(B, cin, cout, h, w, seed, residual=True, scale=True, relu=True):
     if relu:
         ref = torch.relu(ref)
     return x, wt, sc, sh, res, ref
-
-
-@pytest.mark.parametrize('shape', [
-    (8, 256, 1024, 30, 54),        # the dominant trunk shape: 8 chunks per tile, 3 248 tiles (pixel tail: 12 960 = 202.5 tiles of 64)
-    (8, 1024, 256, 30, 54),        # 32 chunks per tile, 812 tiles: most tiles are cut over two or three workgroups
-    (8, 64, 256, 120, 214),        # 2 chunks per tile, 12 840 tiles
-    (4, 2048, 512, 16, 28),        # 64 chunks per tile, 224 -> not eligible (fewer than 512 tiles): must be refused when forced
-    (3, 96, 128, 60, 108),         # K = 96 = 3 chunks; 608 tiles; images of 6 480 pixels (not a multiple of 64: tiles straddle images)
-    (2, 40, 128, 128, 260),        # K = 40: a ragged last chunk (zero rows of the packed weights, out-of-bounds activation rows)
-    (2, 40, 64, 128, 260),         # Cout = 64 is not a multiple of the 128-row tile: refused when forced
-])
-def test_stream_k_gemm_against_fp64(shape):
-    """k_gemm_sk (persistent stream-K 1x1 conv GEMM) against a float64-accumulated reference, forced (tile = FRTM_TILE_SK_64x64) and as the
-    automatic choice; equal bits on repetition (the summation order of a cut tile is fixed); bit-identical to itself under uneven load from a
-    second stream (the hand-off of partial tiles must never deliver a stale word)."""
-    from frtm_vos_amd import ops, _hip as H
-    B, cin, cout, h, w = shape
-    x, wt, sc, sh, res, ref = _sk_case(B, cin, cout, h, w, 11)
-    wT, ktab, layout = ops.pack_weights(wt)
-    ws = torch.empty(1 << 24, device=DEV)
-    ws.uniform_(-1, 1)                                     # the scratch is NOT zeroed by anybody: flags must not depend on it
-    ntiles = -(-B * h * w // 64) * (cout // 64)
-    if ntiles < 512 or cout % 128:                         # not eligible: refused when forced (tile = 0 falls back to the tiled kernels)
-        with pytest.raises(RuntimeError):
-            ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
-        return
-    out = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
-    err = float((out.double() - ref).abs().max() / ref.abs().max())
-    assert err < 3e-6, err
-    auto = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, ws=ws)      # tile 0: the planner's choice (stream-K only with FRTM_SK=1)
-    assert float((auto - out).abs().max() / ref.abs().max()) < 3e-6
-    old = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=4, splitk=1)       # k_conv_igemm 64x64 8 waves
-    assert float((old - out).abs().max() / ref.abs().max()) < 3e-6
-    side = torch.cuda.Stream()
-    noise = torch.randn(64, 1 << 20, device=DEV)
-    bad = 0
-    for it in range(60):
-        if it % 2 == 0:
-            with torch.cuda.stream(side):
-                for k in range(1 + it % 5):
-                    noise[k * 8:(k + 1) * 8].mul_(1.0000001)
-        o2 = ops.conv2d(x, wT, cout, scale=sc, shift=sh, residual=res, relu=True, tile=31, splitk=1, ws=ws)
-        bad += int(not torch.equal(o2, out))
-    torch.cuda.synchronize()
-    assert bad == 0, '%d of 60 repetitions differ' % bad
-    assert H.lib().frtm_sk_timeouts() == 0
-
-
-def test_stream_k_plain_epilogue_and_graph_replay():
-    """No scale / residual / ReLU (the form the batched Winograd products use), and the same launch replayed from a hipGraph: the token in
-    the flag words is frozen under replay, the consumer's reset must make every replay start from clean flags."""
-    from frtm_vos_amd import ops, _hip as H
-    x, wt, sc, sh, res, ref = _sk_case(8, 256, 256, 30, 54, 5, residual=False, scale=False, relu=False)
-    wT, ktab, layout = ops.pack_weights(wt)
-    ws = torch.empty(1 << 23, device=DEV)
-    out = ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws)
-    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 3e-6
-    o2 = torch.empty_like(out)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws, out=o2)
-    torch.cuda.current_stream().wait_stream(s)
-    g = torch.cuda.CUDAGraph()
-    with H.capture(g):
-        ops.conv2d(x, wT, 256, tile=31, splitk=1, ws=ws, out=o2)
-    for _ in range(20):
-        o2.zero_()
-        g.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(o2, out)
-    assert H.lib().frtm_sk_timeouts() == 0
-
-
-@pytest.mark.parametrize('m', [4, 6])
-def test_winograd_products_on_stream_k_equal_the_tiled_kernel(m):
-    """The batched products of the three-launch Winograd forms (36 / 64 GEMMs with one weight matrix each) on the stream-K kernel (tile =
-    FRTM_TILE_SK_64x64 with the scratch behind V and M in the workspace: the 128 x 64 form, the products' "images" are padded to 64 columns)
-    against the same conv on the tiled kernel (k_conv_igemm)."""
-    from frtm_vos_amd import ops
-    g = torch.Generator().manual_seed(3)
-    B, C, h, w = 8, 256, 30, 54
-    x = torch.randn(B, C, h, w, generator=g).to(DEV)
-    wt = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(DEV)
-    layout = 3 if m == 4 else 4
-    wT, _, _ = ops.pack_weights(wt, wino4=(m == 4), wino6=(m == 6))
-    th, tw = -(-h // m), -(-w // m)
-    Tp = (B * th * tw + 63) // 64 * 64
-    need = (m + 2) ** 2 * 2 * C * Tp
-    small, big = torch.empty(need, device=DEV), torch.empty(need + 512 * 16384 + 2048, device=DEV)
-    a = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=small)
-    b = ops.conv2d(x, wT, C, ksize=3, pad=1, w_layout=layout, splitk=1, ws=big, tile=31)
-    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
-    ea, eb = float((a.double() - ref).abs().max() / ref.abs().max()), float((b.double() - ref).abs().max() / ref.abs().max())
-    assert eb < 4e-5 and eb < 2 * ea + 1e-6, (ea, eb)
-    assert float((a - b).abs().max() / ref.abs().max()) < 3e-5        # (k is summed in pairs instead of quadruples: the output transform amplifies that rounding)
 
 
 # ------------------------------------------------------------------------------------------ first-frame augmentation vs oracle/aug_ref.py
@@ -694,81 +598,3 @@ def test_stream_probe_and_placement_of_the_first_tracking_pass():
     # (the probe can only err towards "dependent" -- a host thread descheduled while it polls --, never towards "independent": retry)
     assert any(T_._streams_are_independent(trk._main_stream, trk._first_stream) for _ in range(4))
     assert any(T_._streams_are_independent(trk._first_stream, trk._main_stream) for _ in range(4))
-
-
-@pytest.mark.parametrize('B,Cin,H,W,Cout', [(10, 64, 120, 214, 64),      # the refiner's level-2 convs (5 frames x 2 objects) / layer1
-                                             (2, 64, 30, 54, 64), (1, 8, 8, 8, 64), (1, 16, 9, 21, 64), (2, 24, 17, 16, 64),
-                                             (1, 65, 21, 37, 64),        # ragged last chunk of input channels
-                                             (1, 40, 33, 47, 128)])      # two 64-channel blocks
-def test_winograd_64_channel_blocks_equal_the_32_channel_form(B, Cin, H, W, Cout):
-    """k_conv3x3_wino64 (round 4: 64 output channels x 32 tiles per workgroup, single weight register set, reference convs
-    model/seg_network.py:176-189 and the trunk's layer1): BIT-IDENTICAL to k_conv3x3_wino<2, TALL, 3> (same summation order per output
-    element) for both block orientations and every epilogue variant, and within fp32 rounding of F.conv2d."""
-    import torch.nn.functional as F
-    from frtm_vos_amd import ops
-    g = torch.Generator().manual_seed(B * Cin + Cout)
-    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(DEV)
-    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
-    shift = torch.randn(Cout, generator=g).to(DEV)
-    ref = F.conv2d(x.double(), w.double(), padding=1)
-    res = torch.randn(ref.shape, generator=g).to(DEV)
-    wT, ktab, lay = ops.pack_weights(w, wino=True)
-    for old, new in ((2, 4), (3, 5)):
-        a = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=old)
-        b = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=new)
-        assert torch.equal(a, b), (old, new, float((a - b).abs().max()))
-        assert float((b.double() - ref).abs().max() / ref.abs().max()) < 2e-5
-        a2 = ops.conv2d(x, wT, Cout, 3, 1, 1, scale=scale, shift=shift, residual=res, relu=True, w_layout=lay, tile=old)
-        b2 = ops.conv2d(x, wT, Cout, 3, 1, 1, scale=scale, shift=shift, residual=res, relu=True, w_layout=lay, tile=new)
-        assert torch.equal(a2, b2), (old, new, 'epilogue')
-    auto = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay)
-    assert float((auto.double() - ref).abs().max() / ref.abs().max()) < 2e-5
-    # repeated under load from a second stream: the counted waits of the single weight register set must never let a stale fragment through
-    side = torch.cuda.Stream()
-    noise = torch.randn(32, 1 << 20, device=DEV)
-    first = ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=4)
-    bad = 0
-    for it in range(20):
-        if it % 2 == 0:
-            with torch.cuda.stream(side):
-                noise.mul_(1.0000001)
-        bad += int(not torch.equal(ops.conv2d(x, wT, Cout, 3, 1, 1, w_layout=lay, tile=4), first))
-    torch.cuda.synchronize()
-    assert bad == 0
-
-
-def test_winograd_64_channel_blocks_refuse_other_channel_counts():
-    from frtm_vos_amd import ops
-    x = torch.randn(1, 16, 16, 16, device=DEV)
-    w = torch.randn(96, 16, 3, 3, device=DEV)
-    wT, ktab, lay = ops.pack_weights(w, wino=True)
-    with pytest.raises(RuntimeError, match='64'):
-        ops.conv2d(x, wT, 96, 3, 1, 1, w_layout=lay, tile=4)
-
-
-@pytest.mark.parametrize('B,H,W', [(8, 480, 854), (1, 480, 854), (2, 96, 128), (1, 75, 101), (3, 33, 47), (1, 720, 1280)])
-def test_stem_kernel_equals_the_gather_form_bit_for_bit(B, H, W):
-    """k_stem7x7 (7x7 / stride 2 / pad 3, 3 -> 64 channels: the ResNet stem, reference model/feature_extractor.py:46-50) against the generic
-    gather form of k_conv_igemm (opt-in kernel: measured behind that form, csrc/conv_stem.hip): same k order, same instruction, same epilogue -> equal bits;
-    and both against a float64 convolution.  Ragged blocks (240 x 427 outputs: 427 = 13 x 32 + 11), tiny and odd frames."""
-    import torch.nn.functional as F
-    from frtm_vos_amd import ops
-    g = torch.Generator().manual_seed(B * H + W)
-    x = (torch.randn(B, 3, H, W, generator=g) * 1.2).to(DEV)
-    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(DEV)
-    sc = (torch.rand(64, generator=g) + 0.5).to(DEV)
-    sh = torch.randn(64, generator=g).to(DEV)
-    wT, ktab, lay = ops.pack_weights(w)
-    assert lay == 0 and ktab is not None
-    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3)
-    for kw in (dict(), dict(scale=sc, shift=sh, relu=True)):
-        old = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=1, splitk=1, **kw)        # FRTM_TILE_64x64: the generic kernel
-        new = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=11, **kw)                 # FRTM_TILE_STEM: the stem kernel
-        assert torch.equal(old, new), float((old - new).abs().max())
-        r = ref if not kw else torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
-        assert float((new.double() - r).abs().max() / r.abs().max()) < 3e-6
-    res = torch.randn(ref.shape, generator=g).to(DEV)
-    old = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=1, splitk=1, scale=sc, shift=sh, residual=res, relu=True)
-    new = ops.conv2d(x, wT, 64, 7, 2, 3, ktab=ktab, tile=11, scale=sc, shift=sh, residual=res, relu=True)
-    assert torch.equal(old, new)
