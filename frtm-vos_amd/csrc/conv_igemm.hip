@@ -29,10 +29,6 @@ int frtm_wino4_pack(const float* w_oihw, int Cout, int Cin, float* U, int m, hip
 int frtm_wino4_launch(const ConvParams& p, float* ws, size_t ws_elems, int tile, int m, hipStream_t st);
 // conv_gemm32.hip
 int frtm_g32_launch(const ConvParams& p, int tile, hipStream_t st);
-// FRTM_USE_G32=1: large 1x1 launches take k_conv1x1_g32 (32x32x2 MFMA, operands by LDS-DMA) instead of k_conv_igemm.  Off by default:
-// measured equal inside the trunk (round 3, rocprofv3 kernel trace of tools/trunk_bench.py 8 1: 78.4 vs 76.9 us per 1x1 launch,
-// pass 9.59 vs 9.56 ms) -- at these sizes neither the MFMA form nor the staging path bounds the kernel.
-static const bool g_use_g32 = getenv("FRTM_USE_G32") && atoi(getenv("FRTM_USE_G32"));
 
 #ifdef FRTM_DEBUG_TRACE
 // tools/ktrace.py only (never in the shipped library): every workgroup of k_conv_igemm records where it ran and when its phases began --
@@ -543,8 +539,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 static inline bool halo_layout_requested(const frtm_conv_desc* d) { return d->w_layout == FRTM_WLAYOUT_HALO3X3; }
 
-// FRTM_KPIPE=0: the stride-1 1x1 launches (dwordx4 staging, MODE 1 / 2) of the 8-wave 64x64 and the 32x64 tile keep round 4's K loop (A/B switch)
-static const bool g_kpipe = !(getenv("FRTM_KPIPE") && atoi(getenv("FRTM_KPIPE")) == 0);
+// FRTM_KPIPE=1: the stride-1 1x1 launches (dwordx4 staging, MODE 1 / 2) of the 8-wave 64x64 and the 32x64 tile take the pipelined K loop.  OFF:
+// measured in round 5 on one box, alternating (profiles/r05_kpipe_ab.txt): trunk 16 frames / two lanes 15.36-15.42 ms against 15.17-15.21,
+// one lane 8.77-8.80 against 8.70-8.72, 64-frame bench 561.5 against 566 frames/s; tools/ktrace.py: K loop of a 256 -> 1024 workgroup 14.8 us
+// against 14.3.  The per-chunk drain is not what the K loop waits for (with 3-4 workgroups per CU another workgroup's MFMAs cover it), and
+// the barrier in the middle of the MFMA stream costs more than the drain it removes.
+static const bool g_kpipe = getenv("FRTM_KPIPE") && atoi(getenv("FRTM_KPIPE")) != 0;
 
 template <int BM, int BN, int WGM, int WGN>
 static void launch_tile_u(const ConvParams& p, hipStream_t st) {
@@ -619,10 +619,7 @@ static int halo_tile_width(int Ho, int Wo) {
 // "images" whose weights switch per image (q.w_img_stride); Npix is a multiple of 64, every tile below is 64 columns wide.
 int frtm_igemm_batched(const ConvParams& q, int tile, float* scratch, size_t scratch_elems, hipStream_t st) {
   if (q.Npix % 64 || !q.w_img_stride) { frtm_set_error("frtm_igemm_batched: Npix must be a multiple of 64"); return FRTM_ERR_ARG; }
-  // auto: FRTM_BATCHED_G32=1 tries the 32x32x2-MFMA kernel for the products (1-5 % ahead when timed alone, tools/wino4_bench.py)
-  static const bool g32_products = getenv("FRTM_BATCHED_G32") && atoi(getenv("FRTM_BATCHED_G32"));
-  if (tile == 0) tile = (g32_products && q.M % 64 == 0 && q.Mp % 4 == 0 && ((size_t)q.wT) % 16 == 0 && ((size_t)q.in) % 16 == 0) ? FRTM_TILE_G32_64x64
-                      : (q.M % 64 == 0) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64;
+  if (tile == 0) tile = (q.M % 64 == 0) ? FRTM_TILE_64x64_8W : FRTM_TILE_32x64;
   switch (tile) {
     case FRTM_TILE_128x64: launch_tile<128, 64, 2, 2>(q, true, st); break;
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(q, true, st); break;
@@ -635,10 +632,7 @@ int frtm_igemm_batched(const ConvParams& q, int tile, float* scratch, size_t scr
       if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 128x128 tiles need a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
       if (tile == FRTM_TILE_128x128_8W) launch_tile<128, 128, 2, 4>(q, true, st); else launch_tile<128, 128, 4, 4>(q, true, st);
       break;
-    case FRTM_TILE_G32_128x128:
-      if (q.Npix % 128) { frtm_set_error("frtm_igemm_batched: the 128x128 tiles need a tile count that is a multiple of 128"); return FRTM_ERR_ARG; }
-      // fall through
-    case FRTM_TILE_G32_64x64: case FRTM_TILE_G32_128x64: case FRTM_TILE_G32_64x64_S3: {
+    case FRTM_TILE_G32_64x64: {
       if (q.Mp % 4 || ((size_t)q.wT) % 16 || ((size_t)q.in) % 16) { frtm_set_error("frtm_igemm_batched: G32 tiles need 16-byte aligned operands"); return FRTM_ERR_ARG; }
       int rc = frtm_g32_launch(q, tile, st);
       if (rc) return rc;
@@ -734,11 +728,7 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     halo_tw = halo_tile_width(p.Ho, p.Wo);
   }
   int tile = d->tile, splitk = d->splitk;
-  // (opt-in) launches that fill the chip without split-K on the 32x32x2-MFMA GEMM kernel
-  if (tile == 0 && splitk <= 1 && vec1x1 && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0 && g_use_g32 &&
-      (long)ceil_div(p.M, 64) * ceil_div(p.Ntot, 64) >= 512 && p.K >= 256 && p.M >= 128)
-    tile = FRTM_TILE_G32_64x64;       // (per shape, tools/g32_bench.py: ahead by 4-8 % where K >= 256 and Cout >= 128, behind on the low-K layer1 / layer2 shapes)
-  if (tile >= FRTM_TILE_G32_128x128) {
+  if (tile == FRTM_TILE_G32_64x64) {
     FRTM_CHECK_ARG(vec1x1 && !halo && !d->out_transposed && (((size_t)wT) % 16 == 0) && p.Mp % 4 == 0,
                    "frtm_conv2d: the G32 tiles need a 1x1 stride-1 conv, NCHW output, H*W %% 4 == 0 and 16-byte aligned operands");
     p.splitk = 1; p.chunks_per_split = p.nchunks;

@@ -307,16 +307,7 @@ typedef struct {
 #define FRTM_TILE_128x128_16W 9
 #define FRTM_TILE_80x64 10       /* halo (3x3) kernel only: 65..80 output channels in one M tile */
 /* 1x1 / stride-1 convs on v_mfma_f32_32x32x2_f32 (csrc/conv_gemm32.hip; NCHW output, H*W % 4 == 0, no split-K): Cout x pixel tile */
-#define FRTM_TILE_G32_128x128 20 /* 4 waves of 64x64 */
-#define FRTM_TILE_G32_64x128 21  /* 4 waves of 32x64 */
-#define FRTM_TILE_G32_128x64 22  /* 4 waves of 64x32 */
-#define FRTM_TILE_G32_64x64 23   /* 4 waves of 32x32 */
-#define FRTM_TILE_G32_256x128_8W 24
-#define FRTM_TILE_G32_128x256_8W 25
-#define FRTM_TILE_G32_64x64_S3 26   /* three LDS stages (loads two chunks ahead) */
-#define FRTM_TILE_G32_128x128_S3 27
-#define FRTM_TILE_G32_128x64_S3 28
-#define FRTM_TILE_G32P_64x64 30     /* persistent workgroups: loads across tile boundaries, epilogue of a tile under the next tile's K loop */
+#define FRTM_TILE_G32_64x64 23   /* 4 waves of 32x32 (the only G32 tile left in round 5: the planner's choice for two layer3 GEMMs of the first-frame pass) */
 int frtm_conv_pack_weights(const float* w_oihw, int Cout, int Cin, int ksize, int layout,
                            float* wT, int* ktab, frtm_stream_t stream);
 int frtm_conv2d(const frtm_conv_desc* desc_host, const float* in, const float* wT, const int* ktab,

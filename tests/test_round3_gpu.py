@@ -406,7 +406,7 @@ def test_opt_in_gemm_tiles_match_the_default_kernel(cin, cout, h, w, frames):
             ref = torch.relu(ref)
         kw = dict(scale=sc if scale else None, shift=sh if scale else None, residual=res if residual else None, relu=relu, splitk=1)
         outs = {}
-        for tile in (0, 23, 30):                                     # planner's igemm tile, FRTM_TILE_G32_64x64, FRTM_TILE_G32P_64x64
+        for tile in (0, 23):                                         # planner's igemm tile, FRTM_TILE_G32_64x64
             out = torch.full((frames, cout, h, w), float('nan'), device='cuda')
             ops.conv2d(x, wT, cout, tile=tile, out=out, **kw)
             torch.cuda.synchronize()
@@ -414,12 +414,10 @@ def test_opt_in_gemm_tiles_match_the_default_kernel(cin, cout, h, w, frames):
             err = float((out.double() - ref).abs().max() / ref.abs().max())
             assert err < 5e-6, (tile, scale, residual, relu, err)
             outs[tile] = out
-        assert torch.equal(outs[23], outs[30])
-    # the persistent tile refuses what its addressing cannot do (Cout % 64) instead of computing something else
-    wt2 = (torch.randn(96, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
-    wT2, _, _ = ops.pack_weights(wt2)
-    with pytest.raises(RuntimeError):
-        ops.conv2d(x, wT2, 96, tile=30, splitk=1)
+    # tile ids of forms that were measured slower twice and left the library in round 5 (persistent g32p, stream-K, the stem kernel) fail loudly
+    for gone in (30, 31, 11):
+        with pytest.raises(RuntimeError):
+            ops.conv2d(x, wT, cout, tile=gone, splitk=1)
 
 
 @pytest.mark.parametrize('m', [4, 6])

@@ -7,7 +7,7 @@ try:
     d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), 'valid', d['valid'], 'aborts', d['path_counters']['cg_persistent_aborts'])
 except Exception as e:
     print('NO LINE', e)" ) $(grep -i "invalid" /tmp/fm.err | cut -c1-160)"; }
-for e in "A=1" "FRTM_NO_PERSISTENT_FIRST_FIT=1" "FRTM_NO_PERSISTENT_JOINT=1" "FRTM_NO_WINO4=1" "FRTM_NO_WINO6=1" "FRTM_SK=1" "FRTM_USE_G32=1" "FRTM_BATCHED_G32=1" "FRTM_CONCURRENT_INIT_PASS=1" "FRTM_WINO4_MIN_TILES=100000"; do run "$e" "--objects 3"; done
+for e in "A=1" "FRTM_NO_PERSISTENT_FIRST_FIT=1" "FRTM_NO_PERSISTENT_JOINT=1" "FRTM_NO_WINO4=1" "FRTM_NO_WINO6=1" "FRTM_CONCURRENT_INIT_PASS=1" "FRTM_WINO4_MIN_TILES=100000"; do run "$e" "--objects 3"; done
 for b in resnet18 resnet34 resnet50; do run "A=1" "--backbone $b"; done
 run "FRTM_NO_PERSISTENT_JOINT=1" "--objects 5 --init-lanes 4"
 run "A=1" "--objects 4 --no-persistent-cg"

@@ -19,7 +19,7 @@ LANES = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 Hh = int(sys.argv[3]) if len(sys.argv) > 3 else 480
 Ww = int(sys.argv[4]) if len(sys.argv) > 4 else 854
 NAMES = {0: 'auto', 1: '64x64', 2: '32x64', 3: '128x64', 4: '64x64_8w', 5: '32x64_k64', 6: '64x64_k64', 7: '64x128_8w', 8: '128x128_8w',
-         22: 'g32_128x64', 23: 'g32_64x64', 21: 'g32_64x128', 26: 'g32_64x64_s3', 30: 'g32p_64x64'}
+         23: 'g32_64x64'}
 ext = ResnetFeatureExtractor('resnet101').to('cuda:0')
 ext.reuse_outputs = True
 ext.lanes = LANES
@@ -66,9 +66,9 @@ cur = base
 for key, idxs in sorted(classes.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1] * kv[0][2] ** 2):
     Cout, Cin, ks, stride, last = key
     if ks == 1 and stride == 1:
-        cands = [(t, 0) for t in (2, 1, 4, 5, 6, 7, 3, 8, 23, 22, 21, 26, 30)]
+        cands = [(t, 0) for t in (2, 1, 4, 5, 6, 7, 3, 8, 23)]
     elif ks == 3 and stride == 1:
-        cands = [(t, 0) for t in (4, 2, 1, 7, 3, 8, 23, 22)]            # products of the three-launch forms (1..3 also = fused F(2x2) blocks)
+        cands = [(t, 0) for t in (4, 2, 1, 7, 3, 8, 23)]            # products of the three-launch forms (1..3 also = fused F(2x2) blocks)
     else:
         cands = [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (1, 2), (2, 2), (4, 0)]
     row = []
