@@ -112,8 +112,10 @@ static int ensure(frtm_backbone* bb, float** p, size_t* have, size_t need) {
 // two dominant layer3 GEMMs (9.08 -> 8.92 ms per 9-frame pass).
 // `products`: the launch is the batched GEMM of a three-launch Winograd form (the tile of a 3x3 conv's DIRECT form is never touched).
 static int scanned_tile(const ConvL& c, int B, int Ho, int Wo, bool products) {
+  // Round 5, the exception itself A/B-ed (three alternating runs on one box, tools/trunk_bench.py): 9 frames in two lanes (102 / 127 column tiles per lane)
+  // 8.98-9.03 ms with it against 9.09-9.25 without; 5 frames (51 / 76 tiles) 5.79-5.80 with against 5.69-5.72 without -> from 96 tiles on only.
   const long ntiles = ((long)B * Ho * Wo + 63) / 64;
-  if (ntiles < 64 || ntiles > 130 || c.Cin != 256) return 0;
+  if (ntiles < 96 || ntiles > 130 || c.Cin != 256) return 0;
   if (products) return (c.ks == 3 && c.stride == 1 && c.Cout == 256) ? FRTM_TILE_G32_64x64 : 0;            // (tile counts are padded to 64)
   if (c.ks == 1 && c.stride == 1 && c.Cout == 1024 && ((long)Ho * Wo) % 4 == 0) return FRTM_TILE_G32_64x64;  // (dwordx4 staging needs H*W % 4 == 0)
   return 0;

@@ -374,7 +374,7 @@ def test_per_conv_tile_plan_changes_launches_not_results():
 
 
 def test_scanned_tile_exception_respects_the_kernel_preconditions():
-    """The planner's scanned exception (backbone.hip: scanned_tile -- the 32x32x2-MFMA GEMM kernel for the dominant layer3 GEMMs at 64..130
+    """The planner's scanned exception (backbone.hip: scanned_tile -- the 32x32x2-MFMA GEMM kernel for the dominant layer3 GEMMs at 96..130
     column tiles) must only be taken where that kernel can run: a 272 x 496 frame has 17 x 31 = 527 pixels at stride 16 (not a multiple of
     4: no dwordx4 staging), and 10 frames put the 1x1 convs into the exception's range.  The batched pass equals the frame-by-frame passes."""
     from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
