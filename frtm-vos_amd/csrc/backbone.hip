@@ -338,7 +338,6 @@ int frtm_backbone_destroy(frtm_backbone_t* bb) {
     if (ln.ws) (void)hipFree(ln.ws);
     if (ln.ws4) (void)hipFree(ln.ws4);
     if (ln.done) (void)hipEventDestroy(ln.done);
-    if (ln.stream) (void)hipStreamDestroy(ln.stream);
   }
   if (bb->fork) (void)hipEventDestroy(bb->fork);
   if (bb->fork1) (void)hipEventDestroy(bb->fork1);
@@ -415,6 +414,20 @@ int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable) {
   return FRTM_OK;
 }
 
+// Lane streams are PROCESS-WIDE (per device and lane index) and never destroyed (round 5).  Every trunk used to create its own and destroy them with
+// itself; hipGraphs of later trunks / refiners then crashed inside hipGraphLaunch now and then (twice in ten full test runs of round 5, both in
+// tests that capture trunk graphs after earlier trunks of the process had died) -- the failure class model/seg_network.py: _shared_side_stream
+// documents for the refiner's side stream.  Trunks of one process do not run concurrently, so they can share their lane streams.
+static int lane_stream(int lane, hipStream_t* out) {
+  static hipStream_t pool[16][16] = {};
+  int dev = 0;
+  FRTM_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || lane < 0 || lane >= 16) { frtm_set_error("backbone: no lane stream for device %d lane %d", dev, lane); return FRTM_ERR_ARG; }
+  if (!pool[dev][lane]) FRTM_HIP(hipStreamCreateWithFlags(&pool[dev][lane], hipStreamNonBlocking));
+  *out = pool[dev][lane];
+  return FRTM_OK;
+}
+
 int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
   FRTM_CHECK_ARG(bb && lanes >= 1 && lanes <= 8, "frtm_backbone_set_lanes: lanes must be 1..8");
   // TWO lane sets (round 4): set 0 = lanes [0, n), set 1 = lanes [n, 2n) with their own arenas / scratch / streams, so that two passes
@@ -422,7 +435,7 @@ int frtm_backbone_set_lanes(frtm_backbone_t* bb, int lanes) {
   if ((int)bb->lanes.size() < 2 * lanes) bb->lanes.resize(2 * lanes);
   for (int l = 1; l < 2 * lanes; ++l) {
     Lane& ln = bb->lanes[l];
-    if (!ln.stream) FRTM_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    if (!ln.stream) { int rc = lane_stream(l, &ln.stream); if (rc) return rc; }
     if (!ln.done) FRTM_HIP(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
   }
   if (!bb->fork) FRTM_HIP(hipEventCreateWithFlags(&bb->fork, hipEventDisableTiming));

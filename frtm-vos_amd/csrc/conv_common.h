@@ -14,6 +14,7 @@ struct ConvParams {
   unsigned in_bytes, w_bytes;
   int w_img_stride = 0;     // != 0 (k_conv_igemm MODE 1, batched GEMM): image i multiplies with the weight matrix wT + i * w_img_stride (floats);
                             // Npix must be a multiple of the tile's BN so that no tile straddles two images
+  int epi_pre = 1;          // k_conv_igemm: scale / shift / residual of the epilogue requested before the K loop (0: FRTM_NO_EPIPRE=1, A/B)
 };
 
 constexpr int BK = 32;                 // K granularity of the packed weights / split-K bookkeeping

@@ -170,6 +170,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 :
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- epilogue prefetch (round 5).  Where a thread's share of the output tile is at most two dwordx4 pieces (the 64x64 / 8-wave and 32x64 tiles)
+  // and the launch writes NCHW rows without split-K, everything the epilogue needs from memory -- output offsets (an integer division by the plane
+  // size each), the folded-BN scale / shift of the row and the RESIDUAL values -- is formed / requested right after the first chunk's loads, and
+  // waits in 8-16 registers.  The epilogue used to start these dependent loads after the last MFMA: 4.3 us of a 21.5 us workgroup life for the
+  // 256 -> 1024 convs (tools/ktrace.py), most of it the latency of two residual reads in a row.  Every load is UNCONDITIONAL (out-of-bounds offsets
+  // return zeros at once) so that the compiler can count them: the first LDS store waits for the chunk's operands only (vmcnt(6)), not for these.
+  // Same arithmetic in the same order: results are bit-identical.
+  constexpr int EPI = BM * (BN / 4) / NT;
+  constexpr bool EPI_PRE = MODE == 1 && PIPE == 0 && EPI >= 1 && EPI <= 2 && (BM * (BN / 4)) % NT == 0;
+  f32x4 e_res[EPI_PRE ? EPI : 1];
+  float e_sc[EPI_PRE ? EPI : 1], e_sh[EPI_PRE ? EPI : 1];
+  unsigned e_off[EPI_PRE ? EPI : 1];
+  bool e_pre = false;
+  // two steps: the offsets and the (cached, tiny) scale / shift reads BEFORE the first chunk's operand loads, the residual reads AFTER them --
+  // the load counter retires in order, and the first LDS store must be able to leave both residual reads in flight (vmcnt(2))
+  __amdgpu_buffer_rsrc_t e_rres = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0, 0x00020000);
+  auto epi_prefetch_small = [&]() {
+    if constexpr (EPI_PRE) {
+      const size_t out_bytes = (size_t)p.B * p.M * p.Npix * 4;
+      e_pre = p.epi_pre && p.splitk <= 1 && !p.out_transposed && (((size_t)p.out) % 16 == 0) && (!p.residual || ((size_t)p.residual) % 16 == 0) &&
+              out_bytes < 0x7fffffffull;
+      e_rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, (int)out_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? p.scale : p.out), 0, p.M * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.shift ? p.shift : p.out), 0, p.M * 4, 0x00020000);
+#pragma unroll
+      for (int e = 0; e < EPI; ++e) {
+        const int idx = tid + e * NT;
+        const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+        const int mm = m0 + row, nn = n0 + c4;
+        const bool ok = e_pre && mm < p.M && nn < p.Ntot;
+        const int img = nn / p.Npix, rem = nn - img * p.Npix;
+        e_off[e] = ok ? (unsigned)((((size_t)img * p.M + mm) * p.Npix + rem) * 4) : OOB;
+        const unsigned so = (ok && p.scale) ? (unsigned)mm * 4u : OOB;
+        e_sc[e] = buf_ld1(rsc, so);
+        e_sh[e] = buf_ld1(rsh, so);
+      }
+    }
+  };
+  auto epi_prefetch_res = [&]() {
+    if constexpr (EPI_PRE) {
+      const unsigned keep = p.residual ? 0u : OOB;
+#pragma unroll
+      for (int e = 0; e < EPI; ++e) e_res[e] = buf_ld4(e_rres, e_off[e] | keep);
+    }
+  };
   const int lk = lane >> 4, li = lane & 15;
   if constexpr (PIPE == 2) {
     // Global prefetch TWO chunks ahead (round 5): the operands of chunk c + 2 are requested at the start of chunk c into a second register set
@@ -262,10 +307,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 :
       }
     }
   } else {
-  if (kc0 < kc1) {
-    gload(kc0);
-    lstore(0);
-  }
+  epi_prefetch_small();
+  if (kc0 < kc1) gload(kc0);
+  epi_prefetch_res();
+  if (kc0 < kc1) lstore(0);
   __syncthreads();
   KT_STAMP(1);
   for (int kc = kc0; kc < kc1; ++kc) {
@@ -315,7 +360,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 :
   const bool raw = p.splitk > 1;
   float* dst = raw ? p.ws + (size_t)blockIdx.z * p.M * p.Ntot : p.out;
   const bool vec = (p.Npix % 4 == 0) && !p.out_transposed && (((size_t)dst) % 16 == 0) && (raw || !p.residual || ((size_t)p.residual) % 16 == 0);
-  if (vec) {
+  if (EPI_PRE && e_pre) {
+#pragma unroll
+    for (int e = 0; e < (EPI_PRE ? EPI : 1); ++e) {
+      const int idx = tid + e * NT;
+      const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
+      if (e_off[e] == OOB) continue;
+      f32x4 v = *(const f32x4*)&Cs[row * LDC + c4];
+      if (p.scale) v = v * e_sc[e] + e_sh[e];
+      if (p.residual) v += e_res[e];
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *(f32x4*)((char*)p.out + e_off[e]) = v;
+    }
+  } else if (vec) {
     for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
       const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
       const int mm = m0 + row, nn = n0 + c4;
@@ -737,6 +794,8 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   p.Npix = p.Ho * p.Wo;
   p.Ntot = d->B * p.Npix;
   p.relu = d->relu; p.out_transposed = d->out_transposed;
+  static const bool no_epipre = getenv("FRTM_NO_EPIPRE") != nullptr;
+  p.epi_pre = no_epipre ? 0 : 1;
   p.nchunks = ceil_div(p.K, BK);
   p.Mp = (p.M + 31) / 32 * 32;
   size_t w_bytes = (size_t)p.nchunks * BK * p.Mp * 4;

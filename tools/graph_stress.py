@@ -21,10 +21,13 @@ if len(sys.argv) > 3 and sys.argv[3] == 'tracker':
     torch.set_grad_enabled(False)
     kept = []
     for it in range(N):
-        p = Parameters(None, fast=True, device='cuda:0', feature_extractor='resnet18')
+        p = Parameters(None, fast=True, device='cuda:0', feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
         p.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
         trk = p.get_model().eval()
         trk.refiner.capture_after = 0
+        if os.environ.get('GRAPH_TRUNK'):          # trunk passes as hipGraphs too (lanes fork to the library's lane streams inside the capture)
+            trk.graph_trunk = True
+            trk.feature_extractor.capture_after = 0
         seq = SyntheticSequence('s', 11 + it % 3, (96 + 32 * (it % 2), 160), 1 + it % 3, seed=it)
         seq.preload('cuda:0')
         out, fps = trk.run_sequence(seq)
