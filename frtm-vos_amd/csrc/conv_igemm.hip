@@ -48,12 +48,10 @@ __device__ unsigned g_kt_n[288];          // records per CU (xcc * 36 + se * 9 +
 //         dword alignment (buffer loads only force dword alignment).  A lane's four columns n .. n+3 of the flattened (image, pixel) axis
 //         either lie in one image row -- one dwordx4 -- or straddle the end of an image: those lanes (one per image boundary) take four
 //         dword loads, the wrapped columns from the next image.  Results are those of MODE 0 / 1 bit for bit (same k order per column).
-// PIPE = 1 (round 5): the K loop as ONE software pipeline across chunk boundaries -- fragment reads run two k-steps ahead of their MFMAs in a
-//         ring of four register sets, and the next chunk is staged into LDS (and the barrier taken) before the LAST TWO k-steps of the
-//         current chunk, whose MFMAs then cover the first fragment reads of the next chunk: the per-chunk drain (ds_write, barrier, a full LDS
-//         round trip before the first MFMA) of PIPE = 0 disappears.  Same k order per output element: results are bit-identical.
-template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32, int PIPE = 0>
-__global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 : 1) void k_conv_igemm(const ConvParams p) {
+// (Round 5 built two more forms of the K loop -- fragment reads two k-steps ahead across chunk boundaries, and operand loads two chunks ahead -- verified
+//  them bit-identical and measured them at -1 % / +-0 %: tools/archive/conv_igemm_kloop_variants.hip.txt, profiles/r05_kpipe_ab.txt.)
+template <int BM, int BN, int WGM, int WGN, int MODE, int BKT = 32>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams p) {
   constexpr int BK = BKT;                                // chunk depth of this instantiation (32 or 64)
   constexpr int NT = 64 * WGM * WGN;
   constexpr int LDA = BM + 16, LDB = BN + 16;          // LD % 32 == 16: the two k rows a 32-lane group reads never share a bank
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 :
   // return zeros at once) so that the compiler can count them: the first LDS store waits for the chunk's operands only (vmcnt(6)), not for these.
   // Same arithmetic in the same order: results are bit-identical.
   constexpr int EPI = BM * (BN / 4) / NT;
-  constexpr bool EPI_PRE = MODE == 1 && PIPE == 0 && EPI >= 1 && EPI <= 2 && (BM * (BN / 4)) % NT == 0;
+  constexpr bool EPI_PRE = MODE == 1 && EPI >= 1 && EPI <= 2 && (BM * (BN / 4)) % NT == 0;
   f32x4 e_res[EPI_PRE ? EPI : 1];
   float e_sc[EPI_PRE ? EPI : 1], e_sh[EPI_PRE ? EPI : 1];
   unsigned e_off[EPI_PRE ? EPI : 1];
@@ -216,97 +214,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (PIPE == 2 && WGM * WGN == 8) ? 8 :
     }
   };
   const int lk = lane >> 4, li = lane & 15;
-  if constexpr (PIPE == 2) {
-    // Global prefetch TWO chunks ahead (round 5): the operands of chunk c + 2 are requested at the start of chunk c into a second register set
-    // and reach LDS at the end of chunk c + 1 -- the memory latency budget of a workgroup doubles (PMC and ktrace of the 256 -> 1024 GEMM: a
-    // chunk takes a workgroup 4000 cycles where its share of the matrix pipes accounts for ~3100: it waits for its loads).  Same k order.
-    static_assert(MODE != 0, "dwordx4 staging only");
-    f32x4 ra1[PA], rb41[PB4];
-    auto chunk_mfma = [&](int cur) {
-      float af[2][FM], bf[2][FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[0][i] = As[cur][lk][wm * TM + i * 16 + li];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[0][j] = Bs[cur][lk][wn * TN + j * 16 + li];
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        if (kk + 1 < BK / 4) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = As[cur][(kk + 1) * 4 + lk][wm * TM + i * 16 + li];
-#pragma unroll
-          for (int j = 0; j < FN; ++j) bf[(kk + 1) & 1][j] = Bs[cur][(kk + 1) * 4 + lk][wn * TN + j * 16 + li];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // Every load and every LDS store below is UNCONDITIONAL (chunks beyond this launch's range read rows the bounds checks zero, or a neighbour
-    // split's rows, into registers / an LDS buffer nobody reads): with conditional loads the compiler cannot count the newer loads in flight
-    // and drains them all at every LDS store (vmcnt(0)), which is the wait this form exists to avoid.
-    gload_to(kc0, ra, rb4);
-    gload_to(kc0 + 1, ra1, rb41);
-    lstore_from(0, ra, rb4);
-    __syncthreads();
-    KT_STAMP(1);
-    for (int kc = kc0; kc < kc1; kc += 2) {
-      gload_to(kc + 2, ra, rb4);                            // LDS buffer 0 = chunk kc, set 1 = chunk kc + 1 (in flight), set 0 is free
-      chunk_mfma(0);
-      lstore_from(1, ra1, rb41);
-      __syncthreads();
-      if (kc + 1 >= kc1) break;
-      gload_to(kc + 3, ra1, rb41);                          // buffer 1 = chunk kc + 1, set 0 = chunk kc + 2, set 1 is free
-      chunk_mfma(1);
-      lstore_from(0, ra, rb4);
-      __syncthreads();
-    }
-  } else if constexpr (PIPE == 1) {
-    constexpr int KS = BK / 4;                             // k-steps per chunk
-    static_assert(KS >= 4 && KS % 4 == 0, "ring of four");
-    float af[4][FM], bf[4][FN];
-    auto rd = [&](int buf, int ks, int slot) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[slot][i] = As[buf][ks * 4 + lk][wm * TM + i * 16 + li];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[slot][j] = Bs[buf][ks * 4 + lk][wn * TN + j * 16 + li];
-    };
-    if (kc0 < kc1) {
-      gload(kc0);
-      lstore(0);
-    }
-    __syncthreads();
-    KT_STAMP(1);
-    if (kc0 < kc1) {
-      if (kc0 + 1 < kc1) gload(kc0 + 1);
-      rd(0, 0, 0);
-      rd(0, 1, 1);
-    }
-    for (int kc = kc0; kc < kc1; ++kc) {
-      const int cur = (kc - kc0) & 1;
-      const bool more = (kc + 1) < kc1;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        if (kk == KS - 2) {
-          // every fragment read of this chunk has been issued (steps KS-2, KS-1 at kk = KS-4, KS-3): the other buffer takes the next chunk,
-          // one barrier, and the loads of the chunk after it start
-          if (more) lstore(cur ^ 1);
-          __syncthreads();
-          if (kc + 2 < kc1) gload(kc + 2);
-        }
-        if (kk + 2 < KS) rd(cur, kk + 2, (kk + 2) & 3);
-        else if (more) rd(cur ^ 1, kk + 2 - KS, (kk + 2) & 3);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 3][i], bf[kk & 3][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  } else {
+  {
   epi_prefetch_small();
   if (kc0 < kc1) gload(kc0);
   epi_prefetch_res();
@@ -645,29 +553,16 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 static inline bool halo_layout_requested(const frtm_conv_desc* d) { return d->w_layout == FRTM_WLAYOUT_HALO3X3; }
 
-// FRTM_KPIPE=1: the stride-1 1x1 launches (dwordx4 staging, MODE 1 / 2) of the 8-wave 64x64 and the 32x64 tile take the pipelined K loop.  OFF:
-// measured in round 5 on one box, alternating (profiles/r05_kpipe_ab.txt): trunk 16 frames / two lanes 15.36-15.42 ms against 15.17-15.21,
-// one lane 8.77-8.80 against 8.70-8.72, 64-frame bench 561.5 against 566 frames/s; tools/ktrace.py: K loop of a 256 -> 1024 workgroup 14.8 us
-// against 14.3.  The per-chunk drain is not what the K loop waits for (with 3-4 workgroups per CU another workgroup's MFMAs cover it), and
-// the barrier in the middle of the MFMA stream costs more than the drain it removes.
-static const int g_kpipe = getenv("FRTM_KPIPE") ? atoi(getenv("FRTM_KPIPE")) : 0;     // 1: pipelined K loop, 2: global prefetch two chunks ahead
-
 template <int BM, int BN, int WGM, int WGN>
 static void launch_tile_u(const ConvParams& p, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
-  constexpr bool piped = (BM == 64 && BN == 64 && WGM == 2 && WGN == 4) || (BM == 32 && BN == 64 && WGM == 1 && WGN == 4);
-  if (piped && g_kpipe == 1) k_conv_igemm<BM, BN, WGM, WGN, 2, 32, piped ? 1 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else if (piped && g_kpipe == 2) k_conv_igemm<BM, BN, WGM, WGN, 2, 32, piped ? 2 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT = 32>
 static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
-  constexpr bool piped = BKT == 32 && ((BM == 64 && BN == 64 && WGM == 2 && WGN == 4) || (BM == 32 && BN == 64 && WGM == 1 && WGN == 4));
-  if (vec1x1 && piped && g_kpipe == 1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT, piped ? 1 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else if (vec1x1 && piped && g_kpipe == 2) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT, piped ? 2 : 0><<<g, 64 * WGM * WGN, 0, st>>>(p);
-  else if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
+  if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv_igemm<BM, BN, WGM, WGN, 0, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
