@@ -20,6 +20,16 @@
 #include "../../include/frtm_hip.h"
 #include "conv_common.h"
 
+#ifdef FRTM_DEBUG_TRACE
+// tools/ktrace.py only (never in the shipped library): per-workgroup phase stamps of k_conv3x3_wino, as in conv_igemm.hip
+__device__ unsigned long long* g_ktw_buf = nullptr;
+__device__ unsigned g_ktw_cap = 0;
+__device__ unsigned g_ktw_n[288];
+#define KTW_STAMP(i) do { if (threadIdx.x == 0) kt[i] = wall_clock64(); } while (0)
+#else
+#define KTW_STAMP(i) do { } while (0)
+#endif
+
 constexpr int WCI = 8;                 // input channels per chunk
 constexpr int WBM = 32;                // output channels per workgroup
 constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight block: [xi][lane][(kk,i)]
@@ -44,17 +54,44 @@ constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight b
 // 3 workgroups per CU for FN = 1, 228 / 2 for FN = 2): trunk 118.1 -> 118.6 TF (two lanes), 105.8 -> 107.7 (one lane); the
 // refiner, whose single-M-tile convs take the FN = 2 forms, 31.6 -> 29.7 ms per 63 frames.  Occupancy is not what bounds the
 // trunk's convs: three structurally different variants (3 or 4 workgroups per CU, 8x8 or 8x16 blocks) run at the same rate.
+// Round 5 (per-workgroup phase stamps, tools/ktrace.py wino: of a 23 us workgroup life the K loop took 13.7 us -- 1.7 us per chunk against
+// 0.43 us of MFMA issue -- and the epilogue 6.2 us, 8.4 with a residual):
+//  * K loop: the loads of chunk k+2 were issued under `if (k + 2 < nch)`; counting the loads in flight behind the weight registers of chunk k
+//    the compiler had to assume the branch NOT taken and emitted s_waitcnt vmcnt(3) / (1) / (0) in front of the chunk's MFMAs -- which, with the
+//    branch taken, waits for the prefetch issued a few instructions earlier: every chunk paid a full L2 latency.  Now every chunk issues its
+//    NR + 4 loads unconditionally (past the end they are out of bounds: nothing is fetched, an unused stage receives zeros) and the counts are
+//    exact.  The compiler also orders every LDS read after every earlier LDS-DMA load (it cannot tell the stages apart: vmcnt(4) in front of
+//    each barrier, i.e. the patch of chunk k+2 had to land within chunk k); the B-fragment reads are therefore inline asm with their own
+//    lgkmcnt waits, and the barrier of a chunk waits only for patch k+1 (vmcnt(NR + 8)).
+//  * the input descriptor covers ONE image: channels past Cin (the tail chunk of a 65-channel conv, the chunks past the end) are out of
+//    bounds by themselves -- no per-load channel test;
+//  * epilogue: the column half of the output transform happens in registers (16 -> 8 planes), the planes are written as [plane][tile][cout]
+//    with one ds_write_b128 per accumulator (pitch 36: conflict-free), both tile groups in one exchange (one barrier instead of three), a
+//    thread then owns 4 consecutive output channels of one tile (8 x ds_read_b128); scale / shift / RESIDUAL are requested before the exchange.
+//    The output transform sums columns first, rows second (the earlier form rows first): rounding-level differences to round 4's results.
+__device__ __forceinline__ f32x4 lds_rd4(unsigned byte_addr) {      // 4 consecutive floats at an 8-byte aligned LDS address
+  f32x4 v;
+  asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+
 template <int FN, int TALL, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_conv3x3_wino(const ConvParams p) {
   constexpr int BH = (FN == 2 && TALL) ? 16 : 8, BW = (FN == 2 && !TALL) ? 16 : 8;
   constexpr int PR = BH + 2, PC = BW + 2, PE = PR * PC;
   constexpr int NR = (WCI * PE + 255) / 256;                                 // 4 (8x8 block) or 6 (32-tile blocks)
   constexpr int STAGE = NR * 256;                                            // floats per patch stage, lane-linear
-  static_assert(3 * STAGE <= 16 * WBM * 16, "patch stages must fit the epilogue buffer");
-  __shared__ __attribute__((aligned(16))) float smem[16 * WBM * 16];       // main loop: 3 patch stages; epilogue: M[xi][cout][tile]
-  float* Ms = smem;
+  // epilogue planes: [wave = transformed row][b = output column][tile group j][tile li][cout], cout pitch CP, group j shifted by 16 banks
+  constexpr int CP = 36, JOFF = 16 * CP + 16, PLANE = FN * 16 * CP + (FN - 1) * 16;
+  constexpr int CQ = FN == 2 ? 4 : 2;                                        // output channels per thread in the output phase
+  constexpr int SMEM = 8 * PLANE > 3 * STAGE ? 8 * PLANE : 3 * STAGE;        // 37.4 KB (32 tiles) / 18.4 KB (16 tiles)
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];                // main loop: 3 patch stages; epilogue: the planes
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lk = lane >> 4, li = lane & 15;
+#ifdef FRTM_DEBUG_TRACE
+  unsigned long long kt[4] = {0, 0, 0, 0}, kt_wait = 0, kt_bar = 0;
+#endif
+  KTW_STAMP(0);
   const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
   const int mt = (p.M + WBM - 1) / WBM;
   int m_tile, bt;
@@ -62,9 +99,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
   const int by = bt / tiles_x, bx = bt - by * tiles_x;
   const int y0 = by * BH, x0 = bx * BW, m0 = m_tile * WBM;
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
+  const unsigned img_bytes = (unsigned)p.Cin * (unsigned)HWin * 4u;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)img * p.Cin * HWin), 0, (int)img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   unsigned r_goff[NR];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
@@ -72,36 +110,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const int ci = e / PE, q = e - ci * PE, r = q / PC, c = q - r * PC;
     const int yy = y0 - 1 + r, xx = x0 - 1 + c;
     const bool ok = e < WCI * PE && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-    r_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
+    r_goff[i] = ok ? (unsigned)((ci * HWin + yy * p.Win + xx) * 4) : OOB;
   }
   const unsigned a_lane = (unsigned)(((m_tile * 16 + wid * 4) * 64 + lane) * 16);
   const unsigned a_chunk = (unsigned)mt * WFRAG * 4u;
   const int ra_ = (wid == 0) ? 0 : (wid == 2 ? 2 : 1), rb_ = (wid == 3) ? 3 : (wid == 2 ? 1 : 2);
   const float sb_ = (wid == 1) ? 1.f : -1.f;
-  int offA[FN], offB[FN];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 sb2 = {sb_, sb_};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;      // LDS byte address of smem
+  unsigned offA[FN], offB[FN];                                                                 // LDS byte addresses inside stage 0, k-step 0
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int t_r = (li >> 2) + ((FN == 2 && TALL) ? 4 * j : 0), t_c = (li & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
     const int po = (2 * t_r) * PC + 2 * t_c;
-    offA[j] = lk * PE + po + ra_ * PC;
-    offB[j] = lk * PE + po + rb_ * PC;
+    offA[j] = lds0 + (unsigned)(lk * PE + po + ra_ * PC) * 4u;
+    offB[j] = lds0 + (unsigned)(lk * PE + po + rb_ * PC) * 4u;
   }
 
-  f32x4 fa[3][4];
+  f32x4 fa[2][4];
   auto gloadA = [&](int kc, f32x4* dst) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = buf_ld4(rw, (unsigned)kc * a_chunk + a_lane + (unsigned)(q * 64 * 16));
   };
   auto gloadR = [&](int kc, int stage) {                   // NR x buffer_load_dword ... lds per lane: this wave's NR x 64 words
-    const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);
-    const bool tail = (kc + 1) * WCI > p.Cin;
+    const unsigned cstep = (unsigned)(kc * WCI) * (unsigned)(HWin * 4);      // channels >= Cin: beyond the image's descriptor = zeros
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      unsigned o = r_goff[i] + cstep;
-      if (tail && kc * WCI + (tid + i * 256) / PE >= p.Cin) o = OOB;
+    for (int i = 0; i < NR; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + i * 256 + wid * 64),
-                                               4, (int)o, 0, 0, 0);
-    }
+                                               4, (int)(r_goff[i] + cstep), 0, 0, 0);
   };
   f32x4 acc[4][2][FN];
 #pragma unroll
@@ -111,99 +148,153 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Load queue (vmcnt counts loads in issue order): chunk k issues A(k+1) -- the weights of the next chunk, 4 loads -- and then R(k+2), the
+  // patch two chunks ahead, NR loads.  Patches ring through three LDS stages (runtime index), weights through two register sets (F = k & 1).
   const int nch = p.nchunks;
-  gloadR(0, 0); gloadA(0, fa[0]);
-  if (1 < nch) {
-    gloadR(1, 1); gloadA(1, fa[1]);
-    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);  // vmcnt(NR + 4): patch 0 of this wave is in LDS, the loads of chunk 1 stay in flight
-  } else {
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) (expcnt / lgkmcnt untouched)
-  }
-  __syncthreads();
-  auto chunk = [&](int k, auto S_) {
-    constexpr int S = decltype(S_)::value;                  // k % 3
-    if (k + 2 < nch) { gloadR(k + 2, (S + 2) % 3); gloadA(k + 2, fa[(S + 2) % 3]); }
-    const float* R = smem + S * STAGE;
+  // (sched_barrier: the manual vmcnt values below count loads in THIS order; without the fences the scheduler had moved the patch loads in front
+  //  of the weight loads in one of the two unrolled chunks)
+  gloadA(0, fa[0]); __builtin_amdgcn_sched_barrier(0); gloadR(0, 0); gloadR(1, 1); __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F74 : 0x0F76);    // vmcnt(NR): weights and patch of chunk 0 have arrived, patch 1 stays in flight
+  __builtin_amdgcn_s_barrier();
+  KTW_STAMP(1);
+  auto chunk = [&](int k, int st, auto F_) {
+    constexpr int F = decltype(F_)::value;                  // k & 1
+    gloadA(k + 1, fa[F ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    gloadR(k + 2, st == 0 ? 2 : st - 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      const unsigned so = (unsigned)((st * STAGE + kk * 4 * PE) * 4);
+      f32x4 da[FN], db[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) { da[j] = lds_rd4(offA[j] + so); db[j] = lds_rd4(offB[j] + so); }
+      if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da[0]), "+v"(db[0]), "+v"(da[1]), "+v"(db[1]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da[0]), "+v"(db[0]));
       float bq[FN][4];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const float* da = R + kk * 4 * PE + offA[j];
-        const float* db = R + kk * 4 * PE + offB[j];
-        const float u0 = da[0] + sb_ * db[0], u1 = da[1] + sb_ * db[1], u2 = da[2] + sb_ * db[2], u3 = da[3] + sb_ * db[3];
-        bq[j][0] = u0 - u2; bq[j][1] = u1 + u2; bq[j][2] = u2 - u1; bq[j][3] = u1 - u3;
+      for (int j = 0; j < FN; ++j) {                      // B^T d B of this lane's (channel, tile), row wid: two-float operations on register pairs
+        const f32x2 u01 = da[j].lo + sb2 * db[j].lo, u23 = da[j].hi + sb2 * db[j].hi;
+        const f32x2 d = u01 - u23;                        // (u0 - u2, u1 - u3)
+        bq[j][0] = d.x; bq[j][1] = u01.y + u23.x; bq[j][2] = u23.x - u01.y; bq[j][3] = d.y;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-          acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][q][kk * 2 + 0], bq[j][q], acc[q][0][j], 0, 0, 0);
-          acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][q][kk * 2 + 1], bq[j][q], acc[q][1][j], 0, 0, 0);
+          acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][kk * 2 + 0], bq[j][q], acc[q][0][j], 0, 0, 0);
+          acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][kk * 2 + 1], bq[j][q], acc[q][1][j], 0, 0, 0);
         }
     }
-    // patch k+1 (issued one chunk ago) must have landed before anyone reads it; newer than it in the in-order queue are the
-    // weight loads of k+1 (4) and, if issued, the NR + 4 loads of k+2
-    if (k + 2 < nch) __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F7C : 0x0F7E);   // vmcnt(NR + 8): 12 / 14 newer loads may stay in flight
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
-    __syncthreads();
+    // patch k+1 (issued one chunk ago) must have landed before anyone reads it; newer than it in the queue are A(k+1) and R(k+2), which may
+    // stay in flight.  This wave's LDS reads of the current stage are complete (lgkmcnt(0) above).
+#ifdef FRTM_DEBUG_TRACE
+    const unsigned long long tq0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);
+    const unsigned long long tq1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long tq2 = __builtin_amdgcn_s_memrealtime();
+    kt_wait += tq1 - tq0; kt_bar += tq2 - tq1;
+#else
+    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);   // vmcnt(NR + 4)
+    __builtin_amdgcn_s_barrier();
+#endif
   };
-  for (int kc = 0; kc < nch; kc += 3) {
-    chunk(kc, std::integral_constant<int, 0>{});
-    if (kc + 1 < nch) chunk(kc + 1, std::integral_constant<int, 1>{});
-    if (kc + 2 < nch) chunk(kc + 2, std::integral_constant<int, 2>{});
+  // (a loop body without exits, then the chunk left over: exits inside the body made the loop header reachable with weight loads the compiler
+  //  had not seen consumed, and it waited for vmcnt(0) there)
+  int kc = 0, st = 0;
+  for (; kc + 2 <= nch; kc += 2) {
+    chunk(kc, st, std::integral_constant<int, 0>{});
+    st = st == 2 ? 0 : st + 1;
+    chunk(kc + 1, st, std::integral_constant<int, 1>{});
+    st = st == 2 ? 0 : st + 1;
   }
+  if (kc < nch) chunk(kc, st, std::integral_constant<int, 0>{});
+  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): the zero patches past the end have landed before the stages are re-used
+  __syncthreads();
+  KTW_STAMP(2);
 
+  // ---- epilogue ----
+  // output phase: thread -> (tile tx, ty of the block; CQ output channels)
+  constexpr int TW = BW / 2, TH = BH / 2, TILES = TW * TH;
+  const int tx = tid % TW, ty = (tid / TW) % TH, cq = tid / TILES;
+  const int ej = FN == 2 ? (TALL ? ty >> 2 : tx >> 2) : 0, eli = (ty & 3) * 4 + (tx & 3);
+  const int mm0 = m0 + cq * CQ;
+  const int xx = x0 + 2 * tx, yy0 = y0 + 2 * ty;
+  const bool two = xx + 1 < p.Wo;
   const bool pair_ok = (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
+  float sc[CQ], sh[CQ];
+  float2 rv[CQ][2];
+  size_t oo[CQ];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    if (j > 0) __syncthreads();
+  for (int c = 0; c < CQ; ++c) {
+    const int mm = mm0 + c;
+    const bool okc = mm < p.M;
+    sc[c] = (p.scale && okc) ? p.scale[mm] : 1.f;
+    sh[c] = (p.scale && okc) ? p.shift[mm] : 0.f;
+    oo[c] = ((size_t)img * p.M + mm) * p.Npix + (size_t)yy0 * p.Wo + xx;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ms[(wid * 4 + q) * 512 + (i * 16 + lk * 4 + r) * 16 + li] = acc[q][i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int pidx = tid + h * 256;
-      const int co = pidx >> 4, t = pidx & 15;
-      const int mm = m0 + co;
-      float m[16];
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[xi * 512 + pidx];
-      if (mm >= p.M) continue;
-      const int tr = (t >> 2) + ((FN == 2 && TALL) ? 4 * j : 0), tc = (t & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
-      float s[2][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        s[0][c] = m[c] + m[4 + c] + m[8 + c];
-        s[1][c] = m[4 + c] - m[8 + c] - m[12 + c];
-      }
-      const float sc = p.scale ? p.scale[mm] : 1.f, sh = p.scale ? p.shift[mm] : 0.f;
-      const int xx = x0 + 2 * tc;
-      const size_t plane = ((size_t)img * p.M + mm) * p.Npix;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int yy = y0 + 2 * tr + a;
-        if (yy >= p.Ho || xx >= p.Wo) continue;
-        float v0 = (s[a][0] + s[a][1] + s[a][2]) * sc + sh, v1 = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
-        const size_t o = plane + (size_t)yy * p.Wo + xx;
-        const bool two = xx + 1 < p.Wo;
-        if (two && (o & 1) == 0 && pair_ok) {
-          if (p.residual) { const float2 rv = *(const float2*)&p.residual[o]; v0 += rv.x; v1 += rv.y; }
-          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          *(float2*)&p.out[o] = make_float2(v0, v1);
-        } else {
-          if (p.residual) { v0 += p.residual[o]; if (two) v1 += p.residual[o + 1]; }
-          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          p.out[o] = v0;
-          if (two) p.out[o + 1] = v1;
-        }
+    for (int a = 0; a < 2; ++a) {
+      rv[c][a] = make_float2(0.f, 0.f);
+      if (p.residual && okc && yy0 + a < p.Ho && xx < p.Wo) {
+        const size_t o = oo[c] + (size_t)a * p.Wo;
+        if (two && (o & 1) == 0 && pair_ok) rv[c][a] = *(const float2*)&p.residual[o];
+        else { rv[c][a].x = p.residual[o]; if (two) rv[c][a].y = p.residual[o + 1]; }
       }
     }
   }
+  // column half of the output transform in registers: (M A)[row = wid][b], b = 0: m0 + m1 + m2, b = 1: m1 - m2 - m3
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const f32x4 c0 = acc[0][i][j] + acc[1][i][j] + acc[2][i][j], c1 = acc[1][i][j] - acc[2][i][j] - acc[3][i][j];
+      float* d = smem + j * JOFF + li * CP + i * 16 + lk * 4;
+      *(f32x4*)(d + (wid * 2 + 0) * PLANE) = c0;
+      *(f32x4*)(d + (wid * 2 + 1) * PLANE) = c1;
+    }
+  __syncthreads();
+  typedef float fq __attribute__((ext_vector_type(CQ)));
+  fq P[4][2];
+  const float* src = smem + ej * JOFF + eli * CP + cq * CQ;
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) P[w][b] = *(const fq*)(src + (w * 2 + b) * PLANE);
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) {
+    if (mm0 + c >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if (yy0 + a >= p.Ho || xx >= p.Wo) continue;
+      // row half: a = 0: r0 + r1 + r2, a = 1: r1 - r2 - r3
+      float v0, v1;
+      if (a == 0) { v0 = P[0][0][c] + P[1][0][c] + P[2][0][c]; v1 = P[0][1][c] + P[1][1][c] + P[2][1][c]; }
+      else { v0 = P[1][0][c] - P[2][0][c] - P[3][0][c]; v1 = P[1][1][c] - P[2][1][c] - P[3][1][c]; }
+      v0 = v0 * sc[c] + sh[c] + rv[c][a].x;
+      v1 = v1 * sc[c] + sh[c] + rv[c][a].y;
+      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      const size_t o = oo[c] + (size_t)a * p.Wo;
+      if (two && (o & 1) == 0 && pair_ok) *(float2*)&p.out[o] = make_float2(v0, v1);
+      else { p.out[o] = v0; if (two) p.out[o + 1] = v1; }
+    }
+  }
+#ifdef FRTM_DEBUG_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && g_ktw_buf) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xccid = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    const unsigned key = (xccid & 7u) * 36u + ((hwid >> 13) & 3u) * 9u + min((hwid >> 8) & 15u, 8u);
+    const unsigned per = g_ktw_cap / 288u;
+    const unsigned local = atomicAdd(&g_ktw_n[key], 1u);
+    if (local < per) {
+      unsigned long long* r = g_ktw_buf + ((size_t)key * per + local) * 8;
+      r[0] = hwid; r[1] = xccid;
+      r[2] = kt[0]; r[3] = kt[1]; r[4] = kt[2]; r[5] = wall_clock64();
+      r[6] = (kt_wait << 32) | (kt_bar & 0xffffffffull);      // wave 0: ticks spent in the end-of-chunk vmcnt wait / in the barrier, summed over chunks
+      r[7] = ((unsigned long long)FN << 48) | ((unsigned long long)p.Cin << 8);
+    }
+  }
+#endif
 }
 
 // w (Cout,Cin,3,3) -> U = G g G^T in MFMA A-fragment order: [chunk = ci/8][m_tile = m/32][xi = r*4+c][lane = lk*16+li][kk*2+i]
@@ -272,3 +363,19 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
+
+#ifdef FRTM_DEBUG_TRACE
+extern "C" int frtm_debug_ktrace_wino(unsigned long long* buf, unsigned cap) {
+  static const unsigned zero[288] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ktw_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ktw_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ktw_n), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+extern "C" int frtm_debug_ktrace_wino_counts(unsigned* counts) {
+  if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_ktw_n), 288 * sizeof(unsigned)) != hipSuccess) return -1;
+  int n = 0;
+  for (int k = 0; k < 288; ++k) n += (int)counts[k];
+  return n;
+}
+#endif

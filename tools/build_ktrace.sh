@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p /tmp/ktrace_obj
 for f in frtm-vos_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  if [ $b = conv_igemm ]; then
+  if [ $b = conv_igemm ] || [ $b = conv_wino ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DFRTM_DEBUG_TRACE -c $f -o /tmp/ktrace_obj/$b.o
   else
     cp frtm-vos_amd/csrc/$b.o /tmp/ktrace_obj/$b.o

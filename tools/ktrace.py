@@ -46,13 +46,28 @@ def make_conv(cin, cout, B=8, h=30, w=54, residual=False, tile=0):
     return run, flops
 
 
-def collect(L, buf, fn, name):
+def make_wino(cin, cout, B=10, h=120, w=214, residual=False, variant=0):
+    """A 3x3 conv of the refiner as the fused F(2x2,3x3) kernel (csrc/conv_wino.hip), e.g. 64 -> 64 at the 120 x 214 level of 5 frames x 2 objects."""
+    x = torch.randn(B, cin, h, w, device=DEV)
+    wt = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    wW = ops.pack_weights(wt, wino=True)[0]
+    sc, sh = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    out = torch.empty(B, cout, h, w, device=DEV)
+    res = torch.randn(B, cout, h, w, device=DEV) if residual else None
+    flops = 2.0 * 9 * cout * cin * B * h * w
+
+    def run():
+        ops.conv2d(x, wW, cout, 3, 1, 1, scale=sc, shift=sh, relu=True, out=out, w_layout=2, residual=res, splitk=1, tile=variant)
+    return run, flops
+
+
+def collect(L, buf, fn, name, wino=False):
     torch.cuda.synchronize()
-    assert L.frtm_debug_ktrace(ctypes.c_void_p(buf.data_ptr()), CAP) == 0
+    assert (L.frtm_debug_ktrace_wino if wino else L.frtm_debug_ktrace)(ctypes.c_void_p(buf.data_ptr()), CAP) == 0
     fn()
     torch.cuda.synchronize()
     counts = (ctypes.c_uint * 288)()
-    n = L.frtm_debug_ktrace_counts(counts)
+    n = (L.frtm_debug_ktrace_wino_counts if wino else L.frtm_debug_ktrace_counts)(counts)
     per = CAP // 288
     assert n > 0 and max(counts) <= per, (n, max(counts))
     allrec = buf.cpu().numpy().astype(np.uint64).reshape(288, per, 8)
@@ -61,7 +76,7 @@ def collect(L, buf, fn, name):
     return rec
 
 
-def summarize(name, rec, flops):
+def summarize(name, rec, flops, wino=False):
     hw, xcc = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64) & 0xf
     cu = (xcc << 8) | ((hw >> 8) & 0xff)                    # XCC + (cu_id, sh_id, se_id) bits of HW_ID
     t = rec[:, 2:6].astype(np.int64)
@@ -72,6 +87,8 @@ def summarize(name, rec, flops):
     K = ((rec[:, 7].astype(np.int64) >> 8) & 0xffffff)
     BMv, BNv = (rec[:, 7].astype(np.int64) >> 48) & 0xffff, (rec[:, 7].astype(np.int64) >> 32) & 0xffff
     mfma_cycles = (BMv // 16) * (BNv // 16) * ((K + 3) // 4) * 32            # per tile, on one matrix pipe
+    if wino:                                                  # r[7] = FN << 48 | Cin << 8: 4 waves x ceil(Cin / 8) chunks x 16 FN MFMAs
+        mfma_cycles = 4 * ((K + 7) // 8) * 16 * BMv * 32
     res = np.zeros(5)
     grid = np.arange(0.0, span, 0.05)                         # 50 ns sampling
     for c in cus:
@@ -93,6 +110,11 @@ def summarize(name, rec, flops):
           % (name, len(rec), len(cus), res[4], span, flops / span / 1e6, res[0], res[1], res[2], res[3], floor))
     print('%-34s   phases us (mean / p90): prologue %.2f / %.2f   K loop %.2f / %.2f   epilogue %.2f / %.2f   WG lifetime %.2f'
           % ('', pro.mean(), np.percentile(pro, 90), kl.mean(), np.percentile(kl, 90), epi.mean(), np.percentile(epi, 90), (t[:, 3] - t[:, 0]).mean()))
+    if wino:
+        print('%-34s   wave 0, summed over the chunks of a workgroup (us, mean): end-of-chunk vmcnt wait %.2f   barrier %.2f'
+              % ('', (rec[:, 6].astype(np.int64) >> 32).mean() * 0.01, (rec[:, 6].astype(np.int64) & 0xffffffff).mean() * 0.01))
+    first = t[:, 0] < 0.1 * span
+    print('%-34s   first round (entered in the first tenth of the span: %d WGs) prologue %.2f, later rounds %.2f us' % ('', int(first.sum()), pro[first].mean(), pro[~first].mean() if (~first).any() else float('nan')))
     return span
 
 
@@ -104,6 +126,18 @@ def main():
     L.frtm_debug_ktrace_counts.restype = ctypes.c_int
     L.frtm_debug_ktrace_counts.argtypes = [ctypes.c_void_p]
     buf = torch.zeros(CAP * 8, dtype=torch.int64, device=DEV)
+    if sys.argv[1:2] == ['wino']:
+        for f in (L.frtm_debug_ktrace_wino, L.frtm_debug_ktrace_wino_counts):
+            f.restype = ctypes.c_int
+        L.frtm_debug_ktrace_wino.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.frtm_debug_ktrace_wino_counts.argtypes = [ctypes.c_void_p]
+        for cin, cout, res in ((64, 64, False), (64, 64, True), (65, 65, False), (65, 64, False)):
+            fn, fl = make_wino(cin, cout, residual=res)
+            for _ in range(3):
+                fn()
+            tag = 'wino %d->%d%s 10x120x214' % (cin, cout, ' +res' if res else '')
+            summarize(tag, collect(L, buf, fn, tag.replace(' ', '_').replace('>', ''), wino=True), fl, wino=True)
+        return
     tiles = [int(v) for v in sys.argv[1:]] or [0]
     for tile in tiles:
         c3, f3 = make_conv(256, 1024, residual=True, tile=tile)       # conv3 of a bottleneck block (+ residual)
