@@ -29,6 +29,14 @@ __device__ unsigned g_ktw_n[288];
 #else
 #define KTW_STAMP(i) do { } while (0)
 #endif
+#if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
+// finer (and intrusive: every stamp fences the scheduler) -- where wave 0 spends a chunk: load issue / LDS read / MFMA issue of k-step 0 / LDS read / MFMA issue of k-step 1
+#define KTW_IN(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); kt_in[i] += t_ - kt_last; kt_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KTW_EPI(i) do { __builtin_amdgcn_sched_barrier(0); ke[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KTW_IN(i) do { } while (0)
+#define KTW_EPI(i) do { } while (0)
+#endif
 
 constexpr int WCI = 8;                 // input channels per chunk
 constexpr int WBM = 32;                // output channels per workgroup
@@ -86,10 +94,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   constexpr int CQ = FN == 2 ? 4 : 2;                                        // output channels per thread in the output phase
   constexpr int SMEM = 8 * PLANE > 3 * STAGE ? 8 * PLANE : 3 * STAGE;        // 37.4 KB (32 tiles) / 18.4 KB (16 tiles)
   __shared__ __attribute__((aligned(16))) float smem[SMEM];                // main loop: 3 patch stages; epilogue: the planes
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: M0 of the LDS-DMA loads in SGPRs
   const int lk = lane >> 4, li = lane & 15;
 #ifdef FRTM_DEBUG_TRACE
   unsigned long long kt[4] = {0, 0, 0, 0}, kt_wait = 0, kt_bar = 0;
+#if FRTM_DEBUG_TRACE >= 2
+  unsigned long long kt_in[5] = {0, 0, 0, 0, 0}, kt_last = 0, ke[5] = {0, 0, 0, 0, 0};
+#endif
 #endif
   KTW_STAMP(0);
   const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
@@ -99,6 +110,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
   const int by = bt / tiles_x, bx = bt - by * tiles_x;
   const int y0 = by * BH, x0 = bx * BW, m0 = m_tile * WBM;
+  // BN scale / shift of this workgroup's 32 output channels -> LDS, requested first thing (the epilogue reads them from there)
+  __shared__ __attribute__((aligned(16))) float ssc[2 * WBM];
+  float ssv = tid < WBM ? 1.f : 0.f;
+  if (p.scale && tid < 2 * WBM && m0 + (tid & (WBM - 1)) < p.M) ssv = (tid < WBM ? p.scale : p.shift)[m0 + (tid & (WBM - 1))];
   const int HWin = p.Hin * p.Win;
   const unsigned img_bytes = (unsigned)p.Cin * (unsigned)HWin * 4u;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)img * p.Cin * HWin), 0, (int)img_bytes, 0x00020000);
@@ -117,6 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const int ra_ = (wid == 0) ? 0 : (wid == 2 ? 2 : 1), rb_ = (wid == 3) ? 3 : (wid == 2 ? 1 : 2);
   const float sb_ = (wid == 1) ? 1.f : -1.f;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const f32x2 sb2 = {sb_, sb_};
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;      // LDS byte address of smem
   unsigned offA[FN], offB[FN];                                                                 // LDS byte addresses inside stage 0, k-step 0
@@ -150,99 +166,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 
   // Load queue (vmcnt counts loads in issue order): chunk k issues A(k+1) -- the weights of the next chunk, 4 loads -- and then R(k+2), the
   // patch two chunks ahead, NR loads.  Patches ring through three LDS stages (runtime index), weights through two register sets (F = k & 1).
-  const int nch = p.nchunks;
+  const int nch = max(p.nchunks, 2);                       // (a single chunk -- Cin <= 8 -- runs a second one on zeros: both operands out of bounds)
   // (sched_barrier: the manual vmcnt values below count loads in THIS order; without the fences the scheduler had moved the patch loads in front
   //  of the weight loads in one of the two unrolled chunks)
-  gloadA(0, fa[0]); __builtin_amdgcn_sched_barrier(0); gloadR(0, 0); gloadR(1, 1); __builtin_amdgcn_sched_barrier(0);
+  gloadA(0, fa[0]); gloadA(0, fa[1]);                       // both sets (an odd count starts in the second one): a conditional load would cost exact counts
+  __builtin_amdgcn_sched_barrier(0); gloadR(0, 0); gloadR(1, 1); __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F74 : 0x0F76);    // vmcnt(NR): weights and patch of chunk 0 have arrived, patch 1 stays in flight
   __builtin_amdgcn_s_barrier();
+  // (inline asm: the compiler orders every LDS access it sees after all LDS-DMA loads in flight; the clobber tells it that ssc is written)
+  if (tid < 2 * WBM) asm volatile("ds_write_b32 %0, %1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float*)ssc + (unsigned)tid * 4u), "v"(ssv) : "memory");
   KTW_STAMP(1);
-  auto chunk = [&](int k, int st, auto F_) {
-    constexpr int F = decltype(F_)::value;                  // k & 1
-    gloadA(k + 1, fa[F ^ 1]);
-    __builtin_amdgcn_sched_barrier(0);
-    gloadR(k + 2, st == 0 ? 2 : st - 1);
-    __builtin_amdgcn_sched_barrier(0);
+  // Issue order inside a chunk (wave 0's time by section, tools/ktrace.py wino2, before this order: 700 cycles issuing the ten loads, 2 x 350
+  // waiting for LDS reads, 1800 issuing 32 MFMAs, 310 in the barrier): the LDS reads of k-step 0 go first and the four weight loads are issued
+  // under their latency; the reads of k-step 1 and the NR patch loads are spread over the MFMAs of k-step 0, whose execution covers their issue.
+  // The sched_barriers pin this order (and with it the order of the load queue the vmcnt values count).
+  auto operands = [&](const f32x4* da, const f32x4* db, float (*bq)[4]) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const unsigned so = (unsigned)((st * STAGE + kk * 4 * PE) * 4);
-      f32x4 da[FN], db[FN];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) { da[j] = lds_rd4(offA[j] + so); db[j] = lds_rd4(offB[j] + so); }
-      if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da[0]), "+v"(db[0]), "+v"(da[1]), "+v"(db[1]));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da[0]), "+v"(db[0]));
-      float bq[FN][4];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {                      // B^T d B of this lane's (channel, tile), row wid: two-float operations on register pairs
-        const f32x2 u01 = da[j].lo + sb2 * db[j].lo, u23 = da[j].hi + sb2 * db[j].hi;
-        const f32x2 d = u01 - u23;                        // (u0 - u2, u1 - u3)
-        bq[j][0] = d.x; bq[j][1] = u01.y + u23.x; bq[j][2] = u23.x - u01.y; bq[j][3] = d.y;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][kk * 2 + 0], bq[j][q], acc[q][0][j], 0, 0, 0);
-          acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][kk * 2 + 1], bq[j][q], acc[q][1][j], 0, 0, 0);
-        }
+    for (int j = 0; j < FN; ++j) {                        // B^T d B of this lane's (channel, tile), row wid: two-float operations on register pairs
+      const f32x2 u01 = da[j].lo + sb2 * db[j].lo, u23 = da[j].hi + sb2 * db[j].hi;
+      const f32x2 d = u01 - u23;                          // (u0 - u2, u1 - u3)
+      bq[j][0] = d.x; bq[j][1] = u01.y + u23.x; bq[j][2] = u23.x - u01.y; bq[j][3] = d.y;
     }
-    // patch k+1 (issued one chunk ago) must have landed before anyone reads it; newer than it in the queue are A(k+1) and R(k+2), which may
-    // stay in flight.  This wave's LDS reads of the current stage are complete (lgkmcnt(0) above).
-#ifdef FRTM_DEBUG_TRACE
-    const unsigned long long tq0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);
-    const unsigned long long tq1 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_barrier();
-    const unsigned long long tq2 = __builtin_amdgcn_s_memrealtime();
-    kt_wait += tq1 - tq0; kt_bar += tq2 - tq1;
-#else
-    __builtin_amdgcn_s_waitcnt(NR == 4 ? 0x0F78 : 0x0F7A);   // vmcnt(NR + 4)
-    __builtin_amdgcn_s_barrier();
-#endif
   };
-  // (a loop body without exits, then the chunk left over: exits inside the body made the loop header reachable with weight loads the compiler
-  //  had not seen consumed, and it waited for vmcnt(0) there)
+  // LOADS: 2 = a chunk in the middle (requests the weights of k+1 and the patch of k+2), 1 = the chunk before the last (weights only), 0 = the last
+  // one.  No request is ever issued for data that is not used: after the last chunk nothing is in flight, and -- what matters -- the compiler KNOWS
+  // it (explicit vmcnt(0)): it orders every LDS access it can see after all LDS-DMA loads it believes in flight, and with dummy loads past the end it
+  // put s_waitcnt vmcnt(0) between the epilogue's residual requests and the plane exchange.
+  auto chunk = [&](int k, int st, auto F_, auto L_) {
+    constexpr int F = decltype(F_)::value;                  // k & 1
+    constexpr int LOADS = decltype(L_)::value;
+#if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
+    kt_last = __builtin_amdgcn_s_memrealtime();
+#endif
+    const unsigned so0 = (unsigned)(st * STAGE * 4), so1 = so0 + (unsigned)(4 * PE * 4);
+    const int st2 = st == 0 ? 2 : st - 1;
+    f32x4 da0[FN], db0[FN], da1[FN], db1[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { da0[j] = lds_rd4(offA[j] + so0); db0[j] = lds_rd4(offB[j] + so0); }
+    if constexpr (LOADS >= 1) gloadA(k + 1, fa[F ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da0[0]), "+v"(db0[0]), "+v"(da0[1]), "+v"(db0[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da0[0]), "+v"(db0[0]));
+    KTW_IN(0);
+    float bq[FN][4];
+    operands(da0, db0, bq);
+    const unsigned cstep = (unsigned)((k + 2) * WCI) * (unsigned)(HWin * 4);   // channels >= Cin: beyond the image's descriptor = zeros
+    constexpr int PER = (NR + 2) / 3;                                          // patch loads after each of the first three MFMA groups
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][0], bq[j][q], acc[q][0][j], 0, 0, 0);
+        acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][1], bq[j][q], acc[q][1][j], 0, 0, 0);
+      }
+      if (q == 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { da1[j] = lds_rd4(offA[j] + so1); db1[j] = lds_rd4(offB[j] + so1); }
+      }
+      if constexpr (LOADS == 2)
+#pragma unroll
+      for (int i = q * PER; i < (q + 1) * PER && i < NR; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem + st2 * STAGE + i * 256 + wid * 64),
+                                                 4, (int)(r_goff[i] + cstep), 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    KTW_IN(1);
+    if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da1[0]), "+v"(db1[0]), "+v"(da1[1]), "+v"(db1[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da1[0]), "+v"(db1[0]));
+    KTW_IN(2);
+    operands(da1, db1, bq);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][2], bq[j][q], acc[q][0][j], 0, 0, 0);
+        acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][3], bq[j][q], acc[q][1][j], 0, 0, 0);
+      }
+    KTW_IN(3);
+    // patch k+1 (issued one chunk ago) must have landed before anyone reads it; newer than it in the queue are A(k+1) and, in a middle chunk, R(k+2),
+    // which may stay in flight.  This wave's LDS reads of the current stage are complete (lgkmcnt(0) above).
+    if constexpr (LOADS >= 1) {
+      constexpr int W = LOADS == 2 ? (NR == 4 ? 0x0F78 : 0x0F7A) : 0x0F74;     // vmcnt(NR + 4) / vmcnt(4)
+#ifdef FRTM_DEBUG_TRACE
+      const unsigned long long tq0 = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_s_waitcnt(W);
+      const unsigned long long tq1 = __builtin_amdgcn_s_memrealtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long tq2 = __builtin_amdgcn_s_memrealtime();
+      kt_wait += tq1 - tq0; kt_bar += tq2 - tq1;
+#else
+      __builtin_amdgcn_s_waitcnt(W);
+      __builtin_amdgcn_s_barrier();
+#endif
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): nothing is in flight any more (a no-op in time: the weights of this chunk were the last request)
+    }
+  };
+  // One straight path through the chunks, whatever their number: an odd count runs its first chunk in front of the loop -- the prologue has put the
+  // weights of chunk 0 into the second register set for it --, then full chunks in pairs (a loop body without exits: exits inside the body made
+  // the loop header reachable with weight loads the compiler had not seen consumed, and it waited for vmcnt(0) there), then always the same two last
+  // chunks.  (A three-way tail by remaining count cost 208 spilled registers: the accumulators met in different registers.)
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   int kc = 0, st = 0;
-  for (; kc + 2 <= nch; kc += 2) {
-    chunk(kc, st, std::integral_constant<int, 0>{});
-    st = st == 2 ? 0 : st + 1;
-    chunk(kc + 1, st, std::integral_constant<int, 1>{});
-    st = st == 2 ? 0 : st + 1;
+  if (nch & 1) { chunk(0, 0, I1{}, I2{}); kc = 1; st = 1; }
+  for (; kc + 4 <= nch; kc += 2) {
+    chunk(kc, st, I0{}, I2{}); st = st == 2 ? 0 : st + 1;
+    chunk(kc + 1, st, I1{}, I2{}); st = st == 2 ? 0 : st + 1;
   }
-  if (kc < nch) chunk(kc, st, std::integral_constant<int, 0>{});
-  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): the zero patches past the end have landed before the stages are re-used
-  __syncthreads();
-  KTW_STAMP(2);
+  chunk(kc, st, I0{}, I1{}); st = st == 2 ? 0 : st + 1;
+  chunk(kc + 1, st, I1{}, I0{});
 
-  // ---- epilogue ----
-  // output phase: thread -> (tile tx, ty of the block; CQ output channels)
+  // ---- epilogue ----  (wave 0's time after the K loop before this form, tools/ktrace.py wino2: 1.2 us -- 2.2 with a residual -- computing 64-bit
+  // addresses and issuing predicated loads, 0.6 us exchanging the planes, 2.6 us waiting for scale / shift / residual and issuing predicated stores)
+  // Output phase: thread -> (tile tx, ty of the block; CQ consecutive output channels).  All global accesses are buffer operations on descriptors
+  // of THIS image's planes with 32-bit offsets; invalid elements (channel >= M, row >= Ho, column >= Wo) get an out-of-bounds offset: loads return
+  // 0, stores are dropped -- no branches.
   constexpr int TW = BW / 2, TH = BH / 2, TILES = TW * TH;
   const int tx = tid % TW, ty = (tid / TW) % TH, cq = tid / TILES;
   const int ej = FN == 2 ? (TALL ? ty >> 2 : tx >> 2) : 0, eli = (ty & 3) * 4 + (tx & 3);
   const int mm0 = m0 + cq * CQ;
   const int xx = x0 + 2 * tx, yy0 = y0 + 2 * ty;
   const bool two = xx + 1 < p.Wo;
-  const bool pair_ok = (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
-  float sc[CQ], sh[CQ];
-  float2 rv[CQ][2];
-  size_t oo[CQ];
+  const size_t img_off = (size_t)img * p.M * p.Npix;
+  const unsigned out_bytes = (unsigned)p.M * (unsigned)p.Npix * 4u;
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + img_off), 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(p.residual ? (void*)(p.residual + img_off) : (void*)p.out, 0,
+                                                                        p.residual ? (int)out_bytes : 0, 0x00020000);     // no residual: every load is out of bounds = 0
+  // pairs (x, x+1) as one 8-byte access: even width (a pair never straddles a row; plane sizes are even) and 8-byte aligned tensors
+  const bool pairs = (p.Wo & 1) == 0 && (((size_t)p.out) % 8 == 0) && (!p.residual || ((size_t)p.residual) % 8 == 0);
+  unsigned eo[CQ][2];
 #pragma unroll
-  for (int c = 0; c < CQ; ++c) {
-    const int mm = mm0 + c;
-    const bool okc = mm < p.M;
-    sc[c] = (p.scale && okc) ? p.scale[mm] : 1.f;
-    sh[c] = (p.scale && okc) ? p.shift[mm] : 0.f;
-    oo[c] = ((size_t)img * p.M + mm) * p.Npix + (size_t)yy0 * p.Wo + xx;
+  for (int c = 0; c < CQ; ++c)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      rv[c][a] = make_float2(0.f, 0.f);
-      if (p.residual && okc && yy0 + a < p.Ho && xx < p.Wo) {
-        const size_t o = oo[c] + (size_t)a * p.Wo;
-        if (two && (o & 1) == 0 && pair_ok) rv[c][a] = *(const float2*)&p.residual[o];
-        else { rv[c][a].x = p.residual[o]; if (two) rv[c][a].y = p.residual[o + 1]; }
+    for (int a = 0; a < 2; ++a)
+      eo[c][a] = (mm0 + c < p.M && yy0 + a < p.Ho && xx < p.Wo) ? (unsigned)(((mm0 + c) * p.Npix + (yy0 + a) * p.Wo + xx) * 4) : OOB;
+  f32x2 rv[CQ][2];
+  __builtin_amdgcn_sched_barrier(0);
+  if (pairs) {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) rv[c][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, (int)eo[c][a], 0, 0));
+  } else {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        rv[c][a].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)eo[c][a], 0, 0));
+        rv[c][a].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, (int)(two ? eo[c][a] + 4u : OOB), 0, 0));
       }
-    }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();                              // every wave has read its last patch: the stages become the planes (the residual requests stay in flight)
+  KTW_STAMP(2);
+  KTW_EPI(0);
   // column half of the output transform in registers: (M A)[row = wid][b], b = 0: m0 + m1 + m2, b = 1: m1 - m2 - m3
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -253,7 +330,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       *(f32x4*)(d + (wid * 2 + 0) * PLANE) = c0;
       *(f32x4*)(d + (wid * 2 + 1) * PLANE) = c1;
     }
+  KTW_EPI(1);
   __syncthreads();
+  KTW_EPI(2);
   typedef float fq __attribute__((ext_vector_type(CQ)));
   fq P[4][2];
   const float* src = smem + ej * JOFF + eli * CP + cq * CQ;
@@ -261,12 +340,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   for (int w = 0; w < 4; ++w)
 #pragma unroll
     for (int b = 0; b < 2; ++b) P[w][b] = *(const fq*)(src + (w * 2 + b) * PLANE);
+  const fq sc = *(const fq*)(ssc + cq * CQ), sh = *(const fq*)(ssc + WBM + cq * CQ);
+#if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  KTW_EPI(3);
 #pragma unroll
-  for (int c = 0; c < CQ; ++c) {
-    if (mm0 + c >= p.M) continue;
+  for (int c = 0; c < CQ; ++c)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      if (yy0 + a >= p.Ho || xx >= p.Wo) continue;
       // row half: a = 0: r0 + r1 + r2, a = 1: r1 - r2 - r3
       float v0, v1;
       if (a == 0) { v0 = P[0][0][c] + P[1][0][c] + P[2][0][c]; v1 = P[0][1][c] + P[1][1][c] + P[2][1][c]; }
@@ -274,11 +356,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       v0 = v0 * sc[c] + sh[c] + rv[c][a].x;
       v1 = v1 * sc[c] + sh[c] + rv[c][a].y;
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-      const size_t o = oo[c] + (size_t)a * p.Wo;
-      if (two && (o & 1) == 0 && pair_ok) *(float2*)&p.out[o] = make_float2(v0, v1);
-      else { p.out[o] = v0; if (two) p.out[o + 1] = v1; }
+      if (pairs) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), rout, (int)eo[c][a], 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rout, (int)eo[c][a], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rout, (int)(two ? eo[c][a] + 4u : OOB), 0, 0);
+      }
     }
-  }
+  KTW_EPI(4);
 #ifdef FRTM_DEBUG_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && g_ktw_buf) {
@@ -292,6 +377,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       r[2] = kt[0]; r[3] = kt[1]; r[4] = kt[2]; r[5] = wall_clock64();
       r[6] = (kt_wait << 32) | (kt_bar & 0xffffffffull);      // wave 0: ticks spent in the end-of-chunk vmcnt wait / in the barrier, summed over chunks
       r[7] = ((unsigned long long)FN << 48) | ((unsigned long long)p.Cin << 8);
+#if FRTM_DEBUG_TRACE >= 2
+      r[0] = (kt_in[0] << 48) | (kt_in[1] << 32) | (kt_in[2] << 16) | kt_in[3];          // (HW_ID dropped in this mode: all records count as one CU)
+      r[1] = kt_in[4];
+      // epilogue sections of wave 0, ticks since the K loop's end: requests issued | planes written | barrier passed | planes read | stores issued
+      r[7] = ((ke[0] - kt[2]) << 48) | ((ke[1] - kt[2]) << 36) | ((ke[2] - kt[2]) << 24) | ((ke[3] - kt[2]) << 12) | (ke[4] - kt[2]);
+#endif
     }
   }
 #endif

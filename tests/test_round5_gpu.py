@@ -301,3 +301,45 @@ def test_joint_fit_on_wide_maps_takes_the_strip_forms_and_agrees_with_the_narrow
     e1, e2 = rel(out[True][2], out[False][2]), rel(out[True][3], out[False][3])
     print('wide vs narrow forms: b %.2e, A b %.2e, weights after run((3, 4)): project %.2e filter %.2e' % (eb, eq, e1, e2))
     assert eb < 2e-5 and eq < 2e-5 and e1 < 0.1 and e2 < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# fused Winograd F(2x2, 3x3) kernel after the round-5 rewrite of its load queue and epilogue (csrc/conv_wino.hip; reference
+# model/seg_network.py:7-56 -- the refiner's 3x3 convolutions -- and feature_extractor.py:56-65 for layer1)
+@pytest.mark.parametrize('B,cin,cout,h,w', [
+    (1, 5, 32, 8, 8),          # one chunk: runs a second one on out-of-bounds (zero) operands
+    (2, 16, 64, 30, 54),       # two chunks: no loop, the fixed two-chunk tail only
+    (1, 24, 32, 17, 23),       # three: an odd count enters through the second weight register set
+    (1, 40, 96, 15, 27),       # five, three M tiles, odd height and width (single-dword stores)
+    (2, 65, 65, 60, 107),      # the refiner's 65-channel convs: tail chunk of one channel, third M tile of one channel, odd width
+    (1, 64, 64, 120, 214),     # the refiner's dominant shape
+])
+def test_winograd_fused_kernel_chunk_counts_and_epilogue_paths(B, cin, cout, h, w):
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + cin * 10 + cout)
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    res = torch.randn(B, cout, h, w, generator=g)
+    ref2 = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())      # noqa: E731
+    xd, rd, sc, sh = x.to(DEV), res.to(DEV), scale.to(DEV), shift.to(DEV)
+    wW, ktab, lay = ops.pack_weights(wt.to(DEV), wino=True)
+    assert lay == 2
+    for tile in (0, 1, 2, 3):                 # auto, 8x8 blocks, 8 rows x 16 columns, 16 rows x 8 columns
+        plain = ops.conv2d(xd, wW, cout, 3, 1, 1, w_layout=2, tile=tile)
+        assert rel(plain, ref) < 1e-5, (tile, rel(plain, ref))                       # fp32 against the float64 convolution
+        full = ops.conv2d(xd, wW, cout, 3, 1, 1, scale=sc, shift=sh, residual=rd, relu=True, w_layout=2, tile=tile)
+        assert rel(full, ref2) < 1e-5, (tile, rel(full, ref2))
+        # the same launch 12 times over: a load consumed before it has landed (the kernel counts its loads by hand) shows up as a run that differs
+        for _ in range(12):
+            again = ops.conv2d(xd, wW, cout, 3, 1, 1, scale=sc, shift=sh, residual=rd, relu=True, w_layout=2, tile=tile)
+            assert torch.equal(again, full), tile
+        # output and residual at 4-byte (not 8-byte) alignment: the single-dword store / load path
+        buf_o, buf_r = torch.zeros(full.numel() + 1, device=DEV), torch.zeros(full.numel() + 1, device=DEV)
+        buf_r[1:] = rd.flatten()
+        odd = ops.conv2d(xd, wW, cout, 3, 1, 1, scale=sc, shift=sh, residual=buf_r[1:].view_as(rd), relu=True, w_layout=2, tile=tile,
+                         out=buf_o[1:].view_as(full))
+        assert odd.data_ptr() % 8 == 4 and torch.equal(odd, full), tile
+        assert float(buf_o[0]) == 0.0

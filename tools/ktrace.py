@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frtm_vos_amd import _hip  # noqa: E402
 
-_hip.LIB_PATH = os.path.join(ROOT, 'tools', '_ab_ktrace.so')
+_hip.LIB_PATH = os.path.join(ROOT, 'tools', '_ab_ktrace2.so' if sys.argv[1:2] == ['wino2'] else '_ab_ktrace.so')
 from frtm_vos_amd import ops  # noqa: E402
 
 DEV = 'cuda:0'
@@ -126,6 +126,31 @@ def main():
     L.frtm_debug_ktrace_counts.restype = ctypes.c_int
     L.frtm_debug_ktrace_counts.argtypes = [ctypes.c_void_p]
     buf = torch.zeros(CAP * 8, dtype=torch.int64, device=DEV)
+    if sys.argv[1:2] == ['wino2']:
+        # -DFRTM_DEBUG_TRACE=2 build (tools/_ab_ktrace2.so): wave 0's time inside the chunks, by section (intrusive: the stamps fence the scheduler)
+        for f in (L.frtm_debug_ktrace_wino, L.frtm_debug_ktrace_wino_counts):
+            f.restype = ctypes.c_int
+        L.frtm_debug_ktrace_wino.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.frtm_debug_ktrace_wino_counts.argtypes = [ctypes.c_void_p]
+        for cin, cout, res in ((64, 64, False), (64, 64, True)):
+            fn, fl = make_wino(cin, cout, residual=res)
+            for _ in range(3):
+                fn()
+            rec = collect(L, buf, fn, 'wino2_%d_%d_%d' % (cin, cout, res), wino=True)
+            a, b = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64)
+            sec = np.stack([(a >> 48) & 0xffff, (a >> 32) & 0xffff, (a >> 16) & 0xffff, a & 0xffff, b & 0xffff], 1) * 0.01
+            t = rec[:, 2:6].astype(np.int64) * 0.01
+            w, bar = (rec[:, 6].astype(np.int64) >> 32) * 0.01, (rec[:, 6].astype(np.int64) & 0xffffffff) * 0.01
+            print('wino %d->%d%s: %d WGs; K loop %.2f us of which (wave 0, mean over workgroups): LDS read k0 + weight-load issue %.2f  operands + MFMAs k0 + patch-load issue %.2f  '
+                  'LDS wait k1 %.2f  operands + MFMA issue k1 %.2f  end-of-chunk wait %.2f  barrier %.2f   (prologue %.2f, epilogue %.2f)'
+                  % (cin, cout, ' +res' if res else '', len(rec), (t[:, 2] - t[:, 1]).mean(), sec[:, 0].mean(), sec[:, 1].mean(), sec[:, 2].mean(), sec[:, 3].mean(),
+                     w.mean(), bar.mean(), (t[:, 1] - t[:, 0]).mean(), (t[:, 3] - t[:, 2]).mean()))
+            e = rec[:, 7].astype(np.uint64)
+            es = np.stack([(e >> np.uint64(48)) & np.uint64(0xfff), (e >> np.uint64(36)) & np.uint64(0xfff), (e >> np.uint64(24)) & np.uint64(0xfff),
+                           (e >> np.uint64(12)) & np.uint64(0xfff), e & np.uint64(0xfff)], 1).astype(np.float64) * 0.01
+            print('   epilogue, us after the K loop (mean): requests issued %.2f  planes written %.2f  barrier passed %.2f  planes read %.2f  stores issued %.2f  stores complete %.2f'
+                  % (es[:, 0].mean(), es[:, 1].mean(), es[:, 2].mean(), es[:, 3].mean(), es[:, 4].mean(), (t[:, 3] - t[:, 2]).mean()))
+        return
     if sys.argv[1:2] == ['wino']:
         for f in (L.frtm_debug_ktrace_wino, L.frtm_debug_ktrace_wino_counts):
             f.restype = ctypes.c_int
