@@ -94,6 +94,7 @@ SIGNATURES = {
     'frtm_plane_mean': (I, [P, I, I, P, P]),
     'frtm_cab_gate': (I, [P, P, I, P, P, P, P, I, I, P, P]),
     'frtm_project_tail': (I, [P, I, I, I, I, P, P, I, I, P, P]),
+    'frtm_tap_mix': (I, [P, I, I, I, P, P, P]),
     'frtm_warp_affine': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_affine_u8': (I, [P, I, I, I, P, I, I, P, I, P]),
     'frtm_warp_mask_batch': (I, [P, I, I, P, I, I, P, I, P, P]),

@@ -449,7 +449,8 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
   } else if (variant == 3) {
     k_conv3x3_wino<2, 1, 3><<<p.B * ceil_div(p.Ho, 16) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
   } else {
-    k_conv3x3_wino<1, 0, 4><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
+    // (96 registers, 18 KB of LDS: five workgroups per CU; measured 1-3 % ahead of four on the refiner's shapes, profiles/r05_wino_bench.txt)
+    k_conv3x3_wino<1, 0, 5><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 8) * mt, 256, 0, st>>>(p);
   }
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;

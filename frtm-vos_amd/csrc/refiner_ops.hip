@@ -399,7 +399,52 @@ __global__ __launch_bounds__(256, 4) void k_project_tail(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv2 (3x3, C -> 1) after two resampling steps is linear in y, and the channel sum commutes with the resampling:
+//   conv2(R(U(y)))(p) = sum_t sum_c w[c][t] R(U(y_c))(p + t) = sum_t R(U(Y_t))(p + t),     Y_t = sum_c w[c][t] y_c   (t = one of the nine taps)
+// so the tail only has to resample NINE maps instead of C = 32 (round 5; k_project_tail then runs on Y with one-hot weights).  This kernel forms
+// Y (n,9,h,w) from y (n,C,h,w): one pass over y, V pixels per thread, the nine weights of a channel wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void k_tap_mix(const float* __restrict__ y, const float* __restrict__ w, int C, int hwv, float* __restrict__ out) {
+  typedef float fv __attribute__((ext_vector_type(V)));
+  const int i = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (i >= hwv) return;
+  fv acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = fv(0.f);
+  const fv* yp = (const fv*)(y + (size_t)n * C * hwv * V) + i;
+  int c = 0;
+  for (; c + 4 <= C; c += 4) {                              // four channels' loads in flight
+    fv v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = yp[(size_t)(c + u) * hwv];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += w[(c + u) * 9 + t] * v[u];
+  }
+  for (; c < C; ++c) {
+    const fv v = yp[(size_t)c * hwv];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += w[c * 9 + t] * v;
+  }
+  fv* op = (fv*)(out + (size_t)n * 9 * hwv * V) + i;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) op[(size_t)t * hwv] = acc[t];
+}
+
 extern "C" {
+
+int frtm_tap_mix(const float* y, int n, int C, int hw, const float* w3x3, float* out, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(y && w3x3 && out && n > 0 && C > 0 && hw > 0, "frtm_tap_mix: bad argument");
+  if (hw % 4 == 0 && ((size_t)y % 16 == 0) && ((size_t)out % 16 == 0))
+    k_tap_mix<4><<<dim3(ceil_div(hw / 4, 256), n), 256, 0, (hipStream_t)stream>>>(y, w3x3, C, hw / 4, out);
+  else
+    k_tap_mix<1><<<dim3(ceil_div(hw, 256), n), 256, 0, (hipStream_t)stream>>>(y, w3x3, C, hw, out);
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
 
 int frtm_bilinear_resize(const float* in, int planes, int h, int w, float* out, int H, int W, frtm_stream_t stream) {
   FRTM_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "frtm_bilinear_resize: bad argument");

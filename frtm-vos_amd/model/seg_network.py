@@ -155,6 +155,7 @@ class SegNetwork(nn.Module):
         self._pack_key = None
         self.use_winograd = True      # 3x3 convs as Winograd F(2x2,3x3) when the launch is large enough (frtm_conv2d, layout 2)
         self.fuse_tail = True         # up2 + resize + conv2 as one kernel when the resize ratio allows (frtm_project_tail)
+        self.mix_taps = True          # ... on nine tap maps (conv2's channel sum taken first, frtm_tap_mix) instead of conv1's 32 channels
         self.parallel_levels = True   # graph replay: the pyramid levels' independent halves run as parallel graph branches
         self._side = None
         self._pool = None
@@ -307,7 +308,8 @@ class SegNetwork(nn.Module):
                         cab_w1=c[0].weight.data.flatten(1).t().contiguous(), cab_b1=c[0].bias.data.contiguous(), cab_w2=c[2].weight.data.flatten(1).t().contiguous(),
                         cab_b2=c[2].bias.data.contiguous())
         pj = self.project
-        P['project'] = dict(c1=cv(pj.conv1, relu_=True), w2=pj.conv2.weight.data.contiguous(), b2=pj.conv2.bias.data)
+        P['project'] = dict(c1=cv(pj.conv1, relu_=True), w2=pj.conv2.weight.data.contiguous(), b2=pj.conv2.bias.data,
+                            eye9=torch.eye(9, device=dev).contiguous())
         self._pack, self._pack_key = P, key
         return P
 
@@ -417,7 +419,13 @@ class SegNetwork(nn.Module):
         if self.fuse_tail and int(18 * 4.0 * hh / Ho) + 3 <= 22 and int(66 * 4.0 * ww / Wo) + 3 <= 76:
             # up2 + bilinear resize + conv2 in one kernel: the 32-channel full-resolution tensor never exists in HBM
             out = torch.empty(n, 1, Ho, Wo, device=dev)
-            H.call('frtm_project_tail', H.ptr(y), n, c2, 2 * hh, 2 * ww, H.ptr(pj['w2']), H.ptr(pj['b2']), Ho, Wo, H.ptr(out))
+            if self.mix_taps and c2 > 9:
+                # conv2's channel sum first (it commutes with the resampling): nine maps go through up2 + resize instead of c2 = 32
+                ym = torch.empty(n, 9, 2 * hh, 2 * ww, device=dev)
+                H.call('frtm_tap_mix', H.ptr(y), n, c2, 4 * hh * ww, H.ptr(pj['w2']), H.ptr(ym))
+                H.call('frtm_project_tail', H.ptr(ym), n, 9, 2 * hh, 2 * ww, H.ptr(pj['eye9']), H.ptr(pj['b2']), Ho, Wo, H.ptr(out))
+            else:
+                H.call('frtm_project_tail', H.ptr(y), n, c2, 2 * hh, 2 * ww, H.ptr(pj['w2']), H.ptr(pj['b2']), Ho, Wo, H.ptr(out))
             return out
         u2 = torch.empty(n, c2, 4 * hh, 4 * ww, device=dev)
         H.call('frtm_pyrup2x', H.ptr(y), n * c2, 2 * hh, 2 * ww, H.ptr(u2))

@@ -422,6 +422,11 @@ int frtm_pyrup2x(const float* in, int planes, int h, int w, float* out, frtm_str
  * fails with FRTM_ERR_ARG and the caller composes frtm_pyrup2x + frtm_bilinear_resize + frtm_filter_scores. */
 int frtm_project_tail(const float* y, int n, int C, int h, int w, const float* w3x3, const float* bias, int Ho, int Wo, float* out,
                       frtm_stream_t stream);
+/* The channel sum of conv2 taken BEFORE the two resampling steps (they are linear and act per channel):
+ *   out[n,t] = sum_c w3x3[c*9 + t] * y[n,c]      (t = 0..8: the nine taps; y (n,C,h*w), out (n,9,h*w))
+ * frtm_project_tail(out, n, 9, h, w, one-hot weights (9,3,3): eye(9), bias, ..) then equals frtm_project_tail(y, n, C, h, w, w3x3, bias, ..)
+ * up to summation order, with 9 instead of C maps resampled (model/seg_network.py:117-119). */
+int frtm_tap_mix(const float* y, int n, int C, int hw, const float* w3x3, float* out, frtm_stream_t stream);
 /* adaptive_avg_pool2d(x, 1): out[plane] = mean(in[plane]) */
 int frtm_plane_mean(const float* in, int planes, int HW, float* out, frtm_stream_t stream);
 

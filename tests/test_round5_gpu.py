@@ -343,3 +343,43 @@ def test_winograd_fused_kernel_chunk_counts_and_epilogue_paths(B, cin, cout, h, 
                          out=buf_o[1:].view_as(full))
         assert odd.data_ptr() % 8 == 4 and torch.equal(odd, full), tile
         assert float(buf_o[0]) == 0.0
+
+
+def test_tap_mix_commutes_conv2_with_the_resampling():
+    """Refiner tail (reference model/seg_network.py:117-119): conv2(interpolate(up2(y))) with conv2's channel sum taken first (frtm_tap_mix, nine maps
+    resampled) against the same fused kernel on all 32 channels, and the mix itself against an einsum."""
+    from frtm_vos_amd import _hip as H
+    g = torch.Generator().manual_seed(11)
+    for n, C, h, w, Ho, Wo in ((3, 32, 60, 107, 120, 213), (2, 32, 30, 54, 60, 107), (1, 12, 23, 31, 46, 61)):
+        y = torch.relu(torch.randn(n, C, h, w, generator=g)).to(DEV)
+        w2 = (torch.randn(1, C, 3, 3, generator=g) / (C * 9) ** 0.5).to(DEV)
+        b2 = torch.randn(1, generator=g).to(DEV)
+        ym = torch.empty(n, 9, h, w, device=DEV)
+        H.call('frtm_tap_mix', H.ptr(y), n, C, h * w, H.ptr(w2), H.ptr(ym))
+        ref = torch.einsum('ct,nchw->nthw', w2.view(C, 9).double(), y.double())
+        assert float((ym.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        a, b = torch.empty(n, 1, Ho, Wo, device=DEV), torch.empty(n, 1, Ho, Wo, device=DEV)
+        H.call('frtm_project_tail', H.ptr(y), n, C, h, w, H.ptr(w2), H.ptr(b2), Ho, Wo, H.ptr(a))
+        H.call('frtm_project_tail', H.ptr(ym), n, 9, h, w, H.ptr(torch.eye(9, device=DEV)), H.ptr(b2), Ho, Wo, H.ptr(b))
+        err = float((a - b).abs().max() / a.abs().max())
+        print('tap mix vs 32-channel tail (%d,%d,%d,%d): %.2e' % (n, C, h, w, err))
+        assert err < 5e-6
+
+
+def test_refiner_with_and_without_tap_mix():
+    from collections import OrderedDict
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    torch.manual_seed(5)
+    chans = OrderedDict(layer5=64, layer4=48, layer3=32, layer2=24)
+    net = SegNetwork(1, 32, chans, True).eval().to(DEV)
+    dims = dict(layer5=(8, 14), layer4=(15, 27), layer3=(30, 54), layer2=(60, 107))
+    feats = {L: torch.relu(torch.randn(2, c, *dims[L], device=DEV)) for L, c in chans.items()}
+    scores = torch.randn(4, 1, 15, 27, device=DEV)
+    with torch.no_grad():
+        net.mix_taps = True
+        a = net._forward_hip(scores, feats, (240, 427)).clone()
+        net.mix_taps = False
+        b = net._forward_hip(scores, feats, (240, 427)).clone()
+    err = float((a - b).abs().max() / b.abs().max())
+    print('refiner, tail on nine tap maps vs on 16 channels: %.2e' % err)
+    assert err < 1e-5
