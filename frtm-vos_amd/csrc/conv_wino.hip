@@ -43,40 +43,40 @@ constexpr int WBM = 32;                // output channels per workgroup
 constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight block: [xi][lane][(kk,i)]
 
 // LDS carries only the raw input patch (three stages) and, at the end, the accumulator planes for the output transform (the same
-// 32 KB).  A first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
+// memory).  A first version staged the transformed weights and the 16 V planes through LDS like the direct kernels do and was
 // LDS-bandwidth bound (59 KB of LDS traffic per 64 MFMAs; the skeleton without MFMAs took 73 % of the time).  Now
 //  * the weights are packed in MFMA A-fragment order ([chunk][m_tile][xi][lane][4]) and go from L2 straight into registers:
-//    one dwordx4 per lane per component per chunk, a fully coalesced 1 KB per wave instruction, in a ring of three chunks;
+//    one dwordx4 per lane per component per chunk, a fully coalesced 1 KB per wave instruction, two register sets (chunk k, k+1);
 //  * wave `wid` owns the components xi = 4*wid .. 4*wid+3, i.e. ROW wid of the transformed 4x4 patch: each lane forms its own
 //    B fragments V[wid][0..3] for (channel = kk*4 + lane/16, tile = lane%16) from the two raw rows that row needs -- 8 LDS
 //    values in, 4 MFMA operands out, no transformed image in LDS and no transform stage;
 //  * the raw patch goes from global memory STRAIGHT into LDS (buffer_load ... lds: the hardware bounds checks still give the
 //    zero border; no register ring and no ds_write pass for it).  The LDS image is lane-linear: element e = tid + i*256 of the
-//    8 x PR x PC patch sits at word e of its stage (channel pitch = PR*PC);
-//  * per chunk: issue the loads of chunk k+2, compute chunk k, wait until this wave's part of patch k+1 has landed
-//    (s_waitcnt vmcnt(NR + 8): the loads issued after it may stay in flight), one barrier.
-// FN = 1: 8x8 output block (16 tiles), 128 registers -> four workgroups per CU.  FN = 2: 32 tiles per workgroup, as 8 rows x 16
-// columns (TALL = 0) or 16 rows x 8 columns (TALL = 1), 167 registers -> three per CU: every weight fragment feeds two MFMAs,
-// which halves the L2 -> register weight traffic per FLOP.
-// Round-2 measurements of this form against its predecessor (register ring for the patch, 4-chunk weight ring: 160 registers /
-// 3 workgroups per CU for FN = 1, 228 / 2 for FN = 2): trunk 118.1 -> 118.6 TF (two lanes), 105.8 -> 107.7 (one lane); the
-// refiner, whose single-M-tile convs take the FN = 2 forms, 31.6 -> 29.7 ms per 63 frames.  Occupancy is not what bounds the
-// trunk's convs: three structurally different variants (3 or 4 workgroups per CU, 8x8 or 8x16 blocks) run at the same rate.
-// Round 5 (per-workgroup phase stamps, tools/ktrace.py wino: of a 23 us workgroup life the K loop took 13.7 us -- 1.7 us per chunk against
-// 0.43 us of MFMA issue -- and the epilogue 6.2 us, 8.4 with a residual):
-//  * K loop: the loads of chunk k+2 were issued under `if (k + 2 < nch)`; counting the loads in flight behind the weight registers of chunk k
-//    the compiler had to assume the branch NOT taken and emitted s_waitcnt vmcnt(3) / (1) / (0) in front of the chunk's MFMAs -- which, with the
-//    branch taken, waits for the prefetch issued a few instructions earlier: every chunk paid a full L2 latency.  Now every chunk issues its
-//    NR + 4 loads unconditionally (past the end they are out of bounds: nothing is fetched, an unused stage receives zeros) and the counts are
-//    exact.  The compiler also orders every LDS read after every earlier LDS-DMA load (it cannot tell the stages apart: vmcnt(4) in front of
-//    each barrier, i.e. the patch of chunk k+2 had to land within chunk k); the B-fragment reads are therefore inline asm with their own
-//    lgkmcnt waits, and the barrier of a chunk waits only for patch k+1 (vmcnt(NR + 8)).
-//  * the input descriptor covers ONE image: channels past Cin (the tail chunk of a 65-channel conv, the chunks past the end) are out of
-//    bounds by themselves -- no per-load channel test;
-//  * epilogue: the column half of the output transform happens in registers (16 -> 8 planes), the planes are written as [plane][tile][cout]
-//    with one ds_write_b128 per accumulator (pitch 36: conflict-free), both tile groups in one exchange (one barrier instead of three), a
-//    thread then owns 4 consecutive output channels of one tile (8 x ds_read_b128); scale / shift / RESIDUAL are requested before the exchange.
-//    The output transform sums columns first, rows second (the earlier form rows first): rounding-level differences to round 4's results.
+//    8 x PR x PC patch sits at word e of its stage (channel pitch = PR*PC).  The descriptor covers ONE image: channels past Cin
+//    (the tail chunk of a 65-channel conv) are out of bounds by themselves;
+//  * per chunk k: request the weights of k+1 and the patch of k+2, compute chunk k, wait until this wave's part of patch k+1 has
+//    landed -- s_waitcnt vmcnt(NR + 4): the loads issued after it stay in flight --, one barrier.
+// FN = 1: 8x8 output block (16 tiles), 96 registers, 18 KB of LDS -> five workgroups per CU.  FN = 2: 32 tiles per workgroup, as
+// 8 rows x 16 columns (TALL = 0) or 16 rows x 8 columns (TALL = 1), ~150 registers, 37 KB -> three per CU: every weight fragment
+// feeds two MFMAs, which halves the L2 -> register weight traffic per FLOP.
+//
+// The load queue is counted BY HAND, and round 5 found that the counts the hardware saw were not the ones the source stated
+// (per-workgroup phase stamps, tools/ktrace.py wino, profiles/r05_wino_ktrace.txt: of a 23 us workgroup life the K loop took 13.7 us --
+// 1.7 us per chunk against 0.43 us of MFMA issue -- and the epilogue 6.2 us, 8.4 with a residual).  Rules this file now keeps:
+//  * no load under a condition.  The loads of chunk k+2 used to sit under `if (k + 2 < nch)`: counting the loads in flight behind the
+//    weight registers of chunk k, the compiler must assume the branch NOT taken, and emitted s_waitcnt vmcnt(3) / (1) / (0) in front of
+//    the chunk's MFMAs -- with the branch taken that waits for the prefetch issued a few instructions earlier;
+//  * nothing requested that is not used, and an explicit vmcnt(0) after the last chunk: the compiler orders every LDS access it sees
+//    after every LDS-DMA load it believes in flight (it cannot tell the stages apart);
+//  * for the same reason the B-fragment reads inside the K loop are inline asm with their own lgkmcnt waits (the compiler had put
+//    vmcnt(4) in front of the barriers: the patch of chunk k+2 had to land within chunk k);
+//  * sched_barriers pin the issue order the counts assume (the scheduler had swapped weight and patch loads in one of two chunks);
+//  * no spill inside the loop (scratch loads count in vmcnt too): check `hipcc -S` after every change to this file.
+// Epilogue: the column half of the output transform happens in registers (16 -> 8 planes), the planes are written as
+// [plane][tile][cout] with one ds_write_b128 per accumulator (pitch 36: conflict-free), both tile groups in one exchange, a thread
+// then owns CQ consecutive output channels of one tile; BN scale / shift wait in LDS since the kernel's start, residual and output
+// are buffer operations on per-image descriptors (invalid elements out of bounds: no branches), the residual requested before the
+// exchange.  The output transform sums columns first, rows second (round 4: rows first): rounding-level differences.
 __device__ __forceinline__ f32x4 lds_rd4(unsigned byte_addr) {      // 4 consecutive floats at an 8-byte aligned LDS address
   f32x4 v;
   asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(v) : "v"(byte_addr));
