@@ -41,6 +41,12 @@ __device__ unsigned g_kt_n[288];          // records per CU (xcc * 36 + se * 9 +
 #else
 #define KT_STAMP(i) do { } while (0)
 #endif
+#if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
+// the prologue by section (wave 0): address set-up | requests issued | first chunk in LDS | barrier passed   (intrusive: fences the scheduler)
+#define KT_PRO(i) do { __builtin_amdgcn_sched_barrier(0); kp[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define KT_PRO(i) do { } while (0)
+#endif
 
 // MODE 0: generic gather (any kernel size / stride / padding), one dword per lane per k row.
 // MODE 1: 1x1, stride 1, Npix % 4 == 0: activations staged as dwordx4 along the pixel axis.
@@ -70,8 +76,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   const int wm = wid / WGN, wn = wid % WGN;
 #ifdef FRTM_DEBUG_TRACE
   unsigned long long kt[4] = {0, 0, 0, 0};
+#if FRTM_DEBUG_TRACE >= 2
+  unsigned long long kp[4] = {0, 0, 0, 0};
+#endif
 #endif
   KT_STAMP(0);
+  // (Round 5, wave 0's prologue by section, tools/ktrace.py pro / profiles/r05_prologue_priority_ab.txt: 1.6 us of address arithmetic, 2.7 us issuing a
+  //  dozen loads, 0.35 us until they are in LDS, 1.8 us at the barrier waiting for the workgroup's other waves -- a 6.4 us prologue is instruction issue
+  //  next to seven waves in their K loops, not memory latency.  s_setprio 3 around prologue and epilogue halves it (6.7 -> 3.6 us under two lanes) and
+  //  puts three workgroups of a CU inside their K loops 63 % instead of 37 % of the time -- and the K loops slow down by as much: trunk pass 15.35 ->
+  //  16.05 ms.  The matrix pipes are not waiting for workgroups to arrive.  Not kept.)
   int m_tile, n_tile;
   tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, n_tile);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
@@ -215,11 +229,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   };
   const int lk = lane >> 4, li = lane & 15;
   {
+  KT_PRO(0);
   epi_prefetch_small();
   if (kc0 < kc1) gload(kc0);
   epi_prefetch_res();
+  KT_PRO(1);
   if (kc0 < kc1) lstore(0);
+#if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  KT_PRO(2);
   __syncthreads();
+  KT_PRO(3);
   KT_STAMP(1);
   for (int kc = kc0; kc < kc1; ++kc) {
     const int cur = (kc - kc0) & 1;
@@ -349,6 +370,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       r[1] = xccid;                                           // HW_REG_XCC_ID
       r[2] = kt[0]; r[3] = kt[1]; r[4] = kt[2]; r[5] = wall_clock64();
       r[6] = ((unsigned long long)blockIdx.x << 32) | (unsigned)gridDim.x;
+#if FRTM_DEBUG_TRACE >= 2
+      r[6] = ((kp[0] - kt[0]) << 48) | ((kp[1] - kt[0]) << 32) | ((kp[2] - kt[0]) << 16) | (kp[3] - kt[0]);     // ticks since the entry
+#endif
       r[7] = ((unsigned long long)BM << 48) | ((unsigned long long)BN << 32) | ((unsigned long long)p.K << 8) | (unsigned)MODE;
     }
   }

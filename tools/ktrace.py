@@ -24,7 +24,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from frtm_vos_amd import _hip  # noqa: E402
 
-_hip.LIB_PATH = os.path.join(ROOT, 'tools', '_ab_ktrace2.so' if sys.argv[1:2] == ['wino2'] else '_ab_ktrace.so')
+PRO = sys.argv[1:2] == ['pro']               # -DFRTM_DEBUG_TRACE=2 build of conv_igemm.hip as well: the prologue of k_conv_igemm by section
+if PRO:
+    sys.argv.pop(1)
+_hip.LIB_PATH = os.path.join(ROOT, 'tools', '_ab_ktrace2.so' if (PRO or sys.argv[1:2] == ['wino2']) else '_ab_ktrace.so')
 from frtm_vos_amd import ops  # noqa: E402
 
 DEV = 'cuda:0'
@@ -113,6 +116,11 @@ def summarize(name, rec, flops, wino=False):
     if wino:
         print('%-34s   wave 0, summed over the chunks of a workgroup (us, mean): end-of-chunk vmcnt wait %.2f   barrier %.2f'
               % ('', (rec[:, 6].astype(np.int64) >> 32).mean() * 0.01, (rec[:, 6].astype(np.int64) & 0xffffffff).mean() * 0.01))
+    if PRO and not wino:
+        e = rec[:, 6].astype(np.uint64)
+        ps = np.stack([(e >> np.uint64(48)) & np.uint64(0xffff), (e >> np.uint64(32)) & np.uint64(0xffff), (e >> np.uint64(16)) & np.uint64(0xffff), e & np.uint64(0xffff)], 1).astype(np.float64) * 0.01
+        print('%-34s   prologue of wave 0, us after the entry (mean): address set-up done %.2f  requests issued %.2f  first chunk in LDS %.2f  barrier passed %.2f'
+              % ('', ps[:, 0].mean(), ps[:, 1].mean(), ps[:, 2].mean(), ps[:, 3].mean()))
     first = t[:, 0] < 0.1 * span
     print('%-34s   first round (entered in the first tenth of the span: %d WGs) prologue %.2f, later rounds %.2f us' % ('', int(first.sum()), pro[first].mean(), pro[~first].mean() if (~first).any() else float('nan')))
     return span
