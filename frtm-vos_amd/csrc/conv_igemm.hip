@@ -87,13 +87,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   //  puts three workgroups of a CU inside their K loops 63 % instead of 37 % of the time -- and the K loops slow down by as much: trunk pass 15.35 ->
   //  16.05 ms.  The matrix pipes are not waiting for workgroups to arrive.  Not kept.)
   int m_tile, n_tile;
-  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, n_tile);
+  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, p.dMt, m_tile, n_tile);
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   // p.nchunks / p.chunks_per_split count 32-deep chunks; a 64-deep instantiation walks them in pairs
   const int kc0 = blockIdx.z * p.chunks_per_split / (BK / 32);
   const int kc1 = min((p.nchunks + BK / 32 - 1) / (BK / 32), (int)((blockIdx.z + 1) * p.chunks_per_split / (BK / 32)));
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const float* wbase = (MODE == 1 && p.w_img_stride) ? p.wT + (size_t)(n0 / p.Npix) * p.w_img_stride : p.wT;      // batched GEMM: one weight matrix per image
+  const float* wbase = (MODE == 1 && p.w_img_stride) ? p.wT + (size_t)fdiv(n0, p.dNpix) * p.w_img_stride : p.wT;      // batched GEMM: one weight matrix per image
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     bcol = (tid % TB4) * 4; brow = tid / TB4;
     const int n = n0 + bcol;
     if (n < p.Ntot) {
-      const int img = n / p.Npix, rem = n - img * p.Npix;
+      const int img = fdiv(n, p.dNpix), rem = n - img * p.Npix;
       b_base = (unsigned)(img * p.Cin * HWin + rem) * 4u;
       if (MODE == 2) nfirst = min(4, p.Npix - rem);
     }
@@ -116,12 +116,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     bcol = tid % BN; brow = __builtin_amdgcn_readfirstlane(tid / BN);
     const int n = n0 + bcol;
     if (n < p.Ntot) {
-      const int img = n / p.Npix, rem = n - img * p.Npix;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int img = fdiv(n, p.dNpix), rem = n - img * p.Npix;
+      const int oy = fdiv(rem, p.dWo), ox = rem - oy * p.Wo;
       iy0 = oy * p.stride - p.pad; ix0 = ox * p.stride - p.pad;
       b_base = (unsigned)(img * p.Cin * HWin) * 4u + (unsigned)((iy0 * p.Win + ix0) * 4);
     } else { iy0 = -(1 << 20); }
   }
+  const unsigned a_voff = (unsigned)arow * (unsigned)(p.Mp * 4) + a_off;                                    // per-lane part of the A offsets
+  const unsigned b_voff = (MODE == 1 && b_base != OOB) ? b_base + (unsigned)brow * (unsigned)(HWin * 4) : OOB;   // ... of MODE 1's B offsets
   const unsigned wrap = (unsigned)((p.Cin - 1) * HWin) * 4u;      // MODE 2: column j >= nfirst sits at b_base + 4 j + wrap (next image, same channel)
 
   f32x4 ra[PA];
@@ -129,13 +131,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   float rb[MODE != 0 ? 1 : EB];
   auto gload_to = [&](int kc, f32x4* ra, f32x4* rb4) {
     const int kb = kc * BK;
+    // (row offsets through the scalar-offset field: no VALU instruction per load; wT is zero padded to whole chunks of rows)
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = buf_ld4(rw, (unsigned)(kb + arow + i * RA) * (unsigned)(p.Mp * 4) + a_off);
+    for (int i = 0; i < PA; ++i) ra[i] = buf_ld4s(rw, a_voff, (unsigned)(kb + i * RA) * (unsigned)(p.Mp * 4));
     if (MODE == 1) {
+      if (kb + BK <= p.K) {                                                       // wave-uniform: every k row of the chunk exists
 #pragma unroll
-      for (int i = 0; i < PB4; ++i) {
-        const int k = kb + brow + i * RB4;
-        rb4[i] = buf_ld4(rin, (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4));
+        for (int i = 0; i < PB4; ++i) rb4[i] = buf_ld4s(rin, b_voff, (unsigned)(kb + i * RB4) * (unsigned)(HWin * 4));
+      } else {
+#pragma unroll
+        for (int i = 0; i < PB4; ++i) {
+          const int k = kb + brow + i * RB4;
+          rb4[i] = buf_ld4(rin, (b_base == OOB || k >= p.K) ? OOB : b_base + (unsigned)k * (unsigned)(HWin * 4));
+        }
       }
     } else if (MODE == 2) {
 #pragma unroll
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
         const int row = idx / (BN / 4), c4 = (idx - row * (BN / 4)) * 4;
         const int mm = m0 + row, nn = n0 + c4;
         const bool ok = e_pre && mm < p.M && nn < p.Ntot;
-        const int img = nn / p.Npix, rem = nn - img * p.Npix;
+        const int img = fdiv(nn, p.dNpix), rem = nn - img * p.Npix;
         e_off[e] = ok ? (unsigned)((((size_t)img * p.M + mm) * p.Npix + rem) * 4) : OOB;
         const unsigned so = (ok && p.scale) ? (unsigned)mm * 4u : OOB;
         e_sc[e] = buf_ld1(rsc, so);
@@ -242,35 +250,55 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   __syncthreads();
   KT_PRO(3);
   KT_STAMP(1);
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const int cur = (kc - kc0) & 1;
+  // One chunk on LDS buffer CUR (a compile-time constant: the loop below is unrolled by two).  Every VALU instruction takes ~4 cycles from the matrix
+  // pipe (tools/mfma_valu_probe.hip), so the loop carries none that can be avoided: buffer, k-step and fragment offsets are immediates of ds_read_b32
+  // on two per-lane base addresses (inline asm with its own lgkmcnt waits: the compiler pairs such reads into ds_read2_b32 and pays a v_add_u32 per
+  // pair for the offsets that do not fit its 8-bit fields), and MODE 1's operand loads take their row offsets through the scalar offset of the load.
+  const unsigned a_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&As[0][lk][wm * TM + li];
+  const unsigned b_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)&Bs[0][lk][wn * TN + li];
+  auto lds_rd1 = [](unsigned base, auto off) { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off)); return v; };
+  auto chunk = [&](int kc, auto CUR_) {
+    constexpr int CUR = decltype(CUR_)::value;
     const bool more = (kc + 1) < kc1;
     if (more) gload(kc + 1);
     // fragment reads are software pipelined: the LDS reads of k-step kk+1 are issued before the MFMAs of k-step kk,
     // so the matrix pipe never waits a full LDS round trip (the compiler emits counted lgkmcnt waits for this form)
     float af[2][FM], bf[2][FN];
+    constexpr int AO = CUR * BK * LDA * 4, BO = CUR * BK * LDB * 4;          // byte offset of buffer CUR
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[0][i] = As[cur][lk][wm * TM + i * 16 + li];
+    for (int i = 0; i < FM; ++i) af[0][i] = lds_rd1(a_lds, AO + i * 64);
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bf[0][j] = Bs[cur][lk][wn * TN + j * 16 + li];
+    for (int j = 0; j < FN; ++j) bf[0][j] = lds_rd1(b_lds, BO + j * 64);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       if (kk + 1 < BK / 4) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = As[cur][(kk + 1) * 4 + lk][wm * TM + i * 16 + li];
+        for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = lds_rd1(a_lds, AO + ((kk + 1) * 4 * LDA + i * 16) * 4);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bf[(kk + 1) & 1][j] = Bs[cur][(kk + 1) * 4 + lk][wn * TN + j * 16 + li];
+        for (int j = 0; j < FN; ++j) bf[(kk + 1) & 1][j] = lds_rd1(b_lds, BO + ((kk + 1) * 4 * LDB + j * 16) * 4);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(FM + FN));                // the reads of k-step kk have returned, those of kk+1 stay in flight
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)");
       }
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[kk & 1][i]));    // (ties: the MFMAs below stay behind the wait)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(bf[kk & 1][j]));
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) lstore(cur ^ 1);
+    if (more) lstore(CUR ^ 1);
     __syncthreads();
+  };
+  int kc = kc0;
+  for (; kc + 2 <= kc1; kc += 2) {
+    chunk(kc, std::integral_constant<int, 0>{});
+    chunk(kc + 1, std::integral_constant<int, 1>{});
   }
+  if (kc < kc1) chunk(kc, std::integral_constant<int, 0>{});
 
   }
 
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       if (mm >= p.M || nn >= p.Ntot) continue;
       f32x4 v = *(const f32x4*)&Cs[row * LDC + c4];
       if (raw) { *(f32x4*)&dst[(size_t)mm * p.Ntot + nn] = v; continue; }
-      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      const int img = fdiv(nn, p.dNpix), rem = nn - img * p.Npix;
       const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
       if (p.scale) { const float a = p.scale[mm], b = p.shift[mm]; v = v * a + b; }
       if (p.residual) v += *(const f32x4*)&p.residual[o];
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       const int mm = m0 + row, nn = n0 + c4;
       if (mm >= p.M || nn >= p.Ntot) continue;
       f32x4 v = *(const f32x4*)&Cs[row * LDC + c4];
-      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      const int img = fdiv(nn, p.dNpix), rem = nn - img * p.Npix;
       if (rem + 4 <= p.Npix) {
         if (raw) { *(f32x4u*)&dst[(size_t)mm * p.Ntot + nn] = v; continue; }
         const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
           const int n1 = nn + j;
           if (n1 >= p.Ntot) break;
           if (raw) { dst[(size_t)mm * p.Ntot + n1] = v[j]; continue; }
-          const int im1 = n1 / p.Npix;
+          const int im1 = fdiv(n1, p.dNpix);
           store_out(p, mm, im1, n1 - im1 * p.Npix, v[j]);
         }
       }
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
       if (mm >= p.M || nn >= p.Ntot) continue;
       float v = Cs[row * LDC + col];
       if (raw) { dst[(size_t)mm * p.Ntot + nn] = v; continue; }
-      const int img = nn / p.Npix, rem = nn - img * p.Npix;
+      const int img = fdiv(nn, p.dNpix), rem = nn - img * p.Npix;
       const size_t o = ((size_t)img * p.M + mm) * p.Npix + rem;
       if (p.scale) v = v * p.scale[mm] + p.shift[mm];
       if (p.residual) v += p.residual[o];
@@ -578,13 +606,17 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 static inline bool halo_layout_requested(const frtm_conv_desc* d) { return d->w_layout == FRTM_WLAYOUT_HALO3X3; }
 
 template <int BM, int BN, int WGM, int WGN>
-static void launch_tile_u(const ConvParams& p, hipStream_t st) {
+static void launch_tile_u(const ConvParams& p_, hipStream_t st) {
+  ConvParams p = p_;
+  fill_divs(p, BM);
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
   k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT = 32>
-static void launch_tile(const ConvParams& p, bool vec1x1, hipStream_t st) {
+static void launch_tile(const ConvParams& p_, bool vec1x1, hipStream_t st) {
+  ConvParams p = p_;
+  fill_divs(p, BM);
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
   if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv_igemm<BM, BN, WGM, WGN, 0, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);

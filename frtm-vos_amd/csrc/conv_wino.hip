@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const int tiles_x = (p.Wo + BW - 1) / BW, tiles_y = (p.Ho + BH - 1) / BH;
   const int mt = (p.M + WBM - 1) / WBM;
   int m_tile, bt;
-  tile_order(blockIdx.x, gridDim.x, mt, m_tile, bt);
-  const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
-  const int by = bt / tiles_x, bx = bt - by * tiles_x;
+  tile_order(blockIdx.x, gridDim.x, mt, p.dMt, m_tile, bt);
+  const int img = fdiv(bt, p.dA); bt -= img * tiles_x * tiles_y;             // (uniform: multiplications on the scalar unit instead of VALU division sequences)
+  const int by = fdiv(bt, p.dB), bx = bt - by * tiles_x;
   const int y0 = by * BH, x0 = bx * BW, m0 = m_tile * WBM;
   // BN scale / shift of this workgroup's 32 output channels -> LDS, requested first thing (the epilogue reads them from there)
   __shared__ __attribute__((aligned(16))) float ssc[2 * WBM];
@@ -444,6 +444,9 @@ int frtm_wino_launch(ConvParams& p, int variant, hipStream_t st) {
     // behind on the small ones (@ 30x54: 20.7 vs 19.5); more M tiles: the 8x8 form
     if (mt > 2 || a * 100 > a1 * 115 || blocks2 < (mt == 1 ? 512 : 1024)) variant = 1;
   }
+  p.dMt = fast_div((unsigned)mt);
+  { const int bh = variant == 3 ? 16 : 8, bw = variant == 2 ? 16 : 8;
+    p.dA = fast_div((unsigned)(ceil_div(p.Ho, bh) * ceil_div(p.Wo, bw))); p.dB = fast_div((unsigned)ceil_div(p.Wo, bw)); }
   if (variant == 2) {
     k_conv3x3_wino<2, 0, 3><<<p.B * ceil_div(p.Ho, 8) * ceil_div(p.Wo, 16) * mt, 256, 0, st>>>(p);
   } else if (variant == 3) {
