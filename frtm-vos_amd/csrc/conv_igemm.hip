@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 #if FRTM_DEBUG_TRACE >= 2
   unsigned long long kp[4] = {0, 0, 0, 0};
 #endif
+  const unsigned long long kclk0 = __builtin_readcyclecounter();        // s_memtime: shader clock
 #endif
   KT_STAMP(0);
   // (Round 5, wave 0's prologue by section, tools/ktrace.py pro / profiles/r05_prologue_priority_ab.txt: 1.6 us of address arithmetic, 2.7 us issuing a
@@ -293,12 +294,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     if (more) lstore(CUR ^ 1);
     __syncthreads();
   };
-  int kc = kc0;
-  for (; kc + 2 <= kc1; kc += 2) {
-    chunk(kc, std::integral_constant<int, 0>{});
-    chunk(kc + 1, std::integral_constant<int, 1>{});
+  if constexpr (MODE != 0) {
+    int kc = kc0;
+    for (; kc + 2 <= kc1; kc += 2) {
+      chunk(kc, std::integral_constant<int, 0>{});
+      chunk(kc + 1, std::integral_constant<int, 1>{});
+    }
+    if (kc < kc1) chunk(kc, std::integral_constant<int, 0>{});
+  } else {
+    // gather mode (7x7 stem, strided convs: a table look-up and a bounds test per loaded element) keeps round 4's loop: the compiler schedules its many
+    // loads between the MFMAs, and the unrolled form with fenced asm reads measured 30 % slower here (profiles/r05_valu_diet_ab.txt)
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const int cur = (kc - kc0) & 1;
+      const bool more = (kc + 1) < kc1;
+      if (more) gload(kc + 1);
+      float af[2][FM], bf[2][FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[0][i] = As[cur][lk][wm * TM + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[0][j] = Bs[cur][lk][wn * TN + j * 16 + li];
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        if (kk + 1 < BK / 4) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = As[cur][(kk + 1) * 4 + lk][wm * TM + i * 16 + li];
+#pragma unroll
+          for (int j = 0; j < FN; ++j) bf[(kk + 1) & 1][j] = Bs[cur][(kk + 1) * 4 + lk][wn * TN + j * 16 + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (the scheduler otherwise sinks it)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) lstore(cur ^ 1);
+      __syncthreads();
+    }
   }
-  if (kc < kc1) chunk(kc, std::integral_constant<int, 0>{});
 
   }
 
@@ -395,7 +428,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
     if (local < per) {
       unsigned long long* r = g_kt_buf + ((size_t)key * per + local) * 8;
       r[0] = hwid;                                            // HW_REG_HW_ID
-      r[1] = xccid;                                           // HW_REG_XCC_ID
+      r[1] = (xccid & 0xffu) | ((__builtin_readcyclecounter() - kclk0) << 8);     // HW_REG_XCC_ID | shader-clock cycles of this workgroup's life
       r[2] = kt[0]; r[3] = kt[1]; r[4] = kt[2]; r[5] = wall_clock64();
       r[6] = ((unsigned long long)blockIdx.x << 32) | (unsigned)gridDim.x;
 #if FRTM_DEBUG_TRACE >= 2

@@ -116,6 +116,11 @@ def summarize(name, rec, flops, wino=False):
     if wino:
         print('%-34s   wave 0, summed over the chunks of a workgroup (us, mean): end-of-chunk vmcnt wait %.2f   barrier %.2f'
               % ('', (rec[:, 6].astype(np.int64) >> 32).mean() * 0.01, (rec[:, 6].astype(np.int64) & 0xffffffff).mean() * 0.01))
+    if not wino:
+        cyc = (rec[:, 1].astype(np.uint64) >> np.uint64(8)).astype(np.float64)
+        life = (rec[:, 5].astype(np.int64) - rec[:, 2].astype(np.int64)).astype(np.float64) * 0.01      # us
+        if cyc.max() > 0:
+            print('%-34s   s_memtime cycles per microsecond of workgroup life (mean): %.0f' % ('', (cyc / np.maximum(life, 1e-9)).mean()))
     if PRO and not wino:
         e = rec[:, 6].astype(np.uint64)
         ps = np.stack([(e >> np.uint64(48)) & np.uint64(0xffff), (e >> np.uint64(32)) & np.uint64(0xffff), (e >> np.uint64(16)) & np.uint64(0xffff), e & np.uint64(0xffff)], 1).astype(np.float64) * 0.01
