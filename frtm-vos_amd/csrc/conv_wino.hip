@@ -77,10 +77,12 @@ constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight b
 // then owns CQ consecutive output channels of one tile; BN scale / shift wait in LDS since the kernel's start, residual and output
 // are buffer operations on per-image descriptors (invalid elements out of bounds: no branches), the residual requested before the
 // exchange.  The output transform sums columns first, rows second (round 4: rows first): rounding-level differences.
-__device__ __forceinline__ f32x4 lds_rd4(unsigned byte_addr) {      // 4 consecutive floats at an 8-byte aligned LDS address
-  f32x4 v;
-  asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(v) : "v"(byte_addr));
-  return v;
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+// 4 consecutive floats at the 8-byte aligned LDS address base + OFF, as two pairs; OFF is an immediate of the instructions (no VALU addition:
+// a VALU instruction takes ~4 cycles of matrix-pipe time, an LDS instruction about one -- tools/mfma_valu_probe.hip)
+template <int OFF>
+__device__ __forceinline__ void lds_rd4i(unsigned base, f32x2w& lo, f32x2w& hi) {
+  asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(base), "n"(OFF), "n"(OFF + 8));
 }
 
 template <int FN, int TALL, int WAVES>
@@ -135,14 +137,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const f32x2 sb2 = {sb_, sb_};
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;      // LDS byte address of smem
-  unsigned offA[FN], offB[FN];                                                                 // LDS byte addresses inside stage 0, k-step 0
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int t_r = (li >> 2) + ((FN == 2 && TALL) ? 4 * j : 0), t_c = (li & 3) + ((FN == 2 && !TALL) ? 4 * j : 0);
-    const int po = (2 * t_r) * PC + 2 * t_c;
-    offA[j] = lds0 + (unsigned)(lk * PE + po + ra_ * PC) * 4u;
-    offB[j] = lds0 + (unsigned)(lk * PE + po + rb_ * PC) * 4u;
-  }
+  // LDS byte addresses inside stage 0, k-step 0, tile group 0; the second tile group sits JO bytes further (4 tile columns or 4 tile rows)
+  constexpr int JO = ((FN == 2 && TALL) ? 8 * PC : 8) * 4;
+  const int po0 = (2 * (li >> 2)) * PC + 2 * (li & 3);
+  const unsigned offA0 = lds0 + (unsigned)(lk * PE + po0 + ra_ * PC) * 4u, offB0 = lds0 + (unsigned)(lk * PE + po0 + rb_ * PC) * 4u;
 
   f32x4 fa[2][4];
   auto gloadA = [&](int kc, f32x4* dst) {
@@ -180,14 +178,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   // waiting for LDS reads, 1800 issuing 32 MFMAs, 310 in the barrier): the LDS reads of k-step 0 go first and the four weight loads are issued
   // under their latency; the reads of k-step 1 and the NR patch loads are spread over the MFMAs of k-step 0, whose execution covers their issue.
   // The sched_barriers pin this order (and with it the order of the load queue the vmcnt values count).
-  auto operands = [&](const f32x4* da, const f32x4* db, float (*bq)[4]) {
+  auto operands = [&](const f32x2* alo, const f32x2* ahi, const f32x2* blo, const f32x2* bhi, float (*bq)[4]) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {                        // B^T d B of this lane's (channel, tile), row wid: two-float operations on register pairs
-      const f32x2 u01 = da[j].lo + sb2 * db[j].lo, u23 = da[j].hi + sb2 * db[j].hi;
+      const f32x2 u01 = alo[j] + sb2 * blo[j], u23 = ahi[j] + sb2 * bhi[j];
       const f32x2 d = u01 - u23;                          // (u0 - u2, u1 - u3)
       bq[j][0] = d.x; bq[j][1] = u01.y + u23.x; bq[j][2] = u23.x - u01.y; bq[j][3] = d.y;
     }
   };
+  // one k-step's raw rows of both tile groups: 4 x FN ds_read_b64, every offset an immediate
+  auto rows = [&](unsigned aS, unsigned bS, auto KK_, f32x2* alo, f32x2* ahi, f32x2* blo, f32x2* bhi) {
+    constexpr int KO = decltype(KK_)::value * 4 * PE * 4;
+    lds_rd4i<KO>(aS, alo[0], ahi[0]); lds_rd4i<KO>(bS, blo[0], bhi[0]);
+    if constexpr (FN == 2) { lds_rd4i<KO + JO>(aS, alo[1], ahi[1]); lds_rd4i<KO + JO>(bS, blo[1], bhi[1]); }
+  };
+  auto wait_rows = [&](f32x2* alo, f32x2* ahi, f32x2* blo, f32x2* bhi) {
+    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { asm volatile("" : "+v"(alo[j])); asm volatile("" : "+v"(ahi[j])); asm volatile("" : "+v"(blo[j])); asm volatile("" : "+v"(bhi[j])); }
+  };
+  // (the chunk step of the patch offsets stays a VALU addition per load: with it in the load's scalar offset the channel bound would no longer be
+  //  checked, and a uniform branch between the two forms cost exact load counts and registers -- 14 spills)
   // LOADS: 2 = a chunk in the middle (requests the weights of k+1 and the patch of k+2), 1 = the chunk before the last (weights only), 0 = the last
   // one.  No request is ever issued for data that is not used: after the last chunk nothing is in flight, and -- what matters -- the compiler KNOWS
   // it (explicit vmcnt(0)): it orders every LDS access it can see after all LDS-DMA loads it believes in flight, and with dummy loads past the end it
@@ -198,18 +209,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 #if defined(FRTM_DEBUG_TRACE) && FRTM_DEBUG_TRACE >= 2
     kt_last = __builtin_amdgcn_s_memrealtime();
 #endif
-    const unsigned so0 = (unsigned)(st * STAGE * 4), so1 = so0 + (unsigned)(4 * PE * 4);
+    const unsigned aS = offA0 + (unsigned)(st * STAGE * 4), bS = offB0 + (unsigned)(st * STAGE * 4);     // the only two address additions of a chunk
     const int st2 = st == 0 ? 2 : st - 1;
-    f32x4 da0[FN], db0[FN], da1[FN], db1[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) { da0[j] = lds_rd4(offA[j] + so0); db0[j] = lds_rd4(offB[j] + so0); }
+    f32x2 a0lo[FN], a0hi[FN], b0lo[FN], b0hi[FN], a1lo[FN], a1hi[FN], b1lo[FN], b1hi[FN];
+    rows(aS, bS, std::integral_constant<int, 0>{}, a0lo, a0hi, b0lo, b0hi);
     if constexpr (LOADS >= 1) gloadA(k + 1, fa[F ^ 1]);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da0[0]), "+v"(db0[0]), "+v"(da0[1]), "+v"(db0[1]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da0[0]), "+v"(db0[0]));
+    wait_rows(a0lo, a0hi, b0lo, b0hi);
     KTW_IN(0);
     float bq[FN][4];
-    operands(da0, db0, bq);
+    operands(a0lo, a0hi, b0lo, b0hi, bq);
     const unsigned cstep = (unsigned)((k + 2) * WCI) * (unsigned)(HWin * 4);   // channels >= Cin: beyond the image's descriptor = zeros
     constexpr int PER = (NR + 2) / 3;                                          // patch loads after each of the first three MFMA groups
 #pragma unroll
@@ -219,10 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         acc[q][0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][0], bq[j][q], acc[q][0][j], 0, 0, 0);
         acc[q][1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[F][q][1], bq[j][q], acc[q][1][j], 0, 0, 0);
       }
-      if (q == 0) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) { da1[j] = lds_rd4(offA[j] + so1); db1[j] = lds_rd4(offB[j] + so1); }
-      }
+      if (q == 0) rows(aS, bS, std::integral_constant<int, 1>{}, a1lo, a1hi, b1lo, b1hi);
       if constexpr (LOADS == 2)
 #pragma unroll
       for (int i = q * PER; i < (q + 1) * PER && i < NR; ++i)
@@ -231,10 +237,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       __builtin_amdgcn_sched_barrier(0);
     }
     KTW_IN(1);
-    if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da1[0]), "+v"(db1[0]), "+v"(da1[1]), "+v"(db1[1]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(da1[0]), "+v"(db1[0]));
+    wait_rows(a1lo, a1hi, b1lo, b1hi);
     KTW_IN(2);
-    operands(da1, db1, bq);
+    operands(a1lo, a1hi, b1lo, b1hi, bq);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
