@@ -57,11 +57,25 @@ struct frtm_backbone {
   int generation = 0;          // bumped whenever an arena / workspace is (re)allocated: captured graphs of older generations are stale
 };
 
-__global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __restrict__ img, int HW, const float* __restrict__ sc,
-                                                       const float* __restrict__ bi, float* __restrict__ out, size_t total) {
+// uint8 frame -> normalised float planes (feature_extractor.py:42) WITH the stem's zero border of P pixels written out: the 7x7 stride-2 conv then
+// gathers without a bounds test per tap (csrc/conv_igemm.hip, gather mode with pad = 0).  One thread per 4 output columns of a padded row.
+__global__ __launch_bounds__(256) void k_normalize_u8(const unsigned char* __restrict__ img, int H, int W, int P, const float* __restrict__ sc,
+                                                       const float* __restrict__ bi, float* __restrict__ out, int planes) {
+  const int Wp = W + 2 * P, Hp = H + 2 * P, q4 = (Wp + 3) / 4;
+  const size_t total = (size_t)planes * Hp * q4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (int)((i / HW) % 3);
-    out[i] = sc[c] * (float)img[i] + bi[c];                  // feature_extractor.py:42
+    const int xq = (int)(i % q4);
+    const size_t r = i / q4;
+    const int yp = (int)(r % Hp), pl = (int)(r / Hp), c = pl % 3;
+    const int y = yp - P;
+    const float s = sc[c], b = bi[c];
+    float* o = out + ((size_t)pl * Hp + yp) * Wp + xq * 4;
+    const unsigned char* src = img + ((size_t)pl * H + (y < 0 || y >= H ? 0 : y)) * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xp = xq * 4 + j, x = xp - P;
+      if (xp < Wp) o[j] = (y >= 0 && y < H && x >= 0 && x < W) ? s * (float)src[x] + b : 0.f;
+    }
   }
 }
 
@@ -122,14 +136,15 @@ static int scanned_tile(const ConvL& c, int B, int Ho, int Wo, bool products) {
 }
 
 static int run_conv(frtm_backbone* bb, Lane& ln, int idx, int B, int Hin, int Win, const float* in, const float* residual, int relu,
-                    float* out, int* Ho, int* Wo, hipStream_t st) {
+                    float* out, int* Ho, int* Wo, hipStream_t st, int pad_override = -1) {
   ConvL& c = bb->convs[idx];
   if (!c.loaded) { frtm_set_error("backbone: conv %d has no weights (call frtm_backbone_set_conv)", idx); return FRTM_ERR_STATE; }
+  const int pad = pad_override >= 0 ? pad_override : c.pad;   // (the stem runs on an image whose border the normalisation kernel has written)
   frtm_conv_desc d;
-  d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = c.pad;
+  d.B = B; d.Cin = c.Cin; d.Hin = Hin; d.Win = Win; d.Cout = c.Cout; d.ksize = c.ks; d.stride = c.stride; d.pad = pad;
   d.relu = relu; d.out_transposed = 0; d.splitk = 0; d.tile = 0; d.w_pitch = 0; d.w_layout = c.layout; d.ws_elems = 0;
-  *Ho = (Hin + 2 * c.pad - c.ks) / c.stride + 1;
-  *Wo = (Win + 2 * c.pad - c.ks) / c.stride + 1;
+  *Ho = (Hin + 2 * pad - c.ks) / c.stride + 1;
+  *Wo = (Win + 2 * pad - c.ks) / c.stride + 1;
   // conv2d plans tile/split-K itself; the workspace must cover the largest split it can pick.  Split-K is only
   // chosen when the launch has < ~800 workgroups, i.e. Cout*N <= ~800*64*64 elements, so bound it by that.
   {
@@ -208,7 +223,7 @@ static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {
     need = std::max(need, (size_t)(64 << s) * exp * ah * aw);
     need = std::max(need, (size_t)(64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
   }
-  return std::max(need, (size_t)3 * H * W);
+  return std::max(need, (size_t)3 * (H + 6) * (W + 6));              // (the normalised image carries the stem's border)
 }
 
 static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
@@ -225,11 +240,12 @@ static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_
     ln.buf_elems = need;
   }
   float* norm = ln.buf[0];
-  const size_t npx = (size_t)B * 3 * H * W;
-  k_normalize_u8<<<(int)min((npx + 255) / 256, (size_t)4096), 256, 0, st>>>(image_u8, H * W, norm_scale3, norm_bias3, norm, npx);
+  const int P = bb->convs[0].pad;                              // the stem's padding, materialised by the normalisation kernel
+  const size_t nq = (size_t)B * 3 * (H + 2 * P) * ((W + 2 * P + 3) / 4);
+  k_normalize_u8<<<(int)min((nq + 255) / 256, (size_t)8192), 256, 0, st>>>(image_u8, H, W, P, norm_scale3, norm_bias3, norm, B * 3);
   FRTM_LAUNCH_CHECK();
   int h1, w1;
-  int rc = run_conv(bb, ln, 0, B, H, W, norm, nullptr, 1, ln.buf[1], &h1, &w1, st);   // conv1 + bn1 + relu
+  int rc = run_conv(bb, ln, 0, B, H + 2 * P, W + 2 * P, norm, nullptr, 1, ln.buf[1], &h1, &w1, st, 0);   // conv1 + bn1 + relu on the padded image
   if (rc) return rc;
   const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
   float* x = layer1 ? layer1 : ln.buf[2];

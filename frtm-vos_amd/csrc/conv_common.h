@@ -73,6 +73,9 @@ __device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte
 }
 
 // the same with a wave-uniform part of the offset in the load's scalar-offset field (no VALU addition; the bounds check sees the per-lane part)
+__device__ __forceinline__ float buf_ld1s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)uniform_off, 0));
+}
 __device__ __forceinline__ f32x4 buf_ld4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned uniform_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)uniform_off, 0));
 }

@@ -158,6 +158,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
           for (int j = 0; j < 4; ++j) rb4[i][j] = buf_ld1(rin, o == OOB ? OOB : o + 4u * j + (j >= nfirst ? wrap : 0u));
         }
       }
+    } else if (p.pad == 0 && kb + BK <= p.K) {
+      // gather without padding (the stem on its pre-padded image, strided 1x1 convs), every k row of the chunk real: no tap can fall outside the
+      // map, the tap's offset is wave-uniform -> it rides in the scalar offset of the load, no VALU instruction per element (8 before)
+#pragma unroll
+      for (int i = 0; i < EB; ++i) {
+        const int k = kb + brow + i * SB;                  // wave uniform
+        int ci = k, kh = 0, kw = 0;
+        if (p.ktab) { ci = p.ktab[k * 3]; kh = p.ktab[k * 3 + 1]; kw = p.ktab[k * 3 + 2]; }
+        rb[i] = buf_ld1s(rin, b_base, (unsigned)((ci * HWin + kh * p.Win + kw) * 4));
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < EB; ++i) {
