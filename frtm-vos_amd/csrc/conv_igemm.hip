@@ -479,16 +479,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
   const int wm = wid / WGN, wn = wid % WGN;
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
   int m_tile, bt;
-  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, m_tile, bt);
-  const int img = bt / (tiles_x * tiles_y); bt -= img * tiles_x * tiles_y;
-  const int ty = bt / tiles_x, tx = bt - ty * tiles_x;
+  tile_order(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, p.dMt, m_tile, bt);
+  const int img = fdiv(bt, p.dA); bt -= img * tiles_x * tiles_y;             // (multiplications on the scalar unit: launch_halo fills dMt, dA, dB)
+  const int ty = fdiv(bt, p.dB), tx = bt - ty * tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   const int m0 = m_tile * BM;
   const int kc0 = blockIdx.z * p.chunks_per_split;
   const int kc1 = min(p.nchunks, kc0 + p.chunks_per_split);
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
   const int HWin = p.Hin * p.Win;
+  // the input descriptor covers ONE image: a padding offset stays out of bounds whatever chunk step is added to it, and channels past Cin (last
+  // chunk of a Cin that is no multiple of 8) are out of bounds by themselves -- one VALU addition per loaded element instead of a compare, two
+  // selects and an addition (every VALU instruction takes ~4 cycles from the matrix pipe: tools/mfma_valu_probe.hip)
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)img * p.Cin * HWin), 0, p.Cin * HWin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
 
   // B staging: element e = tid + i*NT of the [HCI][PH][PW] patch
   unsigned b_goff[PB]; int b_loff[PB];
@@ -498,26 +501,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv3x3_halo(const ConvParam
     const int ci = e / PLraw, r = (e - ci * PLraw) / PW, c = e - ci * PLraw - r * PW;
     const int yy = y0 * S - 1 + r, xx = x0 * S - 1 + c;
     const bool ok = e < NB && (unsigned)yy < (unsigned)p.Hin && (unsigned)xx < (unsigned)p.Win;
-    b_goff[i] = ok ? (unsigned)(((img * p.Cin + ci) * HWin + yy * p.Win + xx) * 4) : OOB;
+    b_goff[i] = ok ? (unsigned)((ci * HWin + yy * p.Win + xx) * 4) : OOB;
     b_loff[i] = e < NB ? ci * PL + r * PW + c : -1;
   }
 
   f32x4 ra[PA];
   float rb[PB];
+  unsigned a_voff[PA];                                       // per-lane part of the weight offsets; the chunk's row offset rides in the scalar offset
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int e = tid + i * NT, row = e / TA, col = (e - row * TA) * 4;         // TA is a compile-time constant
+    a_voff[i] = e < NA ? (unsigned)row * (unsigned)(p.Mp * 4) + (unsigned)(m0 + col) * 4u : OOB;
+  }
   auto gload = [&](int kc) {
+    const unsigned astep = (unsigned)(kc * HK) * (unsigned)(p.Mp * 4);
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int e = tid + i * NT, row = e / TA, col = (e - row * TA) * 4;       // TA is a compile-time constant
-      ra[i] = buf_ld4(rw, e < NA ? (unsigned)(kc * HK + row) * (unsigned)(p.Mp * 4) + (unsigned)(m0 + col) * 4u : OOB);
-    }
+    for (int i = 0; i < PA; ++i) ra[i] = buf_ld4s(rw, a_voff[i], astep);
     const unsigned cstep = (unsigned)(kc * HCI) * (unsigned)(HWin * 4);
-    const bool tail = (kc * HCI + HCI) > p.Cin;                     // last chunk of a Cin that is not a multiple of 8
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      unsigned o = b_goff[i] == OOB ? OOB : b_goff[i] + cstep;
-      if (tail && (kc * HCI + (tid + i * NT) / PLraw) >= p.Cin) o = OOB;
-      rb[i] = buf_ld1(rin, o);
-    }
+    for (int i = 0; i < PB; ++i) rb[i] = buf_ld1(rin, b_goff[i] + cstep);
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -692,8 +694,12 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
 }
 
 template <int BM, int WGM, int WGN>
-static void launch_halo(const ConvParams& p, int tw, hipStream_t st) {
+static void launch_halo(const ConvParams& p_, int tw, hipStream_t st) {
   const int th = 64 / tw;
+  ConvParams p = p_;
+  fill_divs(p, BM);
+  p.dA = fast_div((unsigned)(ceil_div(p.Ho, th) * ceil_div(p.Wo, tw)));
+  p.dB = fast_div((unsigned)ceil_div(p.Wo, tw));
   dim3 g(p.B * ceil_div(p.Ho, th) * ceil_div(p.Wo, tw) * ceil_div(p.M, BM), 1, p.splitk);
   if (p.stride == 2) {
     if (tw == 4) k_conv3x3_halo<BM, WGM, WGN, 4, 2><<<g, 64 * WGM * WGN, 0, st>>>(p);
