@@ -925,3 +925,9 @@ extern "C" int frtm_debug_ktrace_counts(unsigned* counts) {
   return n;
 }
 #endif
+
+// Host-side evaluation of FastDiv (conv_common.h) for tests/test_cpu_host.py: the same m, s and the same formula as fdiv() on the device.
+extern "C" unsigned frtm_fastdiv_check(unsigned n, unsigned d) {
+  const FastDiv f = fast_div(d);
+  return (unsigned)((((unsigned long long)n * f.m) >> 32) + n) >> f.s;
+}

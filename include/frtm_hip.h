@@ -350,6 +350,10 @@ void* frtm_backbone_lane_stream(frtm_backbone_t* bb, int lane);
 /* One wave that occupies `stream` for `microseconds` (0..100000): the probe with which the tracker finds out whether two streams share a
  * hardware queue (the runtime maps streams onto GPU_MAX_HW_QUEUES queues; streams of one queue run in order). */
 int frtm_spin(int microseconds, frtm_stream_t stream);
+/* Host-side check of the multiplication the conv kernels use instead of integer divisions in their index arithmetic (csrc/conv_common.h: FastDiv,
+ * q = (mulhi(n, m) + n) >> s with m, s prepared per divisor): returns n / d as that formula computes it, for 0 <= n < 2^31, d >= 1.
+ * No GPU involved; tests/test_cpu_host.py sweeps it against Python's integer division. */
+unsigned frtm_fastdiv_check(unsigned n, unsigned d);
 /* FLOPs (2*MAC over all convs) of the last forward() call. */
 double frtm_backbone_last_flops(const frtm_backbone_t* bb);
 /* The same with the launches that ran as Winograd F(2x2,3x3) counted at the multiplications they execute (16 / 36 of the direct form). */

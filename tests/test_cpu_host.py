@@ -30,6 +30,26 @@ def test_abi_exports_every_declared_symbol():
     assert L.frtm_last_error() is not None
 
 
+def test_fastdiv_matches_integer_division():
+    """The conv kernels divide by multiplying (csrc/conv_common.h: FastDiv; pixel -> image, tile order, epilogue offsets): the host-side evaluation of
+    the same m, s and formula against Python's // for every divisor up to 4096, the sizes the trunk and refiner really use, powers of two and
+    their neighbours, and numerators at the edges of the claimed range 0 <= n < 2^31."""
+    from frtm_vos_amd import _hip
+    import random
+    L = _hip.lib()
+    rnd = random.Random(7)
+    divisors = list(range(1, 4097)) + [30 * 54, 60 * 107, 120 * 214, 240 * 427, 480 * 854, 15 * 27, 45 * 80, 68 * 120, 720 * 1280, 1080 * 1920]
+    divisors += [2 ** k + d for k in range(12, 31) for d in (-1, 0, 1)] + [rnd.randrange(1, 2 ** 31) for _ in range(300)]
+    for d in divisors:
+        if not 1 <= d < 2 ** 31:
+            continue
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31 - d, (2 ** 31 - 1) // d * d, (2 ** 31 - 1) // d * d - 1]
+        ns += [rnd.randrange(0, 2 ** 31) for _ in range(12)]
+        for n in ns:
+            if 0 <= n < 2 ** 31:
+                assert L.frtm_fastdiv_check(n, d) == n // d, (n, d)
+
+
 def test_no_cpu_fallback():
     from frtm_vos_amd.model.discriminator import Discriminator
     from frtm_vos_amd.model.memory import Memory
