@@ -132,9 +132,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
   float rb[MODE != 0 ? 1 : EB];
   auto gload_to = [&](int kc, f32x4* ra, f32x4* rb4) {
     const int kb = kc * BK;
-    // (row offsets through the scalar-offset field: no VALU instruction per load; wT is zero padded to whole chunks of rows)
+    // Row offsets through the scalar-offset field: no VALU instruction per load.  Only chunks whose k rows all exist take this form; the last chunk of a K
+    // that is no multiple of the chunk depth keeps the per-lane offsets: a plain [K][w_pitch] weight matrix -- the weight-gradient GEMM -- ends at row
+    // K, and rows past it must read as zeros, not as whatever lies behind it.  (On gfx950 the bounds check of a raw buffer load turned out to include the
+    // scalar offset -- tests/test_round5_gpu.py's NaN-poisoned matrix reads zeros either way -- but the ISA guide does not promise it: not relied upon.)
+    if (kb + BK <= p.K) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = buf_ld4s(rw, a_voff, (unsigned)(kb + i * RA) * (unsigned)(p.Mp * 4));
+      for (int i = 0; i < PA; ++i) ra[i] = buf_ld4s(rw, a_voff, (unsigned)(kb + i * RA) * (unsigned)(p.Mp * 4));
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = buf_ld4(rw, (unsigned)(kb + arow + i * RA) * (unsigned)(p.Mp * 4) + a_off);
+    }
     if (MODE == 1) {
       if (kb + BK <= p.K) {                                                       // wave-uniform: every k row of the chunk exists
 #pragma unroll

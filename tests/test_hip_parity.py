@@ -150,6 +150,9 @@ CONV_CASES = [
     (1, 65, 30, 54, 65, 3, 1, 1),        # refiner-style odd channel counts, halo layout with a channel tail
     (2, 16, 15, 27, 40, 3, 1, 1),        # 16x4 pixel tiles
     (1, 8, 40, 100, 32, 3, 1, 1),
+    (1, 3, 70, 102, 64, 7, 2, 0),        # the stem on a pre-padded image (round 5): gather without bounds tests, K = 147 (tail chunk on the tested path)
+    (2, 20, 17, 23, 48, 5, 1, 0),        # pad 0, K = 500: fifteen chunks on the scalar-offset path, one with the tail
+    (1, 7, 12, 19, 32, 3, 2, 0),         # pad 0, strided, K = 63 < one full second chunk
 ]
 
 

@@ -383,3 +383,24 @@ def test_refiner_with_and_without_tap_mix():
     err = float((a - b).abs().max() / b.abs().max())
     print('refiner, tail on nine tap maps vs on 16 channels: %.2e' % err)
     assert err < 1e-5
+
+
+def test_gemm_rows_past_k_read_as_zeros_not_as_what_lies_behind_the_matrix():
+    """conv2d with a plain [K][w_pitch] weight matrix (the weight-gradient GEMM of the first-frame fit, reference model/discriminator.py:154-199 through
+    optimizer.py:155-157) and K no multiple of the chunk depth: rows past K must read as zeros.  The kernel's operand loads carry their row offsets in the
+    scalar offset of the buffer load (not promised to be bounds-checked; the last chunk takes per-lane offsets instead).  The matrix is a view into a
+    NaN-filled buffer: a read past row K would poison the result (NaN x 0 = NaN)."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for N, hw, Cin, c in ((5, 1620, 256, 96), (3, 77, 40, 32), (2, 1001, 64, 64)):
+        K = N * hw
+        big = torch.full((K * c + 64 * c,), float('nan'), device=DEV)
+        D = torch.randn(K, c, generator=g)
+        big[:K * c] = D.flatten().to(DEV)
+        Dv = big[:K * c].view(K, c)
+        X = torch.randn(N, hw, Cin, generator=g)
+        ref = torch.einsum('kc,kx->cx', D.double(), X.view(K, Cin).double()).float()
+        out = ops.conv2d(X.to(DEV), Dv, c, shape=(1, K, 1, Cin), w_pitch=c)
+        assert bool(torch.isfinite(out).all()), (N, hw)
+        err = float((out.view(c, Cin).cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 3e-5, (N, hw, err)
