@@ -71,7 +71,9 @@ constexpr int WFRAG = 16 * 64 * 4;     // floats of one (chunk, m_tile) weight b
 //  * for the same reason the B-fragment reads inside the K loop are inline asm with their own lgkmcnt waits (the compiler had put
 //    vmcnt(4) in front of the barriers: the patch of chunk k+2 had to land within chunk k);
 //  * sched_barriers pin the issue order the counts assume (the scheduler had swapped weight and patch loads in one of two chunks);
-//  * no spill inside the loop (scratch loads count in vmcnt too): check `hipcc -S` after every change to this file.
+//  * no spill inside the loop (scratch loads count in vmcnt too).
+// tests/test_isa_invariants.py compiles this file to ISA and checks these rules on every run of the CPU suite (load order and count per chunk, no
+// branch and no scratch access inside the loop, the vmcnt values in front of the barriers).
 // Epilogue: the column half of the output transform happens in registers (16 -> 8 planes), the planes are written as
 // [plane][tile][cout] with one ds_write_b128 per accumulator (pitch 36: conflict-free), both tile groups in one exchange, a thread
 // then owns CQ consecutive output channels of one tile; BN scale / shift wait in LDS since the kernel's start, residual and output
