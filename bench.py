@@ -129,6 +129,12 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+
+def init_dist(backend, world, dev=None, nccl_timeout_s=180):
+    from frtm_vos_amd.shard import init_process_groups
+    return init_process_groups(backend, world, dev, nccl_timeout_s)
+
+
 class StageTimer:
     """HIP events on torch's current stream (the stream every frtm_* kernel is enqueued on)."""
 
@@ -550,6 +556,75 @@ def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20, persistent=Tru
             'ms_per_run': ms, 'ms_per_run_eager_launch': ms_eager, 'valu_tflops': tf, 'hbm_equivalents': hbm_eq}
 
 
+def dominant_kernel_leg(dev, frames=8, hw=(30, 54), reps=40):
+    """roofline.dominant_kernel (VERDICT r5 'Next' #4): the trunk's dominant kernel -- k_conv_igemm<64,64,2,4,1>, the 1x1 GEMMs of ResNet-101's layer3
+    (reference model/feature_extractor.py:50-65) -- ALONE on the GPU, measured in this run: its two shapes at one lane's batch (8 frames, 30x54) as
+    `reps` back-to-back launches between HIP events on the stream they are launched on (BN + residual + ReLU resp. BN + ReLU fused, as in the trunk),
+    with the shader clock read by a one-wave probe on a side stream under the same load (frtm_clock_probe: s_memtime against the 100 MHz counter)."""
+    import ctypes
+    from frtm_vos_amd import _hip as H, ops
+    g = torch.Generator(device='cpu').manual_seed(11)
+    out = {'name': 'k_conv_igemm<64, 64, 2, 4, 1, 32>', 'batch': frames, 'map': '%dx%d' % hw, 'launches_timed': reps, 'shapes': {}}
+    side = torch.cuda.Stream(device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    tot_fl, tot_us = 0.0, 0.0
+    for cin, cout, with_res in ((256, 1024, True), (1024, 256, False)):
+        x = torch.randn(frames, cin, hw[0], hw[1], generator=g).to(dev)
+        wT, ktab, lay = ops.pack_weights((torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)).to(dev))
+        sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        res = torch.randn(frames, cout, hw[0], hw[1], generator=g).to(dev) if with_res else None
+        y = torch.empty(frames, cout, hw[0], hw[1], device=dev)
+
+        def run(n):
+            for _ in range(n):
+                ops.conv2d(x, wT, cout, 1, 1, 0, ktab=ktab, scale=sc, shift=sh, relu=True, out=y, w_layout=lay, residual=res, tile=4)    # FRTM_TILE_64x64_8W: the planner's choice here
+        run(8)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(reps)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        # the clock under this load: probe for ~0.6 x the sequence's length on a side stream, started behind the first launches
+        probe_us = max(200, int(0.6 * us * reps))
+        side.wait_stream(torch.cuda.current_stream())
+        run(4)
+        with torch.cuda.stream(side):
+            H.lib().frtm_clock_probe(probe_us, ctypes.c_void_p(clk.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+        run(reps)
+        torch.cuda.synchronize()
+        cyc, ticks = (int(v) for v in clk.cpu())
+        mhz = 100.0 * cyc / max(ticks, 1)
+        fl = 2.0 * cin * cout * frames * hw[0] * hw[1]
+        tf = fl / us / 1e6
+        out['shapes']['%d->%d' % (cin, cout)] = {
+            'flops_per_launch': fl, 'avg_us': round(us, 2), 'tflops': round(tf, 1), 'frac': round(tf / PEAK_F32_TFLOPS, 3),
+            'shader_clock_mhz_under_load': round(mhz, 0),
+            # the fp32 MFMA rate at the clock the shader really holds: 256 CUs x 4 SIMDs x 64 FLOP per cycle (v_mfma_f32_16x16x4_f32: 2048 FLOP in 32 cycles)
+            'frac_of_rate_at_that_clock': round(tf / (256 * 4 * 64 * mhz * 1e6 / 1e12), 3) if mhz > 0 else None,
+            'epilogue': 'BN + residual + ReLU' if with_res else 'BN + ReLU'}
+        tot_fl += fl
+        tot_us += us
+    out.update({'flops_per_launch': tot_fl / 2, 'avg_us': round(tot_us / 2, 2), 'tflops': round(tot_fl / tot_us / 1e6, 1),
+                'frac': round(tot_fl / tot_us / 1e6 / PEAK_F32_TFLOPS, 3),
+                'shader_clock_mhz_under_load': round(sum(v['shader_clock_mhz_under_load'] for v in out['shapes'].values()) / 2, 0),
+                'note': 'kernel ALONE (one lane); in the timed region two lanes overlap and fill each other\'s tails (per_launch above). frac = against the data-sheet '
+                        'peak (157.3 TFLOP/s at 2.4 GHz); frac_of_rate_at_that_clock = against 256 x 4 x 64 FLOP/cycle at the measured shader clock'})
+    # share of the trunk's kernel time: from the newest committed kernel trace of the bench command (profiles/rNN_steady_state.csv)
+    import glob as _glob
+    for sf in sorted(_glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_steady_state.csv')), reverse=True):
+        try:
+            for ln in open(sf):
+                if ln.startswith('"void k_conv_igemm<64, 64, 2, 4, 1, 32>'):
+                    out['share_of_steady_state_busy_time'] = {'percent': float(ln.rsplit(',', 1)[1]), 'source': 'profiles/' + os.path.basename(sf)}
+                    break
+            break
+        except Exception:      # noqa: BLE001
+            pass
+    return out
+
+
 def dataset_specs(n_seq, size=(480, 854), seed=2017):
     """(name, frames, objects, seed) of a DAVIS-2017-val-like synthetic dataset: 1-5 objects (mean ~2.4), 34-104 frames (SURVEY.md 8d config 3;
     the reference's dv2017val has 30 sequences).  Deterministic: every rank derives the same list."""
@@ -632,8 +707,10 @@ def launch_check(args, rank, world):
     """The N > 1 plumbing of main() without the GPU workload: every rank 'processes' --steps frames in (rank + 1) x 10 ms."""
     import torch.distributed as dist
     from frtm_vos_amd.shard import aggregate_reports, write_rank_report
+    used = None
     if world > 1:
-        dist.init_process_group(args.dist_backend)
+        _, used, _, _, _ = init_dist('gloo' if args.dist_backend != 'nccl' or not torch.cuda.is_available() else 'nccl', world,
+                                     'cuda:0' if torch.cuda.is_available() else None)
         dist.barrier()
     my_frames, mine = args.steps, None
     if args.sequences > 0:                      # sharded mode: this rank's share of the dataset (the same cut main() makes)
@@ -662,7 +739,8 @@ def launch_check(args, rank, world):
     if rank == 0:
         fps_files, frames, _ = aggregate_reports(args.report_dir, world)
         print(json.dumps({'launch_check': True, 'n_gpus': world, 'steps': args.steps, 'value': total / T, 'unit': 'frames/s',
-                          'frames_from_rank_reports': frames, 'frames_total': total, 'scaling': 'weak' if mine is None else 'strong'}))
+                          'frames_from_rank_reports': frames, 'frames_total': total, 'scaling': 'weak' if mine is None else 'strong',
+                          'dist_backend_used': used}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -698,18 +776,16 @@ def main():
         local = 0
     if args.launch_check:
         return launch_check(args, rank, world)
+    dev = 'cuda:%d' % (local if world > 1 else 0)
+    coll, dist_used, rccl_seen, red_dev, dist_err = None, None, None, 'cpu', None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(args.dist_backend)
+        # control group gloo; RCCL on top of it when it comes up on every rank, else gloo for the barrier / max-reduce as well (init_dist)
+        coll, dist_used, rccl_seen, red_dev, dist_err = init_dist(args.dist_backend, world, dev)
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = 'cuda:%d' % (local if world > 1 else 0)
-    red_dev = dev if args.dist_backend == 'nccl' else 'cpu'
     size = tuple(int(v) for v in args.size.split('x'))
 
     from frtm_vos_amd.evaluate import Parameters
@@ -839,7 +915,7 @@ def main():
         del ext.pass_exec_flops[:]
         del ext.pass_form_flops[:]
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=coll)
         torch.cuda.synchronize()
         # target-model start weights are the reference's: drawn from torch's global CPU generator (the first object of the process from this
         # seed, every later one after initialize()'s manual_seed(0), reference tracker.py:174-180; fixture G15): the CPU leg repeats them
@@ -866,18 +942,18 @@ def main():
                         for f in frames:
                             print('    %s:%d %s' % (f['filename'], f['line'], f['name']), file=sys.stderr)
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=coll)
         T_rank = T = time.time() - t0
         n = len(outputs) if shard is None else n_shard
         n_total = world * n
         mallocs = torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - dev_allocs0
         if dist is not None:
             tt = torch.tensor([T], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=coll)
             T = float(tt.item())
             if shard is not None:                       # ranks hold different numbers of frames: sum them
                 nn_ = torch.tensor([float(n)], device=red_dev, dtype=torch.float64)
-                dist.all_reduce(nn_, op=dist.ReduceOp.SUM)
+                dist.all_reduce(nn_, op=dist.ReduceOp.SUM, group=coll)
                 n_total = int(nn_.item())
         runs.append(dict(seq=seq, outputs=outputs, T=T, T_rank=T_rank, n=n, n_total=n_total, mallocs=mallocs,
                          counters=path_counters(tracker, seq, n) if shard is None else shard_counters,
@@ -947,7 +1023,7 @@ def main():
                 problems.append(('repeat %d: ' % ri) + 'filter re-solves %(cg_solves)d of %(cg_solves_scheduled)d scheduled (%(early_outs_fewer_than_10_px)d early-outs "fewer than 10 pixels")' % cn)
     ok = torch.tensor([0.0 if problems else 1.0], device=red_dev)
     if dist is not None:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=coll)
     if problems:
         print('bench.py rank %d: INVALID RUN: %s' % (rank, '; '.join(problems)), file=sys.stderr)
 
@@ -958,14 +1034,13 @@ def main():
     wino4_share = round(form[2] / max(sum(form), 1.0), 4)
     wino6_share = round(form[3] / max(sum(form), 1.0), 4)
     sq_busy = None
-    for cand in ('r04_sq_busy.json', 'r03_sq_busy.json', 'r02_sq_busy.json'):
-        sf = os.path.join(ROOT, 'profiles', cand)
-        if os.path.exists(sf):
-            try:
-                sq_busy = dict(json.load(open(sf))['conv_family'], source='profiles/' + cand)
-            except Exception:
-                sq_busy = None
+    import glob as _glob
+    for sf in sorted(_glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_sq_busy.json')), reverse=True):      # the NEWEST round's PMC pass first
+        try:
+            sq_busy = dict(json.load(open(sf))['conv_family'], source='profiles/' + os.path.basename(sf))
             break
+        except Exception:      # noqa: BLE001
+            sq_busy = None
     traffic = None
     tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # written by tools/pmc_summary.py from the rocprofv3 --pmc passes
     if os.path.exists(tf):
@@ -976,6 +1051,9 @@ def main():
     out = {
         'metric': 'segmented frames/sec/GPU (480p, ResNet101, full CG iters)',
         'value': n_total / T, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        # `warmup` echoes --warmup (the contract's W).  What really ran untimed is MORE: whole throw-away sequences of the timed length, twice (graphs
+        # are captured at the second use of a shape, and only a capture-free pass leaves the allocator warm), plus a W-frame one when W > steps
+        'warmup_frames_run': sum(max(w, 2) for w in warm_lengths),
         'ms_per_step': 1e3 * T * world / max(n_total, 1), 'higher_is_better': True, 'scaling': 'weak' if shard is None else 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('' if shard is None else '%d dv2017val-like synthetic sequences (1-5 objects, 34-104 frames) SHARDED over the ranks by frames x objects; per sequence as in: ' % args.sequences) +
@@ -988,7 +1066,6 @@ def main():
                                 'seeded default init, no confident masks' if args.random_refiner else 'seeded default init + score-following channel',
                                 args.trunk_batch, args.trunk_lanes,
                                 ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else ('Winograd F(2x2,3x3)' if args.no_winograd4 else 'Winograd F(6x6,3x3) / F(4x4,3x3) from 128 channels on, F(2x2,3x3) below')),
-                   'warmup_frames_run': sum(max(w, 2) for w in warm_lengths),
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_conv_igemm / k_conv3x3_halo / k_conv3x3_wino / k_wino4_* (fp32 MFMA convs of the whole ResNet trunk; FLOPs counted in direct form)',
                      'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS,
@@ -1001,10 +1078,10 @@ def main():
                      'winograd_share_of_algorithmic_flops': wino_share, 'winograd_f4x4_share_of_algorithmic_flops': wino4_share,
                      'winograd_f6x6_share_of_algorithmic_flops': wino6_share,
                      'mfma_pipe_busy': sq_busy,
-                     # v_mfma_f32_16x16x4_f32 (the instruction of these kernels) sustains 123-139 TFLOP/s with register operands and nothing
-                     # else in the loop, v_mfma_f32_32x32x2_f32 155 (tools/mfma_peak_probe.hip, profiles/r03_mfma_peak.txt): `peak` stays the
-                     # data-sheet number
-                     'instruction_ceiling_16x16x4': 139.8,
+                     # v_mfma_f32_16x16x4_f32 (the instruction of these kernels) alone in a loop of eight MFMAs and a wait sustains 151-153 TFLOP/s
+                     # (round 5's probe, tools/mfma_valu_probe.hip, profiles/r05_mfma_valu_probe.txt; round 3's loop form reached 139.8): there is
+                     # no issue bubble inherent to the instruction, `peak` stays the data-sheet number
+                     'instruction_ceiling_16x16x4': {'tflops': 152.0, 'source': 'profiles/r05_mfma_valu_probe.txt'},
                      'traffic': traffic,
                      # avg_ms = HIP-event time of the trunk passes / conv launches: the EFFECTIVE duration per launch.  With
                      # trunk_lanes concurrent sub-batches the kernel-trace mean duration is ~lanes x this (kernels share the GPU);
@@ -1039,6 +1116,12 @@ def main():
         'stream_placement': __import__('frtm_vos_amd.model.tracker', fromlist=['STREAM_PROBE']).STREAM_PROBE,
         'valid': bool(ok.item() > 0),
     }
+    if world > 1:
+        # the group that carried barrier + max-reduce: 'nccl' (= RCCL) or, when RCCL did not come up on every rank with one visible device each, 'gloo'
+        out['dist_backend_used'] = dist_used
+        out['rccl_ranks_seen'] = rccl_seen
+        if dist_err:
+            out['rccl_error'] = dist_err
     if shard is not None:
         out['shard_rank0'] = shard
         out['frames_total'] = n_total
@@ -1080,6 +1163,9 @@ def main():
             mk = cg_roofline(dev, size, persistent=False)
             out['roofline_cg']['multi_kernel_form_ms_per_run'] = mk['ms_per_run']
 
+        def leg_dominant():
+            out['roofline']['dominant_kernel'] = dominant_kernel_leg(dev)
+
         def leg_cpu():
             seq.preload('cpu')
             out['cpu_baseline'] = cpu_baseline(args, size, seq, aug_cpu, min(args.cpu_frames, args.steps - 1), gpu_labels=outputs)
@@ -1096,6 +1182,8 @@ def main():
             leg('streaming leg', leg_streaming)
         if not args.no_cg_roofline:
             leg('cg roofline', leg_cg)
+            if args.backbone == 'resnet101':
+                leg('dominant kernel', leg_dominant)
         if not args.no_cpu_baseline and args.late_object is None:
             leg('cpu baseline', leg_cpu)
             if not args.no_jf_fixture and args.backbone == 'resnet101' and os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'g14_jf_float32.npz')):

@@ -4,6 +4,7 @@
 // buffers stay resident in HBM (288 GB: nothing is ever freed or re-packed per frame).
 #include <vector>
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include "frtm_common.h"
@@ -213,6 +214,17 @@ __global__ void k_spin(long long ticks) {
   for (int it = 0; it < (1 << 20) && wall_clock64() - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(16);      // (bounded whatever the counter does)
 }
 
+// One wave that watches both clocks for a given time: out2 = {shader-clock cycles (s_memtime), ticks of the constant 100 MHz counter}.  Launched on a
+// side stream next to a kernel sequence it tells the clock the shader holds UNDER THAT LOAD (bench.py: roofline.dominant_kernel).
+__global__ void k_clock_probe(long long ticks, unsigned long long* out2) {
+  const long long t0 = wall_clock64();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  long long t1 = t0;
+  for (int it = 0; it < (1 << 22) && (t1 = wall_clock64()) - t0 < ticks; ++it) __builtin_amdgcn_s_sleep(32);
+  out2[0] = __builtin_readcyclecounter() - c0;
+  out2[1] = (unsigned long long)(t1 - t0);
+}
+
 static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {
   const int Hs = (H + 6 - 7) / 2 + 1, Ws = (W + 6 - 7) / 2 + 1;
   size_t need = (size_t)64 * Hs * Ws;
@@ -223,7 +235,8 @@ static size_t arena_elems_per_image(const frtm_backbone* bb, int H, int W) {
     need = std::max(need, (size_t)(64 << s) * exp * ah * aw);
     need = std::max(need, (size_t)(64 << s) * (s > 0 ? 4 : 1) * ah * aw);   // conv1 of a strided block runs at the input size
   }
-  return std::max(need, (size_t)3 * (H + 6) * (W + 6));              // (the normalised image carries the stem's border)
+  const int P = bb->convs[0].pad;
+  return std::max(need, (size_t)3 * (H + 2 * P) * (W + 2 * P));      // (the normalised image carries the stem's border: k_normalize_u8 writes (H + 2P) x (W + 2P) per plane)
 }
 
 static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_u8, int B, int H, int W, const float* norm_scale3,
@@ -433,12 +446,17 @@ int frtm_backbone_set_winograd4(frtm_backbone_t* bb, int enable) {
 // Lane streams are PROCESS-WIDE (per device and lane index) and never destroyed (round 5).  Every trunk used to create its own and destroy them with
 // itself; hipGraphs of later trunks / refiners then crashed inside hipGraphLaunch now and then (twice in ten full test runs of round 5, both in
 // tests that capture trunk graphs after earlier trunks of the process had died) -- the failure class model/seg_network.py: _shared_side_stream
-// documents for the refiner's side stream.  Trunks of one process do not run concurrently, so they can share their lane streams.
+// documents for the refiner's side stream.  The pool is created under a lock (two host threads may build trunks at once).  What is shared is the
+// STREAMS: trunks of one process that enqueue passes at the same time from different host threads interleave on them -- still correct (every pass
+// forks from and joins its caller's stream through its own events) unless one of the two is under stream capture: the tracker captures from one
+// thread only, and frtm_backbone_forward_at refuses a multi-lane pass whose caller stream captures while a lane stream is busy capturing for another.
+static std::mutex g_lane_pool_lock;
 static int lane_stream(int lane, hipStream_t* out) {
   static hipStream_t pool[16][16] = {};
   int dev = 0;
   FRTM_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16 || lane < 0 || lane >= 16) { frtm_set_error("backbone: no lane stream for device %d lane %d", dev, lane); return FRTM_ERR_ARG; }
+  std::lock_guard<std::mutex> hold(g_lane_pool_lock);
   if (!pool[dev][lane]) FRTM_HIP(hipStreamCreateWithFlags(&pool[dev][lane], hipStreamNonBlocking));
   *out = pool[dev][lane];
   return FRTM_OK;
@@ -468,6 +486,13 @@ void* frtm_backbone_lane_stream(frtm_backbone_t* bb, int lane) {
 int frtm_spin(int microseconds, frtm_stream_t stream) {
   FRTM_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "frtm_spin: 0..100000 us");
   k_spin<<<1, 64, 0, (hipStream_t)stream>>>((long long)microseconds * 100);      // wall_clock64 ticks at 100 MHz
+  FRTM_LAUNCH_CHECK();
+  return FRTM_OK;
+}
+
+int frtm_clock_probe(int microseconds, unsigned long long* out2, frtm_stream_t stream) {
+  FRTM_CHECK_ARG(out2 && microseconds >= 1 && microseconds <= 100000, "frtm_clock_probe: 1..100000 us and a device buffer of two 64-bit words");
+  k_clock_probe<<<1, 64, 0, (hipStream_t)stream>>>((long long)microseconds * 100, out2);
   FRTM_LAUNCH_CHECK();
   return FRTM_OK;
 }
@@ -518,7 +543,19 @@ int frtm_backbone_forward_at(frtm_backbone_t* bb, int lane_set, const unsigned c
     Lane& ln = bb->lanes[lbase + l];
     const int Bl = B / L + (l < B % L ? 1 : 0);
     hipStream_t ls = (l == 0) ? st : ln.stream;              // lane 0 stays on the caller's stream
-    if (l > 0) FRTM_HIP(hipStreamWaitEvent(ls, fork, 0));
+    if (l > 0) {
+      // the lane streams are shared by every trunk of the process: one that is inside ANOTHER caller's capture right now must not be joined
+      // (a lane that joined THIS capture in an earlier pass of the same graph reports the caller's capture id: fine)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, cs0 = hipStreamCaptureStatusNone;
+      unsigned long long id = 0, id0 = 0;
+      FRTM_HIP(hipStreamGetCaptureInfo(ls, &cs, &id));
+      if (cs != hipStreamCaptureStatusNone) FRTM_HIP(hipStreamGetCaptureInfo(st, &cs0, &id0));
+      if (cs != hipStreamCaptureStatusNone && (cs0 == hipStreamCaptureStatusNone || id0 != id)) {
+        frtm_set_error("frtm_backbone_forward: lane stream %d is inside another stream capture (two trunks enqueueing at once, one of them capturing)", lbase + l);
+        return FRTM_ERR_STATE;
+      }
+      FRTM_HIP(hipStreamWaitEvent(ls, fork, 0));
+    }
     for (int c0 = 0; c0 < Bl; c0 += max_imgs) {              // one call per lane unless the batch is too large for it
       const int Bc = std::min(max_imgs, Bl - c0);
       float* tl[5];

@@ -690,7 +690,7 @@ void frtm_conv_plan(int M, int Ntot, int nchunks, int vec1x1, int* tile, int* sp
                    : ((M % 64 != 0 && M < 64) ? FRTM_TILE_32x64 : FRTM_TILE_64x64);
   const int nb = (*tile == FRTM_TILE_128x64) ? blocks(128, 64) : (*tile == FRTM_TILE_80x64) ? blocks(80, 64) : (*tile == FRTM_TILE_64x128_8W) ? blocks(64, 128)
                : (*tile == FRTM_TILE_128x128_8W || *tile == FRTM_TILE_128x128_16W) ? blocks(128, 128)
-               : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W || *tile == FRTM_TILE_64x64_K64) ? blocks(64, 64) : blocks(32, 64);
+               : (*tile == FRTM_TILE_64x64 || *tile == FRTM_TILE_64x64_8W) ? blocks(64, 64) : blocks(32, 64);
   if (*splitk <= 0) {
     int s = 1;
     const int target = vec1x1 ? 512 : 832;
@@ -873,7 +873,6 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
   }
   splitk = max(1, min(splitk, p.nchunks));
   p.chunks_per_split = ceil_div(p.nchunks, splitk);
-  if (!halo && (tile == FRTM_TILE_32x64_K64 || tile == FRTM_TILE_64x64_K64)) p.chunks_per_split = (p.chunks_per_split + 1) / 2 * 2;
   p.splitk = ceil_div(p.nchunks, p.chunks_per_split);
   FRTM_CHECK_ARG(p.splitk == 1 || workspace, "frtm_conv2d: split-K needs a workspace");
   hipStream_t st = (hipStream_t)stream;
@@ -898,8 +897,6 @@ int frtm_conv2d(const frtm_conv_desc* d, const float* in, const float* wT, const
     case FRTM_TILE_64x64: launch_tile<64, 64, 2, 2>(p, vec1x1, st); break;
     case FRTM_TILE_32x64: launch_tile<32, 64, 1, 4>(p, vec1x1, st); break;
     case FRTM_TILE_64x64_8W: launch_tile<64, 64, 2, 4>(p, vec1x1, st); break;
-    case FRTM_TILE_32x64_K64: launch_tile<32, 64, 1, 4, 64>(p, vec1x1, st); break;
-    case FRTM_TILE_64x64_K64: launch_tile<64, 64, 2, 2, 64>(p, vec1x1, st); break;
     case FRTM_TILE_64x128_8W: launch_tile<64, 128, 2, 4>(p, vec1x1, st); break;
     case FRTM_TILE_128x128_8W: launch_tile<128, 128, 2, 4>(p, vec1x1, st); break;
     case FRTM_TILE_128x128_16W: launch_tile<128, 128, 4, 4>(p, vec1x1, st); break;

@@ -21,8 +21,9 @@ class AttrDict(dict):
 class Parameters:
 
     def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2,
-                 ytvos_fork_solver=False):
+                 ytvos_fork_solver=False, refiner_graphs=None):
         self.device = device
+        self.refiner_graphs = refiner_graphs      # None: the Tracker's default; False: every refiner window launched kernel by kernel (no hipGraph replay)
         self.refiner_factory = None       # optional: callable(ft_channels) -> SegNetwork used instead of a default-initialised one
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes
@@ -80,8 +81,9 @@ class Parameters:
             refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
         else:
             refiner = SegNetwork(self.disc_params.out_channels, p.nchannels, chans, p.use_batch_norm)
+        extra = {} if self.refiner_graphs is None else dict(refiner_graphs=bool(self.refiner_graphs))
         mdl = Tracker(augmenter, extractor, self.disc_params, refiner, self.device, feature_batch=self.feature_batch,
-                      trunk_lanes=self.trunk_lanes)
+                      trunk_lanes=self.trunk_lanes, **extra)
         if self.weights is not None:
             mdl.load_state_dict(self.weights)
         mdl.to(self.device)
@@ -116,19 +118,21 @@ def main(argv=None):
     ap.add_argument('--share-gpu', action='store_true', help='tests only: every rank uses cuda:0')
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
     ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
+    ap.add_argument('--no-refiner-graphs', action='store_true', help='launch every refiner window kernel by kernel instead of replaying hipGraphs (Tracker(refiner_graphs=False))')
     ap.add_argument('--keep-gc', action='store_true', help="leave Python's cyclic collector alone (default: held off while a sequence is enqueued)")
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    coll, red_dev = None, 'cpu'
     if world > 1:
-        import torch.distributed as dist
+        from .shard import init_process_groups
         local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', 0))
         torch.cuda.set_device(local)
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(args.dist_backend)
         args.dev = 'cuda:%d' % local
+        # control group gloo; RCCL on top when it comes up on every rank, else the closing reduction runs over gloo too (shard.py)
+        coll, used, _, red_dev, _ = init_process_groups(args.dist_backend, world, args.dev)
+        if rank == 0:
+            print('process group: %d ranks, closing reduction over %s' % (world, used))
     weights = torch.load(args.model, map_location='cpu')['model']
     if args.dset.startswith('dv'):
         dset = DAVISDataset(args.davis, args.dset[2:6], 'val')
@@ -142,7 +146,8 @@ def main(argv=None):
     host_cpus = [] if (args.no_cpu_pin or args.share_gpu) else pin_host_threads_near_gpu(torch.device(args.dev).index or 0)
     if rank == 0:
         print('host threads: %s' % (('CPUs %d-%d (%d logical) near the GPU' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned'))
-    tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver).get_model()
+    tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver,
+                         refiner_graphs=False if args.no_refiner_graphs else None).get_model()
     if not args.keep_gc:
         # driver-level decisions (process-global, so not the library's): long-lived objects into the permanent generation once, and no
         # cyclic collection while a sequence's launches are being enqueued
@@ -176,8 +181,7 @@ def main(argv=None):
     wall = time.time() - t0
     write_rank_report(out_path, rank, world, dict(frames=_Shard.frames, seconds=wall, fps=_Shard.frames / max(wall, 1e-9),
                                                   dataset=dset.name, device=args.dev))
-    red_dev = args.dev if (world > 1 and args.dist_backend == 'nccl') else 'cpu'
-    fps, total, wall = aggregate_throughput(_Shard.frames, wall, device=red_dev)       # (a collective: also the closing barrier)
+    fps, total, wall = aggregate_throughput(_Shard.frames, wall, device=red_dev, group=coll)       # (a collective: also the closing barrier)
     if rank == 0:
         print('%d frames on %d GPU(s): %.1f frames/s incl. decoding and PNG writing' % (total, world, fps))
         if not args.no_eval and args.dset.startswith('dv'):

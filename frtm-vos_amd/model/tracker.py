@@ -138,7 +138,7 @@ class TargetObject:
 
 class Tracker(nn.Module):
 
-    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=16, trunk_lanes=2):
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=16, trunk_lanes=2, refiner_graphs=True):
         super().__init__()
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
@@ -166,7 +166,9 @@ class Tracker(nn.Module):
         self._early_pass_event = None
         self._init_pool = []
         self._disc_pool = []
-        self.graph_refiner = True
+        # refiner windows replayed as hipGraphs (one host call instead of ~80 launches per window: 2.17 -> 1.92 ms per pass).  A supported
+        # constructor argument (round 6): refiner_graphs=False launches every window kernel by kernel -- same kernels, same results bit for bit
+        self.graph_refiner = bool(refiner_graphs)
         # No cyclic garbage collection while a sequence is being enqueued (_run_sequence).  A process-global side effect, so OPT-IN: the
         # drivers (bench.py, evaluate.py) switch it on; an embedding application keeps its collector unless it sets this or FRTM_HOLD_GC=1.
         self.hold_gc = bool(os.environ.get('FRTM_HOLD_GC')) and not os.environ.get('FRTM_NO_HOLD_GC')

@@ -47,17 +47,50 @@ def aggregate_reports(out_dir, world_size):
     return frames / seconds, frames, seconds
 
 
-def aggregate_throughput(frames, seconds, device='cpu'):
+def aggregate_throughput(frames, seconds, device='cpu', group=None):
     """Whole-job frames/s = sum of frames over ranks / max wall time over ranks.  Works without an
-    initialised process group (single process)."""
+    initialised process group (single process).  ``group``: the group init_process_groups chose (None = the default group)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return frames / seconds, frames, seconds
     f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    dist.all_reduce(f, op=dist.ReduceOp.SUM)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(f.item() / t.item()), float(f.item()), float(t.item())
+
+
+def init_process_groups(backend, world, dev=None, nccl_timeout_s=180):
+    """Process group of an N > 1 run (the data path has no collective; the group only carries the closing barrier and the
+    max-reduce of the wall time).  The CONTROL group is always gloo (CPU tensors: it cannot fail on the GPU side).  With backend 'nccl' an RCCL
+    group is tried on top of it -- every rank sees ONE device (HIP_VISIBLE_DEVICES), a configuration RCCL has never met on this code -- and
+    the ranks agree over gloo whether it works (a one-element all-reduce must count every rank): if any rank failed, ALL of them fall back to
+    gloo for the barrier / reduce instead of losing the whole run at start-up.  Returns (group or None, backend used, ranks RCCL counted,
+    device of the reduction tensors, error text or None)."""
+    import datetime
+    import sys
+    import torch.distributed as dist
+    dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=60))
+    if backend != 'nccl':
+        return None, backend, None, 'cpu', None
+    ok, seen, err, grp = 1.0, 0, None, None
+    try:
+        grp = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=nccl_timeout_s))
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t, group=grp)
+        torch.cuda.synchronize()
+        seen = int(round(float(t.item())))
+        if seen != world:
+            ok, err = 0.0, 'RCCL all-reduce counted %d of %d ranks' % (seen, world)
+    except Exception as ex:      # noqa: BLE001  (whatever RCCL / the runtime raises under the one-device-per-rank isolation)
+        ok, err = 0.0, '%s: %s' % (type(ex).__name__, str(ex)[:300])
+    flag = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)                    # over gloo: every rank takes the same decision
+    if float(flag.item()) > 0:
+        return grp, 'nccl', seen, dev, None
+    if err:
+        print('frtm shard rank %s: RCCL group unusable (%s): barrier / max-reduce over gloo' % (os.environ.get('RANK', '?'), err), file=sys.stderr, flush=True)
+    return None, 'gloo', seen, 'cpu', err or 'another rank failed to bring RCCL up'
 
 
 def _parse_cpulist(text):

@@ -300,8 +300,7 @@ typedef struct {
 #define FRTM_TILE_32x64 2
 #define FRTM_TILE_128x64 3
 #define FRTM_TILE_64x64_8W 4     /* 64x64 tile, 8 waves (two per SIMD) */
-#define FRTM_TILE_32x64_K64 5    /* 64-deep chunks (half the barriers) */
-#define FRTM_TILE_64x64_K64 6
+/* 5, 6: the 64-deep-chunk tiles of rounds 1-5 (an operand array in scratch memory, in no profile): removed in round 6 */
 #define FRTM_TILE_64x128_8W 7
 #define FRTM_TILE_128x128_8W 8   /* large-N regime: 32 FLOP per staged byte instead of 10.7 (32x64) */
 #define FRTM_TILE_128x128_16W 9
@@ -350,6 +349,9 @@ void* frtm_backbone_lane_stream(frtm_backbone_t* bb, int lane);
 /* One wave that occupies `stream` for `microseconds` (0..100000): the probe with which the tracker finds out whether two streams share a
  * hardware queue (the runtime maps streams onto GPU_MAX_HW_QUEUES queues; streams of one queue run in order). */
 int frtm_spin(int microseconds, frtm_stream_t stream);
+/* One wave that reads both clocks for `microseconds` (1..100000): out2 (device, two 64-bit words) = {shader-clock cycles (s_memtime), ticks of the
+ * constant 100 MHz counter}.  On a side stream next to a kernel sequence: the clock the shader holds under that load (bench.py: roofline.dominant_kernel). */
+int frtm_clock_probe(int microseconds, unsigned long long* out2, frtm_stream_t stream);
 /* Host-side check of the multiplication the conv kernels use instead of integer divisions in their index arithmetic (csrc/conv_common.h: FastDiv,
  * q = (mulhi(n, m) + n) >> s with m, s prepared per divisor): returns n / d as that formula computes it, for 0 <= n < 2^31, d >= 1.
  * No GPU involved; tests/test_cpu_host.py sweeps it against Python's integer division. */

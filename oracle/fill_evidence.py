@@ -35,7 +35,10 @@ def main():
     ap.add_argument('--threads', type=int, default=3)
     ap.add_argument('--frames', type=int, default=40)
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden', 'g17_fill_evidence.npz'))
+    ap.add_argument('--subset', default='r5', help="'r5' = round 5's 8 sequences (15 objects); 'all' = every sequence of G14 (77 objects, round 6)")
+    ap.add_argument('--summary-only', action='store_true', help='no tracking: print the summary of what the fixture already holds')
     args = ap.parse_args()
+    subset = SUBSET if args.subset == 'r5' else tuple(range(32))
     from frtm_vos_amd.evaluate import Parameters
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     torch.set_num_threads(args.threads)
@@ -44,16 +47,16 @@ def main():
     P0 = O.resnet_random_params(JF.BACKBONE, seed=0)
     refiner = JF.refiner_for()
     res = dict(np.load(args.out)) if os.path.exists(args.out) else {}
-    res['subset'] = np.array(SUBSET)
     res['frames'] = np.array(args.frames)
-    for tag, fill, ulps in (('pull_push', 'pull_push', 0), ('telea', 'telea', 0), ('pull_push_p1', 'pull_push', 1)):
-        P = dict(P0)
-        P['conv1.weight'] = P0['conv1.weight'] * (1.0 + ulps * 2.0 ** -23)
+    variants = (('pull_push', 'pull_push', 0), ('telea', 'telea', 0), ('pull_push_p1', 'pull_push', 1))
+    for k in (() if args.summary_only else subset):                  # sequence-major: a run that is cut off leaves complete triples
+        for tag, fill, ulps in variants:
+            P = dict(P0)
+            P['conv1.weight'] = P0['conv1.weight'] * (1.0 + ulps * 2.0 ** -23)
 
-        def augment(image, mask, fill=fill):
-            np.random.seed(0)                                           # reference model/tracker.py:180, before every object's augmentation
-            return augment_first_frame_ref(image, mask, aug_params, fill=fill)
-        for k in SUBSET:
+            def augment(image, mask, fill=fill):
+                np.random.seed(0)                                       # reference model/tracker.py:180, before every object's augmentation
+                return augment_first_frame_ref(image, mask, aug_params, fill=fill)
             key = '%s_jf_%d' % (tag, k)
             if key in res:
                 continue
@@ -64,8 +67,10 @@ def main():
             lab = torch.stack(trk.run_sequence(seq)).numpy()
             res[key] = np.array(JF.jf_per_object(lab, seq))
             print('%-13s %s: J&F per object %s  (%.0f s)' % (tag, name, np.round(100 * res[key].mean(1), 2), time.time() - t0), flush=True)
+            res['subset'] = np.array(sorted(set(int(x) for x in res.get('subset', ())) | {k}))
             np.savez_compressed(args.out, **res)
-    v = {t: np.concatenate([res['%s_jf_%d' % (t, k)] for k in SUBSET]).mean(1) * 100 for t in ('pull_push', 'telea', 'pull_push_p1')}
+    done = [k for k in range(32) if all('%s_jf_%d' % (t, k) in res for t, _, _ in variants)]
+    v = {t: np.concatenate([res['%s_jf_%d' % (t, k)] for k in done]).mean(1) * 100 for t in ('pull_push', 'telea', 'pull_push_p1')}
     d_fill, d_noise = v['telea'] - v['pull_push'], v['pull_push_p1'] - v['pull_push']
     print('objects %d;  J&F  pull-push %.3f   Telea %.3f   pull-push (+1 ulp) %.3f' % (len(d_fill), v['pull_push'].mean(), v['telea'].mean(), v['pull_push_p1'].mean()))
     print('Telea - pull-push:           dataset %+.3f   per object mean |d| %.3f  max |d| %.2f' % (d_fill.mean(), np.abs(d_fill).mean(), np.abs(d_fill).max()))
@@ -75,3 +80,4 @@ def main():
 
 if __name__ == '__main__':
     main()
+

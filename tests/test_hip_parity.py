@@ -230,7 +230,7 @@ def test_conv_as_weight_gradient(ops):
 
 # ------------------------------------------------------------------------------------------ backbone
 @pytest.mark.parametrize('name,size,B', [('resnet18', (96, 128), 2), ('resnet101', (64, 96), 1), ('resnet18', (480, 854), 1),
-                                         ('resnet50', (75, 101), 1)])
+                                         ('resnet50', (75, 101), 1), ('resnet34', (96, 160), 2)])
 def test_backbone_vs_oracle(name, size, B):
     from frtm_vos_amd.model.feature_extractor import ResnetFeatureExtractor
     P = O.resnet_random_params(name, seed=3)

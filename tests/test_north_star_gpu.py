@@ -165,6 +165,7 @@ def _teacher_forced(size, n_frames, n_obj, seed, disc):
                 print('   re-solve, object %d: rms |HIP - fp64| %.2e, |fp32 oracle - fp64| %.2e, |HIP - fp32 oracle| %.2e (rms of the filter %.2e)'
                       % (oid, e_h, e_o, rms(hd.filter.weight, od.w2), rms(a.w2, 0 * a.w2)))
                 worst['arb'] = max(worst['arb'], e_h / max(e_o, 1e-12))
+                worst.setdefault('arb_each', []).append(round(e_h / max(e_o, 1e-12), 3))
                 pool_h.append(e_h)
                 pool_o.append(e_o)
             assert hd.memory.previous_replace_ind == od.memory.prev_ind, (t, oid)
@@ -199,11 +200,13 @@ def test_teacher_forced_step_at_720p_wide_maps():
     The arbiter is POOLED over the run's two re-solves here (round 5): on these maps ten CG iterations leave the float32 ORACLE 10-20 % of the
     filter's rms away from float64 (2.1e-3 and 4.7e-3 on 2.2e-2), and the ratio of two such noise magnitudes for ONE object is itself noise --
     measured with the strip-form weight gradient (as accurate per application as the form it replaced, 1.2e-7 against 1.1e-7 relative to
-    float64): object 1 3.8e-3 against 2.1e-3, object 2 4.73e-3 against 4.73e-3.  Per object the ratio stays below 2."""
+    float64): object 1 3.8e-3 against 2.1e-3 (ratio 1.81), object 2 4.73e-3 against 4.73e-3 (1.00).  ADVICE r5: the per-re-solve bound stays 1.5 for
+    all but ONE of the run's re-solves; that one outlier stays below 2, and the pooled ratio below 1.5."""
     disc = dict(JF.DISC, train_skipping=2, memory_size=16)
     worst = _teacher_forced((720, 1280), 4, 2, 301, disc)
     assert worst['raw'] <= 1e-3 and worst['merged'] <= 1e-3, worst
     assert worst['filt'] == 0.0 and worst['arb_pooled'] <= 1.5 and worst['arb'] <= 2.0 and worst['sw'] <= 1e-6, worst
+    assert sum(1 for v in worst['arb_each'] if v > 1.5) <= 1, worst['arb_each']
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,130 @@
+"""Round-6 GPU tests (VERDICT r5 'Next round' #2, #5).
+
+  * BASELINE config 2 ASSEMBLED at full size against the oracle: ResNet-18, fast schedule (5,10,10,10)/(5,), 480 x 854, ONE object, through
+    Tracker.run_sequence and the single-object threshold decoding of reference model/tracker.py:143-150.
+  * Tracker(refiner_graphs=False): a supported constructor argument; the same kernels launched one by one, results bit for bit.
+  * NaN-poisoned guard tests of the operand loads that carry a wave-uniform offset in the load's scalar-offset field (pad-0 gather, MODE-1 GEMM
+    and the halo kernel with a column count that is no tile multiple): idle lanes must read zeros, never what lies behind the tensor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+from oracle import make_golden_jf as JF
+from oracle.tracker_ref import TrackerRef
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _tracker(backbone, refiner, fast=False, **disc):
+    from test_north_star_gpu import _hip_tracker
+    return _hip_tracker(backbone, refiner, fast=fast, **disc)
+
+
+def _labels(trk, seq, size):
+    labels, _ = trk.run_sequence(seq)
+    return torch.stack([l.reshape(size) for l in labels]).cpu().numpy()
+
+
+def test_config2_resnet18_fast_single_object_480p_against_the_oracle():
+    """BASELINE.json configs[1] (and configs[0]'s CPU-runnable case): ResNet-18 --fast on a single-object 480p sequence.  26 frames = frame 0
+    (initialize) + 25 tracked frames: filter re-solves at (5,) on tracked frames 8, 16 and 24.  HIP path = Tracker.run_sequence (trunk batches,
+    windows, resident solvers, Winograd), oracle = oracle/tracker_ref.py frame by frame; both decode ONE object by the 0.5 threshold on channel 1
+    (reference model/tracker.py:143-150), not by the soft-max merge.  Gates: label agreement > 0.995 over the tracked frames; |J&F difference| no
+    larger than twice what the float32 oracle differs from ITSELF at half the thread count (floor 0.5 points: one object, 24 scored frames)."""
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    size, n_frames, seed = (480, 854), 26, 616
+    threads = min(16, os.cpu_count() or 8)
+    refiner = JF.refiner_for('resnet18')
+    sw = lambda oid: JF.start_weights(seed, oid, cin=256)
+    disc = dict(JF.DISC, init_iters=(5, 10, 10, 10), update_iters=(5,))           # evaluate.py:46-51, fast
+    P = O.resnet_random_params('resnet18', seed=0)
+    seq = SyntheticSequence('cfg2', n_frames, size, 1, seed=seed)
+    assert len(seq.obj_ids) == 1
+    ora = {}
+    for tag, nt in (('full', threads), ('half', max(1, threads // 2))):
+        torch.set_num_threads(nt)
+        cpu = TrackerRef('resnet18', P, refiner, sw, **disc)
+        lab = torch.stack(cpu.run_sequence(seq)).numpy()
+        ora[tag] = (lab, 100 * np.array(JF.jf_per_object(lab, seq)).mean())
+    torch.set_num_threads(threads)
+    trk = _tracker('resnet18', refiner, fast=True)
+    assert tuple(trk.disc_params['init_iters']) == (5, 10, 10, 10) and tuple(trk.disc_params['update_iters']) == (5,)
+    trk.start_weights = sw
+    lab_h = _labels(trk, seq, size)
+    disc_h = trk.targets[seq.obj_ids[0]].discriminator if getattr(trk, 'targets', None) else None
+    jf_h = 100 * np.array(JF.jf_per_object(lab_h, seq)).mean()
+    agree = float((lab_h[1:] == ora['full'][0][1:]).mean())
+    agree_self = float((ora['half'][0][1:] == ora['full'][0][1:]).mean())
+    d_hip, d_self = abs(jf_h - ora['full'][1]), abs(ora['half'][1] - ora['full'][1])
+    print('config 2 (RN18 fast, 480x854, 1 object, %d frames): J&F HIP %.3f  oracle %.3f (%d threads) / %.3f (%d threads);  label agreement HIP-oracle %.5f, '
+          'oracle-oracle %.5f' % (n_frames, jf_h, ora['full'][1], threads, ora['half'][1], max(1, threads // 2), agree, agree_self))
+    assert set(np.unique(lab_h)) <= {0, seq.obj_ids[0]}                              # threshold decoding: background or THE object
+    assert agree > 0.995, agree
+    assert d_hip <= max(2.0 * d_self, 0.5), (d_hip, d_self)
+    if disc_h is not None:
+        assert disc_h.frame_num >= 24
+
+
+def test_refiner_graphs_constructor_argument():
+    """Tracker(..., refiner_graphs=False) (VERDICT r5 'Next' #2): a supported switch, not an environment variable.  The same sequence twice through
+    a tracker with graph replay (the second run replays what the first captured) and through one without: identical label maps, and the graph-free
+    tracker holds no captured graph."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from oracle.tracker_ref import shift_flip_augment
+    import copy
+    torch.set_grad_enabled(False)
+    size, seed = (192, 256), 909
+    refiner = JF.refiner_for('resnet18')
+    sw = lambda oid: JF.start_weights(seed, oid, cin=256)
+    seq = SyntheticSequence('rg', 28, size, 2, seed=seed)
+    seq.preload(DEV)
+    out = {}
+    for graphs in (True, False):
+        params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', refiner_graphs=graphs)
+        params.refiner_factory = lambda chans: copy.deepcopy(refiner)
+        trk = params.get_model().eval()
+        trk.augment = shift_flip_augment
+        trk.start_weights = sw
+        assert trk.graph_refiner is graphs
+        runs = [_labels(trk, seq, size) for _ in range(3)]
+        assert all(np.array_equal(runs[0], r) for r in runs[1:])
+        out[graphs] = (runs[-1], len(trk.refiner._graphs))
+    assert out[False][1] == 0 and out[True][1] > 0, (out[False][1], out[True][1])
+    assert np.array_equal(out[True][0], out[False][0])
+
+
+@pytest.mark.parametrize('kind', ['gather_pad0', 'gemm_mode1', 'halo'])
+def test_idle_lanes_read_zeros_with_scalar_offset_loads(kind):
+    """ADVICE r5 #5.  The conv kernels give idle lanes (columns past Ntot, rows past the tile) the out-of-bounds sentinel 0x80000000 as PER-LANE offset
+    and add a wave-uniform row / tap offset through the load's scalar-offset field.  The activations are a view into a NaN-filled buffer and the
+    column count is no multiple of the 64-column tile: a sentinel that wrapped back into the buffer (or past its end into the neighbour) would poison
+    the output (NaN x 0 = NaN) or change it.  Compared with torch's convolution on the clean tensors."""
+    from frtm_vos_amd import ops
+    g = torch.Generator().manual_seed(17)
+    if kind == 'gather_pad0':       # strided 1x1 (the down-sampling shortcut) and a 3x3 / pad 0 conv: gather mode without padding
+        cases = [(2, 64, 33, 47, 128, 1, 2, 0), (1, 24, 19, 23, 40, 3, 1, 0), (3, 32, 21, 30, 64, 3, 2, 0)]
+    elif kind == 'gemm_mode1':      # stride-1 1x1, H*W % 4 == 0, Ntot no multiple of 64
+        cases = [(1, 256, 10, 18, 1024, 1, 1, 0), (3, 96, 6, 14, 64, 1, 1, 0)]
+    else:                           # halo kernel: 3x3 / pad 1, stride 1 and 2, maps that no 64-pixel tile divides
+        cases = [(2, 40, 13, 21, 64, 3, 1, 1), (1, 72, 27, 31, 96, 3, 2, 1)]
+    for B, cin, h, w, cout, ks, stride, pad in cases:
+        n = B * cin * h * w
+        big = torch.full((n + 2 * 4096,), float('nan'), device=DEV)
+        x = torch.randn(B, cin, h, w, generator=g)
+        big[4096:4096 + n] = x.flatten().to(DEV)
+        xv = big[4096:4096 + n].view(B, cin, h, w)
+        wt = torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), stride=stride, padding=pad).float()
+        for halo in ((True, False) if kind == 'halo' else (False,)):              # (False: the plain [K][M] layout, gather / GEMM forms)
+            wT, ktab, lay = ops.pack_weights(wt.to(DEV), halo=halo)
+            out = ops.conv2d(xv, wT, cout, ks, stride, pad, ktab=ktab, w_layout=lay)
+            assert bool(torch.isfinite(out).all()), (kind, B, cin, h, w, cout, ks, stride, halo)
+            err = float((out.cpu() - ref).abs().max() / ref.abs().max())
+            assert err < 3e-5, (kind, B, cin, h, w, cout, ks, stride, halo, err)

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frtm_vos_amd import ops
 from conv_bench import timeit
-NAMES = {1: '64x64', 2: '32x64', 3: '128x64', 4: '64x64_8W', 5: '32x64_K64', 6: '64x64_K64', 7: '64x128_8W', 8: '128x128_8W', 9: '128x128_16W'}
+NAMES = {1: '64x64', 2: '32x64', 3: '128x64', 4: '64x64_8W', 7: '64x128_8W', 8: '128x128_8W', 9: '128x128_16W'}
 for (b, cin, cout, h, w) in [(4, 256, 1024, 30, 54), (4, 1024, 256, 30, 54), (4, 64, 256, 120, 214), (4, 512, 2048, 15, 27), (2, 256, 64, 120, 214), (8, 256, 1024, 30, 54), (8, 1024, 256, 30, 54)]:
     x = torch.randn(b, cin, h, w, device='cuda'); wt = torch.randn(cout, cin, 1, 1, device='cuda') * 0.05
     wT, ktab, lay = ops.pack_weights(wt); out = torch.empty(b, cout, h, w, device='cuda')
