@@ -80,7 +80,8 @@ def parse(argv=None):
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
     ap.add_argument('--no-window-inserts', action='store_true', help='memory inserts frame by frame (3 launches per frame and object) instead of one batched update per window')
-    ap.add_argument('--no-refiner-graph', action='store_true', help='refiner windows launched kernel by kernel instead of replayed as hipGraphs')
+    ap.add_argument('--refiner-graph', action='store_true', help='refiner windows replayed as hipGraphs (Tracker(refiner_graphs=True); opt-in since round 6: the default launches them kernel by kernel with the deep levels on a side stream -- same speed, profiles/r06_refiner_window_ab.txt)')
+    ap.add_argument('--no-refiner-graph', action='store_true', help='(the default since round 6; kept so that older command lines still parse)')
     ap.add_argument('--trunk-graph', action='store_true', help='trunk passes replayed as hipGraphs instead of launched kernel by kernel (no gain measured)')
     ap.add_argument('--no-fold-tail', action='store_true', help='a last trunk batch of 1-3 frames stays a pass of its own instead of joining the one before it')
     ap.add_argument('--balance', action='store_true', help='trunk batches of similar size instead of full ones and a short tail pass (measured slower at 20 frames)')
@@ -821,7 +822,7 @@ def main():
         tracker.fold_tail = 0
     tracker.first_batch = args.first_batch or None
     tracker.graph_trunk = args.trunk_graph
-    tracker.graph_refiner = not args.no_refiner_graph
+    tracker.graph_refiner = bool(args.refiner_graph) and not args.no_refiner_graph
     if args.no_window_inserts:
         from frtm_vos_amd.model.discriminator import Discriminator as _D
         _D.window_inserts = False

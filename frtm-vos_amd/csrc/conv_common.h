@@ -31,6 +31,7 @@ struct ConvParams {
   int epi_pre = 1;          // k_conv_igemm: scale / shift / residual of the epilogue requested before the K loop (0: FRTM_NO_EPIPRE=1, A/B)
   FastDiv dNpix, dWo, dMt;  // divisions by Npix, Wo and the launch's number of M tiles (set by the launch helpers: fill_divs)
   FastDiv dA, dB;           // k_conv3x3_wino: output blocks per image / per block row
+  int ntiles = 0;           // k_conv_igemm_p: tiles of the launch (a workgroup walks tiles blockIdx.x, + gridDim.x, ...)
 };
 
 #ifdef __HIPCC__

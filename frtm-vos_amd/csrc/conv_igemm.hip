@@ -459,6 +459,163 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_conv_igemm(const ConvParams 
 }
 
 // ------------------------------------------------------------------------------------------
+// PERSISTENT form of k_conv_igemm<64, 64, 2, 4, 1> (round 6; VERDICT r5 "Next" #1a).  The stride-1 1x1 GEMMs of the bottleneck blocks are 40 % of the
+// trunk's busy time, and a K = 256 workgroup spent a third of its life outside its K loop: born, 80 VALU instructions of address set-up, a dozen loads
+// issued next to seven older waves in their K loops (2.7 us: the arbiter prefers the older waves), a barrier, 8 chunks, the epilogue, dead.  Here a
+// workgroup is born ONCE per launch and walks tiles t = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0: a workgroup's tiles stay in its XCD's
+// range of tile_order); the first operand chunk of tile n + 1 is requested at the top of tile n's LAST chunk and stored to LDS at its end -- exactly
+// what every other chunk does for its successor -- so a tile's K loop starts the moment the epilogue of the tile before it has drained:
+//   * two LDS stages laid out stage-major [A0 B0 | A1 B1]; a tile's chunks alternate 1, 0, 1, 0, ... (chunk counts are even): the last chunk reads
+//     stage 0, the next tile's first chunk waits in stage 1, and the epilogue's 64 x 68 output tile fits into stage 0 (17.4 of 20 KB);
+//   * the epilogue's operands (output offsets, BN scale / shift, residual) are requested behind the epilogue of the tile before;
+//   * stores and residual reads are buffer operations on per-tensor descriptors (columns past Ntot: offset out of bounds, no branch).
+// Same arithmetic in the same order per output element as k_conv_igemm<64,64,2,4,1>: results are bit-identical (tests/test_round6_gpu.py).
+// Conditions (launch_tile checks them, else the plain kernel runs): M % 64 == 0, K % 64 == 0 (even number of full chunks), NCHW output without
+// split-K, Npix % 4 == 0, 16-byte aligned in / out / residual.
+__global__ __launch_bounds__(512) void k_conv_igemm_p(const ConvParams p) {
+  constexpr int BK = 32, LDA = 80, LDB = 80, LDC = 68, TM = 32, TN = 16, FM = 2;
+  constexpr int STG = BK * (LDA + LDB);                 // floats per stage (A then B)
+  __shared__ __attribute__((aligned(16))) float smem[2 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 2, wn = wid & 3, lk = lane >> 4, li = lane & 15;
+  const int acol = (tid & 15) * 4, arow = tid >> 4;     // operand staging: one dwordx4 of A and one of B per thread and chunk (row arow, columns acol..+3)
+  const int HWin = p.Hin * p.Win, Mt = p.M >> 6, ntiles = p.ntiles, nch = p.nchunks, G = gridDim.x;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const int out_bytes = (int)((size_t)p.B * p.M * p.Npix * 4);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? p.scale : p.out), 0, p.M * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.shift ? p.shift : p.out), 0, p.M * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wT, 0, (int)p.w_bytes, 0x00020000);
+  const unsigned keep_res = p.residual ? 0u : OOB, keep_sc = p.scale ? 0u : OOB;
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned st_lds = lds0 + (unsigned)(arow * LDA + acol) * 4u;                        // A store address in stage 0; B: + BK * LDA * 4; stage 1: + STG * 4
+  const unsigned a_lds = lds0 + (unsigned)(lk * LDA + wm * TM + li) * 4u;                    // fragment reads (stage 0)
+  const unsigned b_lds = lds0 + (unsigned)(BK * LDA + lk * LDB + wn * TN + li) * 4u;
+  const unsigned c_wr = lds0 + (unsigned)((wm * TM + lk * 4) * LDC + wn * TN + li) * 4u;     // accumulator (i, r) -> + (i * 16 + r) * LDC * 4
+  const unsigned c_rd = lds0 + (unsigned)((tid >> 4) * LDC + acol) * 4u;                     // output piece e -> + e * 32 * LDC * 4
+  auto lds_rd1 = [](unsigned base, auto off) { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off)); return v; };
+
+  unsigned a_voff, b_voff, e_off0 = OOB, e_next = OOB;
+  // operand offsets of tile tt (and the offset of this thread's first output piece: same column as its B staging column)
+  auto setup_ab = [&](int tt) {
+    int m_tile, n_tile;
+    tile_order(tt, ntiles, Mt, p.dMt, m_tile, n_tile);
+    const int m0 = m_tile * 64, n0 = n_tile * 64;
+    if (p.w_img_stride) rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wT + (size_t)fdiv(n0, p.dNpix) * p.w_img_stride), 0, (int)p.w_bytes, 0x00020000);
+    a_voff = (unsigned)arow * (unsigned)(p.Mp * 4) + (unsigned)(m0 + acol) * 4u;
+    const int n = n0 + acol;
+    b_voff = OOB; e_next = OOB;
+    if (n < p.Ntot) {
+      const int img = fdiv(n, p.dNpix), rem = n - img * p.Npix;
+      b_voff = (unsigned)(img * p.Cin * HWin + rem) * 4u + (unsigned)arow * (unsigned)(HWin * 4);
+      e_next = (unsigned)(((img * p.M + m0 + (tid >> 4)) * p.Npix + rem) * 4);
+    }
+    return m0;
+  };
+  f32x4 ra, rb;
+  auto gload = [&](int kc) {
+    ra = buf_ld4s(rw, a_voff, (unsigned)(kc * BK) * (unsigned)(p.Mp * 4));
+    rb = buf_ld4s(rin, b_voff, (unsigned)(kc * BK) * (unsigned)(HWin * 4));
+  };
+  f32x4 e_res[2];
+  float e_sc[2], e_sh[2];
+  auto epi_request = [&](int m0) {                       // scale / shift / residual of the tile whose first output offset is e_off0
+    const unsigned so = (e_off0 == OOB ? OOB : (unsigned)(m0 + (tid >> 4)) * 4u) | keep_sc;
+    e_sc[0] = buf_ld1(rsc, so); e_sh[0] = buf_ld1(rsh, so);
+    e_sc[1] = buf_ld1(rsc, so + 128u); e_sh[1] = buf_ld1(rsh, so + 128u);       // (OOB + 128 stays out of bounds)
+    e_res[0] = buf_ld4(rres, e_off0 | keep_res);
+    e_res[1] = buf_ld4(rres, (e_off0 + (unsigned)(32 * p.Npix * 4)) | keep_res | (e_off0 & OOB));
+  };
+  f32x4 acc[FM];
+  auto chunk = [&](auto CUR_, bool more, int kc_next) {
+    constexpr int CUR = decltype(CUR_)::value;
+    if (more) gload(kc_next);
+    float af[2][FM], bf[2];
+    constexpr int SO = CUR * STG * 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = lds_rd1(a_lds, SO + i * 64);
+    bf[0] = lds_rd1(b_lds, SO);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      if (kk + 1 < BK / 4) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[(kk + 1) & 1][i] = lds_rd1(a_lds, SO + ((kk + 1) * 4 * LDA + i * 16) * 4);
+        bf[(kk + 1) & 1] = lds_rd1(b_lds, SO + ((kk + 1) * 4 * LDB) * 4);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(FM + 1));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)");
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[kk & 1][i]));
+      asm volatile("" : "+v"(bf[kk & 1]));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {                                           // the successor's operands into the other stage
+      constexpr int DO = (CUR ^ 1) * STG * 4;
+      asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(st_lds), "v"(ra), "n"(DO) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(st_lds), "v"(rb), "n"(DO + BK * LDA * 4) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  int t = blockIdx.x;
+  int m0 = setup_ab(t);
+  e_off0 = e_next;
+  epi_request(m0);
+  gload(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(st_lds), "v"(ra), "n"(STG * 4) : "memory");
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(st_lds), "v"(rb), "n"(STG * 4 + BK * LDA * 4) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kc = 0;
+    for (; kc + 2 < nch; kc += 2) {
+      chunk(S1{}, true, kc + 1);
+      chunk(S0{}, true, kc + 2);
+    }
+    chunk(S1{}, true, kc + 1);
+    const int tn = t + G;
+    const bool has_next = tn < ntiles;                    // uniform
+    int m0n = 0;
+    if (has_next) m0n = setup_ab(tn);
+    chunk(S0{}, has_next, 0);
+    // ---- epilogue of tile t: accumulators -> LDS tile (stage 0) -> rows of four columns with scale / shift / residual / ReLU -> global
+    // (the LDS writes are inline asm: the compiler's hazard recogniser does not see that they read MFMA results -- an 8-pass MFMA needs ~11 wait states
+    //  before its destination may be read as LDS store data; the last MFMA is at least a barrier away, the s_nop makes it certain: 16 cycles per tile)
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(c_wr), "v"(acc[i][r]), "n"((i * 16 + r) * LDC * 4) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      f32x4 v;
+      asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(c_rd), "n"(e * 32 * LDC * 4) : "memory");
+      if (p.scale) v = v * e_sc[e] + e_sh[e];
+      if (p.residual) v += e_res[e];
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      const unsigned o = (e_off0 + (unsigned)(e * 32 * p.Npix * 4)) | (e_off0 & OOB);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)o, 0, 0);
+    }
+    if (!has_next) break;
+    __syncthreads();                                      // the output tile has been read: chunk 0 of the next tile may store chunk 1 into stage 0
+    t = tn; m0 = m0n; e_off0 = e_next;
+    epi_request(m0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with a halo tile in LDS ("im2col-free" in LDS as well).
 // The pixel tile is TH x TW = 64 output pixels of one image; per chunk of 8 input channels the raw
 // (TH+2) x (TW+2) input patch is staged ONCE (zero border through buffer-load bounds checks) and the nine
@@ -666,11 +823,44 @@ static void launch_tile_u(const ConvParams& p_, hipStream_t st) {
   k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
+static long g_persistent_launches = 0;      // launches that took k_conv_igemm_p (frtm_conv_persistent_launches: tests assert that the form they mean to test ran)
+
+// Workgroups of a persistent launch: what fits the chip at once (occupancy query, once per process), a multiple of 8 (XCDs).
+static int persistent_grid() {
+  static int G = -1;
+  if (G < 0) {
+    int dev = 0, cus = 256, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_conv_igemm_p, 512, 0) != hipSuccess || per <= 0) { (void)hipGetLastError(); per = 3; }
+    const char* e = getenv("FRTM_PERSIST_WG_PER_CU");               // A/B
+    if (e && atoi(e) > 0) per = atoi(e);
+    G = (cus * per) / 8 * 8;
+  }
+  return G;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BKT = 32>
 static void launch_tile(const ConvParams& p_, bool vec1x1, hipStream_t st) {
   ConvParams p = p_;
   fill_divs(p, BM);
   dim3 g(ceil_div(p.Ntot, BN) * ceil_div(p.M, BM), 1, p.splitk);
+  if constexpr (BM == 64 && BN == 64 && WGM == 2 && WGN == 4 && BKT == 32) {
+    // persistent form (k_conv_igemm_p) from two tiles per workgroup slot on; FRTM_NO_PERSIST_GEMM=1: the plain kernel (A/B; results are bit-identical)
+    static const bool off = getenv("FRTM_NO_PERSIST_GEMM") && atoi(getenv("FRTM_NO_PERSIST_GEMM"));
+    static const int min_rounds_x2 = getenv("FRTM_PERSIST_MIN_ROUNDS_X2") ? atoi(getenv("FRTM_PERSIST_MIN_ROUNDS_X2")) : 3;     // tiles >= 1.5 x slots
+    const size_t out_bytes = (size_t)p.B * p.M * p.Npix * 4;
+    if (!off && vec1x1 && p.splitk <= 1 && !p.out_transposed && p.M % 64 == 0 && p.K % 64 == 0 && p.Npix % 4 == 0 && ((size_t)p.out) % 16 == 0 &&
+        (!p.residual || ((size_t)p.residual) % 16 == 0) && ((size_t)p.wT) % 16 == 0 && p.Mp % 4 == 0 && out_bytes < 0x7fffffffull) {
+      const int G = persistent_grid();
+      if ((long)g.x * 2 >= (long)G * min_rounds_x2) {
+        p.ntiles = (int)g.x;
+        k_conv_igemm_p<<<G, 512, 0, st>>>(p);
+        g_persistent_launches += 1;
+        return;
+      }
+    }
+  }
   if (vec1x1) k_conv_igemm<BM, BN, WGM, WGN, 1, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
   else k_conv_igemm<BM, BN, WGM, WGN, 0, BKT><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
@@ -930,6 +1120,8 @@ extern "C" int frtm_debug_ktrace_counts(unsigned* counts) {
   return n;
 }
 #endif
+
+extern "C" long frtm_conv_persistent_launches(void) { return g_persistent_launches; }
 
 // Host-side evaluation of FastDiv (conv_common.h) for tests/test_cpu_host.py: the same m, s and the same formula as fdiv() on the device.
 extern "C" unsigned frtm_fastdiv_check(unsigned n, unsigned d) {

@@ -23,7 +23,7 @@ class Parameters:
     def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2,
                  ytvos_fork_solver=False, refiner_graphs=None):
         self.device = device
-        self.refiner_graphs = refiner_graphs      # None: the Tracker's default; False: every refiner window launched kernel by kernel (no hipGraph replay)
+        self.refiner_graphs = refiner_graphs      # None: the Tracker's default (no replay since round 6); True: refiner windows replayed as hipGraphs
         self.refiner_factory = None       # optional: callable(ft_channels) -> SegNetwork used instead of a default-initialised one
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes
@@ -118,7 +118,7 @@ def main(argv=None):
     ap.add_argument('--share-gpu', action='store_true', help='tests only: every rank uses cuda:0')
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
     ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
-    ap.add_argument('--no-refiner-graphs', action='store_true', help='launch every refiner window kernel by kernel instead of replaying hipGraphs (Tracker(refiner_graphs=False))')
+    ap.add_argument('--refiner-graphs', action='store_true', help='replay refiner windows as hipGraphs (Tracker(refiner_graphs=True); default: kernel by kernel, deep levels on a side stream)')
     ap.add_argument('--keep-gc', action='store_true', help="leave Python's cyclic collector alone (default: held off while a sequence is enqueued)")
     args = ap.parse_args(argv)
 
@@ -147,7 +147,7 @@ def main(argv=None):
     if rank == 0:
         print('host threads: %s' % (('CPUs %d-%d (%d logical) near the GPU' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned'))
     tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver,
-                         refiner_graphs=False if args.no_refiner_graphs else None).get_model()
+                         refiner_graphs=True if args.refiner_graphs else None).get_model()
     if not args.keep_gc:
         # driver-level decisions (process-global, so not the library's): long-lived objects into the permanent generation once, and no
         # cyclic collection while a sequence's launches are being enqueued

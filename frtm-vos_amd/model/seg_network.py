@@ -151,6 +151,7 @@ class SegNetwork(nn.Module):
             self.RRB2[L] = RRB(out_channels, use_bn=use_bn)
         self.project = BackwardCompatibleUpsampler(out_channels)
         self.use_graphs = False       # set by the tracker when the backbone taps live at stable addresses
+        self.parallel_eager = True    # without graphs: deep levels on the shared side stream (fork / join through events), else one stream
         self._graphs = {}
         self._pack_key = None
         self.use_winograd = True      # 3x3 convs as Winograd F(2x2,3x3) when the launch is large enough (frtm_conv2d, layout 2)
@@ -193,7 +194,10 @@ class SegNetwork(nn.Module):
                                    '(the PyTorch definition of the same network)')
             if self.use_graphs:
                 return self._forward_graphed(scores, features, image_size)
-            return self._forward_hip(scores, features, image_size)
+            # launched kernel by kernel: the deep pyramid levels still run on the shared side stream next to the 120x214 level (round 6:
+            # what a graph replay gains over serial launches is this overlap, not the launch count -- the host enqueues ahead of the GPU)
+            par = self.parallel_levels and self.parallel_eager and not torch.cuda.is_current_stream_capturing()
+            return self._forward_hip(scores, features, image_size, self._side_streams() if par else None)
         return self.forward_torch(scores, features, image_size, shared)
 
     def forward_torch(self, scores, features, image_size, shared=None):

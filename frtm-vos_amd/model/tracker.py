@@ -138,7 +138,7 @@ class TargetObject:
 
 class Tracker(nn.Module):
 
-    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=16, trunk_lanes=2, refiner_graphs=True):
+    def __init__(self, augmenter, feature_extractor, disc_params, refiner, device, feature_batch=16, trunk_lanes=2, refiner_graphs=False):
         super().__init__()
         self.feature_batch = feature_batch
         self.trunk_lanes = trunk_lanes   # concurrent sub-batches of a trunk pass (frtm_backbone_set_lanes)
@@ -166,8 +166,14 @@ class Tracker(nn.Module):
         self._early_pass_event = None
         self._init_pool = []
         self._disc_pool = []
-        # refiner windows replayed as hipGraphs (one host call instead of ~80 launches per window: 2.17 -> 1.92 ms per pass).  A supported
-        # constructor argument (round 6): refiner_graphs=False launches every window kernel by kernel -- same kernels, same results bit for bit
+        # Refiner windows replayed as hipGraphs: OPT-IN since round 6 (constructor argument refiner_graphs=True).  What a replay gained over
+        # launching the ~80 kernels of a window one by one was the overlap of the deep pyramid levels with the 120x214 level, not the launch
+        # count (the host enqueues ahead of the GPU) -- and the eager path now forks them onto the shared side stream itself
+        # (SegNetwork.parallel_eager; profiles/r06_refiner_window_ab.txt: 8 frames x 2 objects 3.03 ms serial, 2.87 eager-parallel, 2.89 replayed).
+        # Twice in round 5 a test process died inside hipGraphLaunch replaying such a graph; tools/graph_repro.hip (pure HIP: capture across
+        # pooled / destroyed streams and events, replay of graphs whose streams are gone, destruction in flight; 2000-3000 iterations per mode)
+        # does not reproduce it (profiles/r06_graph_repro.txt), so the cause is NOT named and the default path does not replay graphs.
+        # Same kernels either way: results are bit-identical (tests/test_round6_gpu.py).
         self.graph_refiner = bool(refiner_graphs)
         # No cyclic garbage collection while a sequence is being enqueued (_run_sequence).  A process-global side effect, so OPT-IN: the
         # drivers (bench.py, evaluate.py) switch it on; an embedding application keeps its collector unless it sets this or FRTM_HOLD_GC=1.
@@ -324,6 +330,7 @@ class Tracker(nn.Module):
             return self._run_sequence(sequence, speedrun, ytvos_merge)
         if self._main_stream is None:
             self._main_stream = _independent_stream(self.device, 'main', self._trunk_lane_streams)
+        self._place_refiner_side_stream()
         self._main_stream.wait_stream(cur)
         with torch.cuda.stream(self._main_stream):
             out = self._run_sequence(sequence, speedrun, ytvos_merge)
@@ -332,6 +339,14 @@ class Tracker(nn.Module):
             if torch.is_tensor(o) and o.is_cuda:             # now the caller's: tell the allocator who reads them
                 o.record_stream(cur)
         return out
+
+    def _place_refiner_side_stream(self):
+        """The refiner's shared side stream (deep pyramid levels next to the 120x214 level, model/seg_network.py: _shared_side_stream) on a
+        hardware queue other than the tracker's main stream's: streams of one queue run in order, the fork would buy nothing."""
+        from . import seg_network as SN
+        idx = torch.device(self.device).index
+        if idx not in SN._SIDE and hasattr(self.refiner, 'parallel_eager'):
+            SN._SIDE[idx] = _independent_stream(self.device, 'refiner_side', lambda: [self._main_stream])
 
     def _run_sequence(self, sequence, speedrun=False, ytvos_merge=False):
         """_run_sequence_loop with the interpreter's cyclic garbage collector held off (``hold_gc``): the host enqueues a sequence's

@@ -352,6 +352,10 @@ int frtm_spin(int microseconds, frtm_stream_t stream);
 /* One wave that reads both clocks for `microseconds` (1..100000): out2 (device, two 64-bit words) = {shader-clock cycles (s_memtime), ticks of the
  * constant 100 MHz counter}.  On a side stream next to a kernel sequence: the clock the shader holds under that load (bench.py: roofline.dominant_kernel). */
 int frtm_clock_probe(int microseconds, unsigned long long* out2, frtm_stream_t stream);
+/* Launches of frtm_conv2d (this process) that took the PERSISTENT form of the 64x64 / 8-wave GEMM kernel (csrc/conv_igemm.hip: k_conv_igemm_p, round 6):
+ * stride-1 1x1 convs with Cout % 64 == 0, Cin % 64 == 0, H*W % 4 == 0 and at least 1.5 tiles per resident workgroup.  FRTM_NO_PERSIST_GEMM=1 switches
+ * the form off (A/B; results are bit-identical either way). */
+long frtm_conv_persistent_launches(void);
 /* Host-side check of the multiplication the conv kernels use instead of integer divisions in their index arithmetic (csrc/conv_common.h: FastDiv,
  * q = (mulhi(n, m) + n) >> s with m, s prepared per divisor): returns n / d as that formula computes it, for 0 <= n < 2^31, d >= 1.
  * No GPU involved; tests/test_cpu_host.py sweeps it against Python's integer division. */

@@ -346,8 +346,10 @@ def test_prewarm_leaves_nothing_to_capture():
     params = Parameters(None, fast=True, device=DEV, feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
     params.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
     trk = params.get_model().eval()
+    trk.graph_refiner = True                     # (opt-in since round 6: Tracker(refiner_graphs=True))
     trk.prewarm((96, 128), object_counts=(2,))
     graphs = len(trk.refiner._graphs)
+    assert graphs > 0
     trunk_graphs = sum(1 for e in trk.feature_extractor._out_cache.values() if e.get('graph') is not None)
     for L in (14, 23):
         seq = SyntheticSequence('p', L, (96, 128), 2, seed=L)

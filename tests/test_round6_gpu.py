@@ -128,3 +128,66 @@ def test_idle_lanes_read_zeros_with_scalar_offset_loads(kind):
             assert bool(torch.isfinite(out).all()), (kind, B, cin, h, w, cout, ks, stride, halo)
             err = float((out.cpu() - ref).abs().max() / ref.abs().max())
             assert err < 3e-5, (kind, B, cin, h, w, cout, ks, stride, halo, err)
+
+
+@pytest.mark.parametrize('B,cin,cout,h,w,res', [(8, 256, 1024, 30, 54, True), (4, 64, 256, 60, 108, False), (8, 1024, 256, 46, 70, True), (5, 128, 512, 44, 62, True)])
+def test_persistent_gemm_is_bit_identical_to_the_plain_kernel(B, cin, cout, h, w, res):
+    """k_conv_igemm_p (round 6): a workgroup walks several 64 x 64 tiles of a stride-1 1x1 conv, the next tile's first operands requested under the last
+    chunk of the tile before.  Same multiplications in the same order per output: bit-identical to the plain kernels (64 x 64 / 4-wave tile, whose results the
+    round-4 tests tie to every other tile), with and without BN + residual + ReLU, on column counts that are no tile multiple; the launch counter says that
+    the persistent form is what ran (reference: the bottleneck 1x1 convs of torchvision's ResNet, model/feature_extractor.py:50-65)."""
+    from frtm_vos_amd import _hip as H, ops
+    g = torch.Generator().manual_seed(B * 1000 + cin)
+    x = torch.randn(B, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin ** 0.5)).to(DEV)
+    wT, ktab, lay = ops.pack_weights(wt)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+    r = torch.randn(B, cout, h, w, generator=g).to(DEV) if res else None
+    n0 = H.lib().frtm_conv_persistent_launches()
+    outs = {}
+    for tile in (4, 1):
+        for bn in (True, False):
+            outs[(tile, bn)] = ops.conv2d(x, wT, cout, 1, 1, 0, ktab=ktab, scale=sc if bn else None, shift=sh if bn else None, residual=r if bn else None,
+                                          relu=bn, w_layout=lay, tile=tile, splitk=1)
+    torch.cuda.synchronize()
+    tiles = ((B * h * w + 63) // 64) * (cout // 64)
+    assert H.lib().frtm_conv_persistent_launches() - n0 == 2, (tiles, H.lib().frtm_conv_persistent_launches() - n0)
+    for bn in (True, False):
+        assert torch.equal(outs[(4, bn)], outs[(1, bn)]), (bn, float((outs[(4, bn)] - outs[(1, bn)]).abs().max()))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double()).float()
+    assert float((outs[(4, False)] - ref).abs().max() / ref.abs().max()) < 3e-5
+    # twelve launches in a row agree bit for bit (an operand consumed before it landed, or an LDS stage overwritten early, would show as a run that differs)
+    for _ in range(12):
+        again = ops.conv2d(x, wT, cout, 1, 1, 0, ktab=ktab, scale=sc, shift=sh, residual=r, relu=True, w_layout=lay, tile=4, splitk=1)
+        assert torch.equal(again, outs[(4, True)])
+
+
+def test_refiner_eager_parallel_levels_equal_the_serial_launches():
+    """SegNetwork.parallel_eager (round 6): without graphs the deep pyramid levels run on the shared side stream next to the 120x214 level (fork / join
+    through events, intermediates kept until the pass ends).  Same kernels on the same inputs: bit-identical to the one-stream launches, over repeated
+    passes with allocator churn in between (a block handed to the other stream too early would show as a pass that differs).  Reference
+    model/seg_network.py:149-189."""
+    from collections import OrderedDict
+    from frtm_vos_amd.model.seg_network import SegNetwork
+    torch.set_grad_enabled(False)
+    torch.manual_seed(3)
+    chans = OrderedDict(layer5=96, layer4=64, layer3=48, layer2=32)
+    net = SegNetwork(1, 16, chans, True).eval().to(DEV)
+    size = (200, 264)
+    dims = [((size[0] + 2 ** k - 1) // 2 ** k, (size[1] + 2 ** k - 1) // 2 ** k) for k in (5, 4, 3, 2)]
+    main = torch.cuda.Stream()
+    for it in range(12):
+        Fn, n = 1 + it % 4, 1 + it % 3
+        feats = {L: torch.relu(torch.randn(Fn, c, *d, device=DEV)) for (L, c), d in zip(chans.items(), dims)}
+        scores = torch.randn(Fn * n, 1, *dims[1], device=DEV)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(main):
+            net.parallel_eager = False
+            a = net(scores, feats, size).clone()
+            junk = [torch.randn(1 << (10 + (it + k) % 10), device=DEV) for k in range(4)]
+            net.parallel_eager = True
+            b = net(scores, feats, size).clone()
+            del junk
+            c = net(scores, feats, size).clone()
+        main.synchronize()
+        assert torch.equal(a, b) and torch.equal(a, c), (it, float((a - b).abs().max()))

@@ -13,6 +13,9 @@
 //   mode 1  lane streams from a pool that is never destroyed (round 5's mitigation), events still destroyed with the trunk
 //   mode 2  pool + events never destroyed (nothing that took part in a capture is ever destroyed)
 //   mode 3  like 0, and older graph execs (captured across streams that are gone) KEEP being replayed for a few generations
+//   mode 4  pool streams; the tracker's graphs are destroyed WHILE THEIR LAST REPLAYS ARE STILL IN FLIGHT (no synchronise before hipGraphExecDestroy: what
+//           Python does when a CUDAGraph object loses its last reference -- an LRU eviction, a cache clear, a dead tracker -- right after a replay)
+//   mode 5  like 4 with per-trunk streams / events destroyed in flight as well
 // A SIGSEGV handler reports the iteration and the phase; exit code 139 then.
 #include <hip/hip_runtime.h>
 #include <csignal>
@@ -49,7 +52,7 @@ static std::vector<hipEvent_t> g_event_cemetery;      // mode 2: events are park
 
 static Trunk* make_trunk(int mode) {
   Trunk* t = new Trunk();
-  t->owns_streams = (mode == 0 || mode == 3);
+  t->owns_streams = (mode == 0 || mode == 3 || mode == 5);
   for (int l = 0; l < 2; ++l) {
     if (t->owns_streams) CK(hipStreamCreateWithFlags(&t->lane[l], hipStreamNonBlocking));
     else { if (!g_pool[l]) CK(hipStreamCreateWithFlags(&g_pool[l], hipStreamNonBlocking)); t->lane[l] = g_pool[l]; }
@@ -59,6 +62,7 @@ static Trunk* make_trunk(int mode) {
   return t;
 }
 static void kill_trunk(Trunk* t, int mode) {
+  // (hipStreamDestroy of a busy stream is legal: the runtime defers it)
   for (int l = 0; l < 2; ++l) {
     if (mode == 2) g_event_cemetery.push_back(t->done[l]); else CK(hipEventDestroy(t->done[l]));
     if (t->owns_streams) CK(hipStreamDestroy(t->lane[l]));
@@ -141,7 +145,7 @@ int main(int argc, char** argv) {
       if (mode == 3) for (Graph& G : old_refiner_graphs) { g_phase = "replay OLD refiner graph"; CK(hipGraphLaunch(G.x, M)); }
       if (mode == 3) for (Graph& G : old_trunk_graphs) { g_phase = "replay OLD trunk graph (its lane streams are gone)"; CK(hipGraphLaunch(G.x, M)); }
     }
-    g_phase = "sync"; CK(hipStreamSynchronize(M));
+    if (mode < 4 || (it % 16) == 15) { g_phase = "sync"; CK(hipStreamSynchronize(M)); }
     // ---- the tracker dies; which of its parts goes first depends on the garbage collector: alternate ----
     if (mode == 3) {
       old_trunk_graphs.push_back(T); old_refiner_graphs.push_back(Ra);
