@@ -76,6 +76,19 @@ def main():
     print('Telea - pull-push:           dataset %+.3f   per object mean |d| %.3f  max |d| %.2f' % (d_fill.mean(), np.abs(d_fill).mean(), np.abs(d_fill).max()))
     print('pull-push: +1 ulp - default: dataset %+.3f   per object mean |d| %.3f  max |d| %.2f   (the noise floor of this subset)' %
           (d_noise.mean(), np.abs(d_noise).mean(), np.abs(d_noise).max()))
+    # per-object distribution (round 6, VERDICT r5 'Next' #9): quantiles of the two difference sets, and every object whose fill difference leaves
+    # three standard deviations of the noise set (sigma of ONE object's run-to-run difference, estimated robustly from the noise set's median |d|)
+    q = (5, 25, 50, 75, 95)
+    print('quantiles %s of d = Telea - pull-push:      %s' % (q, np.round(np.percentile(d_fill, q), 3)))
+    print('quantiles %s of d = +1 ulp - default:       %s' % (q, np.round(np.percentile(d_noise, q), 3)))
+    sig = 1.4826 * np.median(np.abs(d_noise - np.median(d_noise)))
+    names = [(k, o) for k in done for o in range(len(res['pull_push_jf_%d' % k]))]
+    out_f = [(names[i], round(float(d_fill[i]), 2)) for i in np.argsort(-np.abs(d_fill)) if abs(d_fill[i]) > 3 * sig]
+    out_n = [(names[i], round(float(d_noise[i]), 2)) for i in np.argsort(-np.abs(d_noise)) if abs(d_noise[i]) > 3 * sig]
+    print('robust sigma of one object\'s difference (noise set): %.3f points;  objects beyond 3 sigma: fill set %d of %d %s;  noise set %d of %d %s'
+          % (sig, len(out_f), len(d_fill), out_f[:8], len(out_n), len(d_noise), out_n[:8]))
+    se = np.std(d_noise, ddof=1) / np.sqrt(len(d_noise))
+    print('dataset-level: fill difference %+.3f against a standard error of %.3f for %d objects at this per-object noise' % (d_fill.mean(), se, len(d_fill)))
 
 
 if __name__ == '__main__':

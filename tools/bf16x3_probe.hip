@@ -67,10 +67,11 @@ template <> struct Pairs<6> { static constexpr int a[6] = {2, 0, 1, 1, 0, 0}, b[
 template <> struct Pairs<9> { static constexpr int a[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, b[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
 
 // 128 x 128 tile, 4 waves of 64 x 64 (2 x 2 fragments of 32 x 32), chunks of K = 32 (4 blocks of 8), one LDS stage + register prefetch.
-// (v2: three workgroups per CU -- 168 registers, 48 KB of LDS each; v1 had two: profiles/r06_bf16x3_probe_v1.txt)
+// (two workgroups per CU: 176 registers, 48 KB of LDS each.  Forcing three -- amdgpu_waves_per_eu(3,3): 168 registers, 2 spilled -- measured SLOWER:
+//  59.4 instead of 56.1 us, profiles/r06_bf16x3_probe.txt.)
 constexpr int BM = 128, BN = 128, KB = 4;
 template <int NP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gemm_bf16x3(const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Xp, float* __restrict__ C,
+__global__ __launch_bounds__(256) void k_gemm_bf16x3(const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Xp, float* __restrict__ C,
                                                      int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) u32x4 As[3 * KB * BM], Bs[3 * KB * BN];      // [piece][kb][row] x 16 bytes: 24 KB each
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
