@@ -80,6 +80,7 @@ def parse(argv=None):
     ap.add_argument('--no-init-sweep', action='store_true', help='skip the initialize() timing for 1/2/5 objects')
     ap.add_argument('--cpu-frames', type=int, default=12, help='tracked frames of the CPU baseline sample (bounded to ~30 s)')
     ap.add_argument('--no-window-inserts', action='store_true', help='memory inserts frame by frame (3 launches per frame and object) instead of one batched update per window')
+    ap.add_argument('--pull-push-fill', action='store_true', help="first-frame hole fill by the device-side pull-push pyramid (ImageAugmenter(fill='pull_push'), rounds 2-5) instead of Telea's method on the host (the reference's recipe restated; default since round 6)")
     ap.add_argument('--refiner-graph', action='store_true', help='refiner windows replayed as hipGraphs (Tracker(refiner_graphs=True); opt-in since round 6: the default launches them kernel by kernel with the deep levels on a side stream -- same speed, profiles/r06_refiner_window_ab.txt)')
     ap.add_argument('--no-refiner-graph', action='store_true', help='(the default since round 6; kept so that older command lines still parse)')
     ap.add_argument('--trunk-graph', action='store_true', help='trunk passes replayed as hipGraphs instead of launched kernel by kernel (no gain measured)')
@@ -671,8 +672,10 @@ def init_sweep(tracker, size, dev, counts=(1, 2, 5), reps=3):
     objects starting on frame 0, HIP events, best of `reps` after one untimed call."""
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     out = {}
-    # (on a stream of its own, like Tracker.run_sequence: the default stream is the legacy null stream)
-    own = torch.cuda.Stream(device=dev)
+    # (on the tracker's own stream, like Tracker.run_sequence: the default stream is the legacy null stream, and ANOTHER fresh stream may share a
+    #  hardware queue with a trunk lane -- the lanes then run one after the other: +1 ms per initialize(), seen in round 6 when one more stream
+    #  of the process moved this leg's stream onto a lane's queue)
+    own = getattr(tracker, '_main_stream', None) or torch.cuda.Stream(device=dev)
     own.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(own):
         _init_sweep(tracker, size, dev, counts, reps, out)
@@ -804,7 +807,7 @@ def main():
         host_cpus = pin_host_threads_near_gpu(torch.device(dev).index)
 
     params = Parameters(None, fast=args.fast, device=dev, feature_extractor=args.backbone, feature_batch=args.trunk_batch,
-                        trunk_lanes=args.trunk_lanes)
+                        trunk_lanes=args.trunk_lanes, aug_fill='pull_push' if args.pull_push_fill else 'telea')
     params.disc_params['memory_size'] = args.memory
     params.refiner_factory = lambda chans: synthetic_refiner(args, chans)
     tracker = params.get_model()
@@ -1060,11 +1063,12 @@ def main():
         'config': {'workload': ('' if shard is None else '%d dv2017val-like synthetic sequences (1-5 objects, 34-104 frames) SHARDED over the ranks by frames x objects; per sequence as in: ' % args.sequences) +
                                'dv2017val-like synthetic sequence per GPU: %s, %dx%d, %d objects, %d frames incl. initialize(), '
                                '%s iterations, memory %d, c=96, synthetic weights (trunk: seeded random, residual-branch BN x0.25; refiner: %s), '
-                               'trunk fed %d frames per pass in %d concurrent lanes, '
+                               'first-frame hole fill %s, trunk fed %d frames per pass in %d concurrent lanes, '
                                'frames between two filter re-solves tracked as one window%s, 3x3 stride-1 convs %s (fp32)' %
                                (args.backbone, size[0], size[1], args.objects, args.steps,
                                 'fast (5,10,10,10)/(5,)' if args.fast else 'full (5,10,10,10,10)/(10,)', args.memory,
                                 'seeded default init, no confident masks' if args.random_refiner else 'seeded default init + score-following channel',
+                                'pull-push on the device' if args.pull_push_fill else "Telea on the host (the reference's recipe restated)",
                                 args.trunk_batch, args.trunk_lanes,
                                 ' (off)' if args.no_windows else '', 'direct' if args.no_winograd else ('Winograd F(2x2,3x3)' if args.no_winograd4 else 'Winograd F(6x6,3x3) / F(4x4,3x3) from 128 channels on, F(2x2,3x3) below')),
                    'parallelism': 'one process per GPU, sequences sharded, no collectives on the data path'},
@@ -1143,7 +1147,18 @@ def main():
             _phase('%s done' % name)
 
         def leg_init_sweep():
-            out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev, counts=tuple(int(v) for v in args.init_sweep_counts.split(',')))
+            counts = tuple(int(v) for v in args.init_sweep_counts.split(','))
+            out['initialize_ms_by_objects'] = init_sweep(tracker, size, dev, counts=counts)
+            # the same with the OTHER first-frame hole fill: Telea's method is a host step of ~3 ms per object that a caller of initialize() waits
+            # for (run_sequence hides it under the first tracking pass); the pull-push pyramid runs on the device
+            aug = tracker.augmenter
+            fill0 = aug.fill
+            aug.fill = 'pull_push' if fill0 == 'telea' else 'telea'
+            try:
+                out['initialize_ms_by_objects_%s_fill' % aug.fill] = init_sweep(tracker, size, dev, counts=counts)
+            finally:
+                aug.fill = fill0
+            out['first_frame_hole_fill'] = fill0
 
         def leg_dataset():
             # the headline above is ONE sequence; this is the dataset-level figure the reference's run_dataset prints (mean of the per-

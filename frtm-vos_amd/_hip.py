@@ -80,6 +80,7 @@ SIGNATURES = {
     'frtm_spin': (I, [I, P]),
     'frtm_clock_probe': (I, [I, P, P]),
     'frtm_conv_persistent_launches': (ctypes.c_long, []),
+    'frtm_telea_inpaint_u8': (I, [P, P, I, I, I, I, P]),
     'frtm_fastdiv_check': (ctypes.c_uint, [ctypes.c_uint, ctypes.c_uint]),
     'frtm_backbone_set_lanes': (I, [P, I]),
     'frtm_backbone_generation': (I, [P]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfrtm_hip.so')
-SOURCES = ['target_model.hip', 'cg_persistent.hip', 'joint_persistent.hip', 'joint_fit.hip', 'wide_maps.hip', 'conv_igemm.hip', 'conv_gemm32.hip', 'conv_wino.hip', 'conv_wino4.hip', 'backbone.hip', 'image_ops.hip', 'refiner_ops.hip']
+SOURCES = ['target_model.hip', 'cg_persistent.hip', 'joint_persistent.hip', 'joint_fit.hip', 'wide_maps.hip', 'conv_igemm.hip', 'conv_gemm32.hip', 'conv_wino.hip', 'conv_wino4.hip', 'backbone.hip', 'image_ops.hip', 'refiner_ops.hip', 'telea_host.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 if os.environ.get('FRTM_BUILD_ABLATE'):      # tools/g32_bench.py ablations (kernels that skip work on purpose): never in the default build

@@ -21,8 +21,9 @@ class AttrDict(dict):
 class Parameters:
 
     def __init__(self, weights=None, fast=False, device='cuda:0', feature_extractor=None, backbone_weights=None, feature_batch=16, trunk_lanes=2,
-                 ytvos_fork_solver=False, refiner_graphs=None):
+                 ytvos_fork_solver=False, refiner_graphs=None, aug_fill='telea'):
         self.device = device
+        self.aug_fill = aug_fill                  # first-frame hole fill: 'telea' (the reference's recipe, on the host; default) or 'pull_push' (device-side substitute of rounds 2-5)
         self.refiner_graphs = refiner_graphs      # None: the Tracker's default (no replay since round 6); True: refiner windows replayed as hipGraphs
         self.refiner_factory = None       # optional: callable(ft_channels) -> SegNetwork used instead of a default-initialised one
         self.feature_batch = feature_batch
@@ -69,7 +70,7 @@ class Parameters:
         self.refnet_params = AttrDict(layers=('layer5', 'layer4', 'layer3', 'layer2'), nchannels=64, use_batch_norm=True)
 
     def get_model(self):
-        augmenter = ImageAugmenter(self.aug_params)
+        augmenter = ImageAugmenter(self.aug_params, fill=self.aug_fill)
         extractor = ResnetFeatureExtractor(self.feature_extractor, weights=self.backbone_weights).to(self.device)
         self.disc_params.in_channels = extractor.get_out_channels()[self.disc_params.layer]
         p = self.refnet_params
@@ -119,6 +120,7 @@ def main(argv=None):
     ap.add_argument('--prewarm', default=None, help='HxW: capture the graphs for this frame size (1-3 objects) before the first sequence')
     ap.add_argument('--no-cpu-pin', action='store_true', help='leave the host threads to the scheduler instead of pinning them to cores near the GPU')
     ap.add_argument('--refiner-graphs', action='store_true', help='replay refiner windows as hipGraphs (Tracker(refiner_graphs=True); default: kernel by kernel, deep levels on a side stream)')
+    ap.add_argument('--pull-push-fill', action='store_true', help="first-frame hole fill by the device-side pull-push pyramid (rounds 2-5) instead of Telea's fast-marching method on the host (the reference's cv2.inpaint recipe restated, the default)")
     ap.add_argument('--keep-gc', action='store_true', help="leave Python's cyclic collector alone (default: held off while a sequence is enqueued)")
     args = ap.parse_args(argv)
 
@@ -147,7 +149,7 @@ def main(argv=None):
     if rank == 0:
         print('host threads: %s' % (('CPUs %d-%d (%d logical) near the GPU' % (min(host_cpus), max(host_cpus), len(host_cpus))) if host_cpus else 'not pinned'))
     tracker = Parameters(weights, fast=args.fast, device=args.dev, ytvos_fork_solver=args.ytvos_solver,
-                         refiner_graphs=True if args.refiner_graphs else None).get_model()
+                         refiner_graphs=True if args.refiner_graphs else None, aug_fill='pull_push' if args.pull_push_fill else 'telea').get_model()
     if not args.keep_gc:
         # driver-level decisions (process-global, so not the library's): long-lived objects into the permanent generation once, and no
         # cyclic collection while a sequence's launches are being enqueued

@@ -30,9 +30,21 @@ def _mat(rows):
 
 class ImageAugmenter:
 
-    def __init__(self, parameters):
+    def __init__(self, parameters, fill='telea'):
+        """fill: how the hole the cut-out object leaves is filled before the background is warped (reference augmenter.py:317-324:
+        cv2.inpaint(image, mask1, inpaintRadius=d, cv2.INPAINT_TELEA) with d = 1).
+          'telea'      (default since round 6) the reference's recipe restated: the mask dilated by OpenCV's 2x2 ellipse, filled by Telea's
+                       fast-marching method ON THE HOST (csrc/telea_host.hip: frtm_telea_inpaint_u8; sequential by nature, on the CPU in the
+                       reference as well): one device -> host copy of the frame, ~3 ms per object at 480p, one upload.  Tracker.run_sequence hides
+                       it under the first tracking pass (20-frame sequence: 474.6 against 472 frames/s); a caller of initialize() pays it;
+          'pull_push'  rounds 2-5's device-side pull-push pyramid over the 3x3-dilated mask (csrc/image_ops.hip): microseconds, no host step.
+                       Against Telea's fill it moves the oracle's J&F by -0.13 points on the mean of G14's objects, 0.01 on the median
+                       (profiles/r06_fill_evidence.txt)."""
+        if fill not in ('pull_push', 'telea'):
+            raise ValueError("ImageAugmenter: fill must be 'pull_push' or 'telea' (got %r)" % (fill,))
         self.params = parameters
         self.max_retries = 100
+        self.fill = fill
 
     # ---- parameter draws (numpy global RNG, like the reference) --------------------------------
     @staticmethod
@@ -210,6 +222,25 @@ class ImageAugmenter:
                                   fwd=torch.empty(19, 6, **f), inv=torch.empty(19, 6, **f))
         return sc
 
+    @staticmethod
+    def _telea_background(im8, lb8, background):
+        """background (3,H,W float32, device) <- the frame with the reference's hole (mask grown by one pixel down and right: cv2.dilate with
+        cv2.getStructuringElement(MORPH_ELLIPSE, (2, 2)), augmenter.py:318 at d = 1) filled by Telea's method on the host."""
+        import ctypes
+        Hh, Ww = int(lb8.shape[-2]), int(lb8.shape[-1])
+        m = lb8.reshape(Hh, Ww) > 0
+        hole = m.clone()
+        hole[1:, :] |= m[:-1, :]
+        hole[:, 1:] |= m[:, :-1]
+        im_h = im8.reshape(3, Hh, Ww).cpu().numpy()                      # (synchronises the stream: the host needs the pixels)
+        hole_h = hole.to(torch.uint8).cpu().numpy()
+        out = np.empty_like(im_h)
+        rc = H.lib().frtm_telea_inpaint_u8(im_h.ctypes.data_as(ctypes.c_void_p), hole_h.ctypes.data_as(ctypes.c_void_p), 3, Hh, Ww, 1,
+                                           out.ctypes.data_as(ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError('frtm_telea_inpaint_u8 failed (%d)' % rc)
+        background.copy_(H.upload(torch.from_numpy(out), background.device))
+
     def augment_first_frame(self, im, lb):
         p = self.params
         im_sz = tuple(int(v) for v in im.shape[-2:])
@@ -228,8 +259,12 @@ class ImageAugmenter:
         labels = torch.empty(N + 1, 1, Hh, Ww, dtype=torch.uint8, device=dev)
         H.call('frtm_aug_prepare', im8.data_ptr(), lb8.data_ptr(), Hh, Ww, H.ptr(sc['target']), H.ptr(pyr), H.ptr(sc['maskf']),
                labels[0].data_ptr())                                                  # (sample 0's label = the binarised input label)
-        H.call('frtm_pull_push_fill', H.ptr(pyr), pyr.numel(), Hh, Ww)
         background = pyr[:3 * Hh * Ww].view(3, Hh, Ww)
+        if self.fill == 'telea':
+            self._telea_background(im8, lb8, background)
+        else:
+            H.call('frtm_pull_push_fill', H.ptr(pyr), pyr.numel(), Hh, Ww)
+        self.last_background = background        # (a view of the scratch: valid until the next call; read by the parity tests)
 
         fg = deepcopy(dict(p.fg_aug_params))
         fg['location'] = self._target_locations(p.num_aug, im_sz)

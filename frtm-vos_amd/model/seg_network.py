@@ -196,7 +196,10 @@ class SegNetwork(nn.Module):
                 return self._forward_graphed(scores, features, image_size)
             # launched kernel by kernel: the deep pyramid levels still run on the shared side stream next to the 120x214 level (round 6:
             # what a graph replay gains over serial launches is this overlap, not the launch count -- the host enqueues ahead of the GPU)
-            par = self.parallel_levels and self.parallel_eager and not torch.cuda.is_current_stream_capturing()
+            # (from two frames per window on: on a single frame -- the online caller's track() -- the fork / join costs more than the overlap buys,
+            #  streaming 317.7 -> 312 frames/s; windows of 5-8 frames gain 5-6 %: profiles/r06_refiner_window_ab.txt)
+            par = (self.parallel_levels and self.parallel_eager and next(iter(features.values())).shape[0] >= 2
+                   and not torch.cuda.is_current_stream_capturing())
             return self._forward_hip(scores, features, image_size, self._side_streams() if par else None)
         return self.forward_torch(scores, features, image_size, shared)
 

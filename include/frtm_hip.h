@@ -352,6 +352,11 @@ int frtm_spin(int microseconds, frtm_stream_t stream);
 /* One wave that reads both clocks for `microseconds` (1..100000): out2 (device, two 64-bit words) = {shader-clock cycles (s_memtime), ticks of the
  * constant 100 MHz counter}.  On a side stream next to a kernel sequence: the clock the shader holds under that load (bench.py: roofline.dominant_kernel). */
 int frtm_clock_probe(int microseconds, unsigned long long* out2, frtm_stream_t stream);
+/* HOST-side hole fill of the reference's first-frame augmentation: cv2.inpaint(image, hole, inpaintRadius = radius, cv2.INPAINT_TELEA)
+ * (reference model/augmenter.py:317-324; the reference runs it on the CPU through OpenCV, once per object).  Restated from the published
+ * fast-marching algorithm (csrc/telea_host.hip); every pointer is HOST memory, no GPU involved.  image / out: C planes of H x W uint8 (C <= 4),
+ * hole: H x W, nonzero = pixel to fill.  An OPTION of the product (ImageAugmenter(fill='telea')); the default fill is frtm_pull_push_fill. */
+int frtm_telea_inpaint_u8(const unsigned char* image_chw, const unsigned char* hole_hw, int C, int H, int W, int radius, unsigned char* out_chw);
 /* Launches of frtm_conv2d (this process) that took the PERSISTENT form of the 64x64 / 8-wave GEMM kernel (csrc/conv_igemm.hip: k_conv_igemm_p, round 6):
  * stride-1 1x1 convs with Cout % 64 == 0, Cin % 64 == 0, H*W % 4 == 0 and at least 1.5 tiles per resident workgroup.  FRTM_NO_PERSIST_GEMM=1 switches
  * the form off (A/B; results are bit-identical either way). */

@@ -827,3 +827,36 @@ def test_g15_default_start_weights_are_the_references(golden):
         torch.random.manual_seed(0)
         torch.nn.Conv2d(cin, c, 1, bias=False), torch.nn.Conv2d(c, 1, 3, padding=1, bias=False)
         assert torch.equal(after_hit, torch.random.get_rng_state())
+
+
+def test_telea_host_fill_equals_the_oracle_restatement():
+    """frtm_telea_inpaint_u8 (csrc/telea_host.hip; the reference's cv2.inpaint(..., INPAINT_TELEA) of model/augmenter.py:317-324 restated, HOST code:
+    no GPU involved) against oracle/aug_ref.py: telea_fill_ref -- same published algorithm, same float / double arithmetic: bit-identical, radius 1
+    (the reference's d = 1) and larger, holes that touch every image border, several channel counts."""
+    import ctypes
+    from frtm_vos_amd import _hip as H
+    from oracle.aug_ref import reference_hole, telea_fill_ref
+    L = H.lib()
+    rng = np.random.RandomState(7)
+    for Hh, Ww, r, C in ((40, 56, 1, 3), (33, 47, 1, 3), (24, 30, 2, 3), (37, 29, 3, 3), (20, 20, 1, 1)):
+        yy, xx = np.mgrid[0:Hh, 0:Ww]
+        base = np.stack([yy * 3 + xx, 2 * xx + 40, 200 - yy * 2]).astype(np.float32)[:C]
+        img = ((rng.randint(0, 256, (C, Hh, Ww)) * 0.3 + base * 0.7) % 256).astype(np.uint8)
+        m = np.zeros((Hh, Ww), bool)
+        m[8:18, 10:25] = True
+        m[0:4, 0:6] = True
+        m[Hh - 5:, Ww - 7:] = True
+        m[Hh - 3:, 0:3] = True
+        m[12:15, Ww - 2:] = True
+        hole = reference_hole(m)
+        im3 = img if C == 3 else np.repeat(img, 3, 0)
+        ref = telea_fill_ref(im3, hole, radius=r)[:C]
+        out = np.empty_like(img)
+        h8 = np.ascontiguousarray(hole.astype(np.uint8))
+        rc = L.frtm_telea_inpaint_u8(np.ascontiguousarray(img).ctypes.data_as(ctypes.c_void_p), h8.ctypes.data_as(ctypes.c_void_p), C, Hh, Ww, r,
+                                     out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        assert np.array_equal(out, ref), (Hh, Ww, r, C, int((out != ref).sum()))
+        assert np.array_equal(out[:, ~hole], img[:, ~hole])                     # known pixels are never touched
+    bad = np.zeros((3, 4, 4), np.uint8)
+    assert L.frtm_telea_inpaint_u8(bad.ctypes.data_as(ctypes.c_void_p), None, 3, 4, 4, 1, bad.ctypes.data_as(ctypes.c_void_p)) != 0

@@ -180,7 +180,7 @@ def test_augment_first_frame_against_the_oracle(seed, size, objs):
     from frtm_vos_amd.lib.synthetic import SyntheticSequence
     from frtm_vos_amd.model.augmenter import ImageAugmenter
     from oracle.aug_ref import augment_ref
-    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params)
+    aug = ImageAugmenter(Parameters(None, feature_extractor='resnet18').aug_params, fill='pull_push')      # (the device-side fill; Telea's: tests/test_round6_gpu.py)
     seq = SyntheticSequence('a', 1, size, objs, seed=10 + seed)
     im, lb, ids = seq[0]
     lb1 = (lb == 1).to(torch.uint8)

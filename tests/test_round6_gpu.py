@@ -191,3 +191,38 @@ def test_refiner_eager_parallel_levels_equal_the_serial_launches():
             c = net(scores, feats, size).clone()
         main.synchronize()
         assert torch.equal(a, b) and torch.equal(a, c), (it, float((a - b).abs().max()))
+
+
+def test_augmenter_with_the_telea_fill_follows_the_reference_recipe():
+    """ImageAugmenter(fill='telea') (round 6): the background behind the pasted object is the frame with the reference's hole (mask dilated by OpenCV's
+    2x2 ellipse) filled by Telea's method (reference model/augmenter.py:317-324 at d = 1, :497) -- bit-identical to the oracle's telea_background_ref --
+    and the augmented stack is the oracle's composition over THAT background within the tolerances of the pull-push test (tests/test_round4_gpu.py).
+    It is the default fill since round 6; fill='pull_push' selects the device-side pyramid of rounds 2-5."""
+    from frtm_vos_amd.evaluate import Parameters
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    from frtm_vos_amd.model.augmenter import ImageAugmenter
+    from oracle.aug_ref import augment_ref, telea_background_ref
+    P = Parameters(None, feature_extractor='resnet18')
+    assert P.get_model().augmenter.fill == 'telea' and Parameters(None, feature_extractor='resnet18', aug_fill='pull_push').get_model().augmenter.fill == 'pull_push'
+    with pytest.raises(ValueError):
+        ImageAugmenter(P.aug_params, fill='navier_stokes')
+    size = (240, 320)
+    aug = ImageAugmenter(P.aug_params)
+    assert aug.fill == 'telea'
+    seq = SyntheticSequence('tf', 1, size, 2, seed=21)
+    im, lb, ids = seq[0]
+    lb1 = (lb == 1).to(torch.uint8)
+    np.random.seed(5)
+    ims, labs = aug.augment_first_frame(im.to(DEV), lb1.to(DEV))
+    bg_ref = telea_background_ref(im, lb1.reshape(size))
+    assert torch.equal(aug.last_background.cpu(), bg_ref)
+    surv = [dict(T=np.vstack([fwd[j].cpu().numpy().reshape(2, 3), [0, 0, 1]]), G=G, Tb=Tb, Gb=Gb) for fwd, j, G, Tb, Gb in aug.last_transforms]
+    rim, rlb = augment_ref(im, lb1, surv, background=bg_ref)
+    d = (ims.cpu().int() - rim.int()).abs()
+    assert int(d.max()) <= 2 and float((d <= 1).float().mean()) >= 0.999, (int(d.max()), float((d <= 1).float().mean()))
+    assert float((labs.cpu() != rlb).float().mean()) < 2e-4
+    # and it is a different background than the default fill's
+    aug_pp = ImageAugmenter(P.aug_params, fill='pull_push')
+    np.random.seed(5)
+    aug_pp.augment_first_frame(im.to(DEV), lb1.to(DEV))
+    assert not torch.equal(aug_pp.last_background.cpu(), bg_ref)
