@@ -38,7 +38,7 @@ class ImageAugmenter:
                        reference as well): one device -> host copy of the frame, ~3 ms per object at 480p, one upload.  Tracker.run_sequence hides
                        it under the first tracking pass (20-frame sequence: 474.6 against 472 frames/s); a caller of initialize() pays it;
           'pull_push'  rounds 2-5's device-side pull-push pyramid over the 3x3-dilated mask (csrc/image_ops.hip): microseconds, no host step.
-                       Against Telea's fill it moves the oracle's J&F by -0.13 points on the mean of G14's objects, 0.01 on the median
+                       Against Telea's fill it moves the CPU restatement's J&F by -0.13 points on the mean of G14's objects, 0.01 on the median
                        (profiles/r06_fill_evidence.txt)."""
         if fill not in ('pull_push', 'telea'):
             raise ValueError("ImageAugmenter: fill must be 'pull_push' or 'telea' (got %r)" % (fill,))
