@@ -559,14 +559,14 @@ def cg_roofline(dev, size, n_samples=80, c=96, iters=10, reps=20, persistent=Tru
 
 
 def dominant_kernel_leg(dev, frames=8, hw=(30, 54), reps=40):
-    """roofline.dominant_kernel (VERDICT r5 'Next' #4): the trunk's dominant kernel -- k_conv_igemm<64,64,2,4,1>, the 1x1 GEMMs of ResNet-101's layer3
+    """roofline.dominant_kernel (VERDICT r5 'Next' #4): the trunk's dominant kernel -- k_conv_igemm<64,64,2,4,1> and its persistent form, the 1x1 GEMMs of ResNet-101's layer3
     (reference model/feature_extractor.py:50-65) -- ALONE on the GPU, measured in this run: its two shapes at one lane's batch (8 frames, 30x54) as
     `reps` back-to-back launches between HIP events on the stream they are launched on (BN + residual + ReLU resp. BN + ReLU fused, as in the trunk),
     with the shader clock read by a one-wave probe on a side stream under the same load (frtm_clock_probe: s_memtime against the 100 MHz counter)."""
     import ctypes
     from frtm_vos_amd import _hip as H, ops
     g = torch.Generator(device='cpu').manual_seed(11)
-    out = {'name': 'k_conv_igemm<64, 64, 2, 4, 1, 32>', 'batch': frames, 'map': '%dx%d' % hw, 'launches_timed': reps, 'shapes': {}}
+    out = {'name': 'k_conv_igemm_p (256->1024: the persistent form of k_conv_igemm<64,64,2,4,1>, round 6) / k_conv_igemm<64, 64, 2, 4, 1, 32> (1024->256: 812 tiles, below 1.5 per resident workgroup)', 'batch': frames, 'map': '%dx%d' % hw, 'launches_timed': reps, 'shapes': {}}
     side = torch.cuda.Stream(device=dev)
     clk = torch.zeros(2, dtype=torch.int64, device=dev)
     tot_fl, tot_us = 0.0, 0.0
@@ -618,9 +618,9 @@ def dominant_kernel_leg(dev, frames=8, hw=(30, 54), reps=40):
     for sf in sorted(_glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_steady_state.csv')), reverse=True):
         try:
             for ln in open(sf):
-                if ln.startswith('"void k_conv_igemm<64, 64, 2, 4, 1, 32>'):
-                    out['share_of_steady_state_busy_time'] = {'percent': float(ln.rsplit(',', 1)[1]), 'source': 'profiles/' + os.path.basename(sf)}
-                    break
+                if ln.startswith(('"void k_conv_igemm<64, 64, 2, 4, 1, 32>', 'k_conv_igemm_p', '"k_conv_igemm_p')):
+                    sh = out.setdefault('share_of_steady_state_busy_time', {'percent': 0.0, 'source': 'profiles/' + os.path.basename(sf)})
+                    sh['percent'] = round(sh['percent'] + float(ln.rsplit(',', 1)[1]), 2)
             break
         except Exception:      # noqa: BLE001
             pass

@@ -90,8 +90,8 @@ if len(sys.argv) > 6:
     tdir = sys.argv[6]
     t2 = list(csv.DictReader(open(os.path.join(tdir, 'prof_kernel_trace.csv'))))
     # (the F(4x4,3x3) convs are three kernels -- transform, the batched products on k_conv_igemm, transform -- and ONE conv launch in bench.py's count)
-    conv = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in t2 if r['Kernel_Name'].startswith(('void k_conv', 'k_splitk')) or 'k_wino4_' in r['Kernel_Name'] or 'k_wino6_' in r['Kernel_Name']]
-    convk = [r for r in t2 if r['Kernel_Name'].startswith('void k_conv')]
+    conv = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in t2 if r['Kernel_Name'].startswith(('void k_conv', 'k_conv', 'k_splitk')) or 'k_wino4_' in r['Kernel_Name'] or 'k_wino6_' in r['Kernel_Name']]
+    convk = [r for r in t2 if r['Kernel_Name'].startswith(('void k_conv', 'k_conv'))]
     u = union_ns(conv)
     ssum = sum(e - a for a, e in conv)
     with open(os.path.join(out, tag + '_trunk_only.json'), 'w') as f:

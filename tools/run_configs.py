@@ -11,7 +11,7 @@ CONFIGS = ['--backbone resnet18 --fast --objects 1', '--objects 1', '--objects 3
            '--size 720x1280 --objects 3 --late-object 10 --steps 32', '--size 720x1280 --objects 3 --late-object 10 --steps 96',
            '--size 1080x1920 --objects 8 --memory 32 --steps 24', '--size 1080x1920 --objects 8 --memory 32 --steps 64',
            '--sequences 12 --steps 20 --warmup 5',
-           '--steps 20 --warmup 5', '--no-winograd', '--no-windows', '--no-persistent-cg', '--no-early-first-pass', '--no-fold-tail --steps 20',
+           '--steps 20 --warmup 5', '--steps 20 --warmup 5 --pull-push-fill', '--steps 20 --warmup 5 --refiner-graph', '--steps 20 --warmup 5 --refiner-serial', '--no-winograd', '--no-windows', '--no-persistent-cg', '--no-early-first-pass', '--no-fold-tail --steps 20',
            '--trunk-batch 1 --trunk-lanes 1 --no-windows --no-winograd']
 lines = ['# python bench.py --no-cpu-baseline --no-cg-roofline --no-init-sweep --no-dataset-sim <flags>   (1x MI355X; default = resnet101, 480x854, 2 objects, 64 frames, '
          'full iterations, memory 80;', '# every line on the real per-frame path: path_counters = inserts / re-solves performed vs scheduled)']

@@ -22,13 +22,13 @@ out = {'command': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ
                   '(one lane of 8 frames, RN101 480x854: every conv kernel ALONE on the GPU; in bench.py two such lanes run concurrently)',
        'kernels': {}}
 for k, v in sorted(per.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', 0) * 1.0):
-    if not (k.startswith('void k_conv') or 'k_wino4_' in k or 'k_wino6_' in k) or n[k] == 0:
+    if not (k.startswith(('void k_conv', 'k_conv')) or 'k_wino4_' in k or 'k_wino6_' in k) or n[k] == 0:
         continue
     gui = v['GRBM_GUI_ACTIVE'] / 8 / n[k]
     out['kernels'][k[:70]] = {'launches': n[k], 'active_cycles_per_launch': round(gui), 'cu_busy': round(v['SQ_BUSY_CU_CYCLES'] / 256 / n[k] / gui, 3),
                               'mfma_pipe_busy': round(v['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / n[k] / gui, 3), 'waves_per_launch': round(v['SQ_WAVES'] / n[k])}
-tot_m = sum(v['SQ_VALU_MFMA_BUSY_CYCLES'] for k, v in per.items() if k.startswith('void k_conv')) / 1024
-tot_g = sum(v['GRBM_GUI_ACTIVE'] for k, v in per.items() if k.startswith('void k_conv')) / 8
+tot_m = sum(v['SQ_VALU_MFMA_BUSY_CYCLES'] for k, v in per.items() if k.startswith(('void k_conv', 'k_conv'))) / 1024
+tot_g = sum(v['GRBM_GUI_ACTIVE'] for k, v in per.items() if k.startswith(('void k_conv', 'k_conv'))) / 8
 out['conv_family'] = {'mfma_pipe_busy': round(tot_m / tot_g, 3)}
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps(out['conv_family']), len(out['kernels']), 'kernels')
