@@ -861,7 +861,9 @@ def main():
         out = raw_augment(im, lb)
         aug_log.append(out)                      # references only (no copy inside the timed region)
         return out
+    logged_augment.wraps_augmenter = True       # (Tracker.initialize may start the objects' hole fills together: model/augmenter.py: prefetch_fills)
     tracker.augment = timer.wrap('init_augment', logged_augment)
+    tracker.augment.wraps_augmenter = True
     tracker.initialize = timer.wrap('initialize_total', tracker.initialize)
     tracker.refiner.forward = timer.wrap('refiner', tracker.refiner.forward)
     tracker.track_window = timer.wrap('track_window', tracker.track_window)          # (contains 'refiner' and 'target_update')

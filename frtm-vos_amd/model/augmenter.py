@@ -28,6 +28,9 @@ def _mat(rows):
     return np.array(rows, dtype=np.float64)
 
 
+_FILL_POOL = None          # host threads of the Telea fills of objects that start together (ImageAugmenter.prefetch_fills)
+
+
 class ImageAugmenter:
 
     def __init__(self, parameters, fill='telea'):
@@ -223,22 +226,50 @@ class ImageAugmenter:
         return sc
 
     @staticmethod
-    def _telea_background(im8, lb8, background):
-        """background (3,H,W float32, device) <- the frame with the reference's hole (mask grown by one pixel down and right: cv2.dilate with
-        cv2.getStructuringElement(MORPH_ELLIPSE, (2, 2)), augmenter.py:318 at d = 1) filled by Telea's method on the host."""
-        import ctypes
+    def _hole_host(lb8):
+        """The reference's hole as a host array: the mask grown by one pixel down and right (cv2.dilate with
+        cv2.getStructuringElement(MORPH_ELLIPSE, (2, 2)), augmenter.py:318 at d = 1)."""
         Hh, Ww = int(lb8.shape[-2]), int(lb8.shape[-1])
         m = lb8.reshape(Hh, Ww) > 0
         hole = m.clone()
         hole[1:, :] |= m[:-1, :]
         hole[:, 1:] |= m[:, :-1]
-        im_h = im8.reshape(3, Hh, Ww).cpu().numpy()                      # (synchronises the stream: the host needs the pixels)
-        hole_h = hole.to(torch.uint8).cpu().numpy()
+        return hole.to(torch.uint8).cpu().numpy()
+
+    @staticmethod
+    def _telea_host(im_h, hole_h):
+        import ctypes
         out = np.empty_like(im_h)
-        rc = H.lib().frtm_telea_inpaint_u8(im_h.ctypes.data_as(ctypes.c_void_p), hole_h.ctypes.data_as(ctypes.c_void_p), 3, Hh, Ww, 1,
-                                           out.ctypes.data_as(ctypes.c_void_p))
+        rc = H.lib().frtm_telea_inpaint_u8(im_h.ctypes.data_as(ctypes.c_void_p), hole_h.ctypes.data_as(ctypes.c_void_p), 3, im_h.shape[-2], im_h.shape[-1], 1,
+                                           out.ctypes.data_as(ctypes.c_void_p))         # (ctypes releases the GIL: fills of several objects run at once)
         if rc != 0:
             raise RuntimeError('frtm_telea_inpaint_u8 failed (%d)' % rc)
+        return out
+
+    def prefetch_fills(self, im, masks):
+        """Objects that start on the same frame: their Telea fills (a host step of a few ms each) are started on host threads at once; the
+        augment_first_frame calls that follow (same image tensor, same uint8 mask tensors) pick the results up.  No-op for other fills."""
+        self._fills = {}
+        if self.fill != 'telea' or len(masks) < 2:
+            return
+        global _FILL_POOL
+        if _FILL_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _FILL_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix='frtm-telea')
+        Hh, Ww = int(im.shape[-2]), int(im.shape[-1])
+        im_h = im.reshape(3, Hh, Ww).to(torch.uint8).cpu().numpy()
+        for m in masks:
+            if m.dtype == torch.uint8 and m.is_contiguous():
+                self._fills[(im.data_ptr(), m.data_ptr())] = _FILL_POOL.submit(self._telea_host, im_h, self._hole_host(m))
+
+    def _telea_background(self, im8, lb8, background, key=None):
+        """background (3,H,W float32, device) <- the frame with the reference's hole filled by Telea's method on the host."""
+        fut = getattr(self, '_fills', {}).pop(key, None)
+        if fut is not None:
+            out = fut.result()
+        else:
+            Hh, Ww = int(lb8.shape[-2]), int(lb8.shape[-1])
+            out = self._telea_host(im8.reshape(3, Hh, Ww).cpu().numpy(), self._hole_host(lb8))     # (synchronises the stream: the host needs the pixels)
         background.copy_(H.upload(torch.from_numpy(out), background.device))
 
     def augment_first_frame(self, im, lb):
@@ -261,7 +292,7 @@ class ImageAugmenter:
                labels[0].data_ptr())                                                  # (sample 0's label = the binarised input label)
         background = pyr[:3 * Hh * Ww].view(3, Hh, Ww)
         if self.fill == 'telea':
-            self._telea_background(im8, lb8, background)
+            self._telea_background(im8, lb8, background, key=(im.data_ptr(), lb.data_ptr()))
         else:
             H.call('frtm_pull_push_fill', H.ptr(pyr), pyr.numel(), Hh, Ww)
         self.last_background = background        # (a view of the scratch: valid until the next call; read by the parity tests)

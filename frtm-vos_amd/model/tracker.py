@@ -684,7 +684,7 @@ class Tracker(nn.Module):
         # the one-kernel mask path reads uint8 label maps; any other integer type (object ids beyond 255 exist in such maps, and a narrowing
         # cast would wrap them onto small ids) takes the reference's literal comparison below
         lab8 = lab8.contiguous() if lab8.dtype == torch.uint8 else None
-        fresh = []
+        fresh, started = [], []
         for obj_id in new_objects:
             # mask = (labels == obj_id) as uint8 and as the object's plane of current_masks: one kernel (reference :170-172,188)
             if lab8 is not None and 0 <= int(obj_id) < 256:
@@ -704,8 +704,15 @@ class Tracker(nn.Module):
                 d.project.weight.data.copy_(w1.to(d.project.weight.dtype))
                 d.filter.weight.data.copy_(w2.to(d.filter.weight.dtype))
                 d._invalidate()
-            torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept:
-            np.random.seed(0)                  # augmentation draws are identical for every object
+            torch.random.manual_seed(0)        # the reference's "HACK for debugging" (:179-180) is kept (the next object's weights
+            started.append((target, mask))     # are drawn from this state; the augmentation below draws from numpy only)
+        # Telea's hole fill is a host step of a few ms per object (model/augmenter.py): the fills of objects that start TOGETHER run on host
+        # threads at once instead of one after the other (only when self.augment still is the augmenter's own method, or says it wraps it)
+        if len(started) > 1 and hasattr(self.augmenter, 'prefetch_fills') and \
+                (self.augment == self.augmenter.augment_first_frame or getattr(self.augment, 'wraps_augmenter', False)):
+            self.augmenter.prefetch_fills(image, [m for _, m in started])
+        for target, mask in started:
+            np.random.seed(0)                  # augmentation draws are identical for every object (reference :180)
             im, msk = self.augment(image, mask)
             fresh.append((target, im, msk))
         if fresh:

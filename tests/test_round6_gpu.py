@@ -221,6 +221,19 @@ def test_augmenter_with_the_telea_fill_follows_the_reference_recipe():
     d = (ims.cpu().int() - rim.int()).abs()
     assert int(d.max()) <= 2 and float((d <= 1).float().mean()) >= 0.999, (int(d.max()), float((d <= 1).float().mean()))
     assert float((labs.cpu() != rlb).float().mean()) < 2e-4
+    # objects that start together: their fills run on host threads at once (prefetch_fills, what Tracker.initialize calls) -- same stacks
+    imd, masks = im.to(DEV), [(lb == k).to(torch.uint8).reshape(1, *size).to(DEV).contiguous() for k in (1, 2)]
+    alone = []
+    for m in masks:
+        np.random.seed(5)
+        alone.append(tuple(t.clone() for t in aug.augment_first_frame(imd, m)))
+    aug.prefetch_fills(imd, masks)
+    assert len(aug._fills) == 2
+    for m, (ims_a, labs_a) in zip(masks, alone):
+        np.random.seed(5)
+        ims_p, labs_p = aug.augment_first_frame(imd, m)
+        assert torch.equal(ims_p, ims_a) and torch.equal(labs_p, labs_a)
+    assert len(aug._fills) == 0
     # and it is a different background than the default fill's
     aug_pp = ImageAugmenter(P.aug_params, fill='pull_push')
     np.random.seed(5)
