@@ -239,3 +239,4 @@ def test_augmenter_with_the_telea_fill_follows_the_reference_recipe():
     np.random.seed(5)
     aug_pp.augment_first_frame(im.to(DEV), lb1.to(DEV))
     assert not torch.equal(aug_pp.last_background.cpu(), bg_ref)
+
