@@ -24,6 +24,7 @@ if len(sys.argv) > 3 and sys.argv[3] == 'tracker':
         p = Parameters(None, fast=True, device='cuda:0', feature_extractor='resnet18', feature_batch=8, trunk_lanes=2)
         p.disc_params.update(memory_size=8, init_iters=(2, 3), update_iters=(3,))
         trk = p.get_model().eval()
+        trk.graph_refiner = True                   # (opt-in since round 6)
         trk.refiner.capture_after = 0
         if os.environ.get('GRAPH_TRUNK'):          # trunk passes as hipGraphs too (lanes fork to the library's lane streams inside the capture)
             trk.graph_trunk = True
