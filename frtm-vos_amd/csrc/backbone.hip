@@ -103,6 +103,46 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const float* __restrict__ in
   out[((size_t)blockIdx.z * Ho + oy) * Wo + ox] = m;
 }
 
+// The same pool, FOUR output columns per thread (round 6): the nine input columns 2 ox0 - 1 .. 2 ox0 + 7 of a row come as one dword and two 16-byte
+// loads at dword alignment instead of four (dword + 8 bytes) pairs -- a quarter of the load instructions per output; the four results leave as one
+// 16-byte store.  Maxima are exact: identical to k_maxpool3s2.  Rows whose last group would read past the row end take the scalar form per column.
+typedef float f32x4m __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void k_maxpool3s2_x4(const float* __restrict__ in, int Hin, int Win, int Ho, int Wo, float* __restrict__ out) {
+  const int ox0 = (blockIdx.x * 64 + threadIdx.x) * 4, oy = blockIdx.y * 4 + threadIdx.y;
+  if (ox0 >= Wo || oy >= Ho) return;
+  const float* ip = in + (size_t)blockIdx.z * Hin * Win;
+  const int x0 = ox0 * 2;
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const bool full = x0 + 7 < Win && ox0 + 3 < Wo;            // all nine columns inside the row, four outputs wanted
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = oy * 2 - 1 + dy;
+    if ((unsigned)yy >= (unsigned)Hin) continue;
+    const float* row = ip + (size_t)yy * Win + x0;
+    if (full) {
+      const f32x4m a = *(const f32x4m*)row, b = *(const f32x4m*)(row + 4);
+      const float l = x0 >= 1 ? row[-1] : -INFINITY;
+      m[0] = fmaxf(m[0], fmaxf(l, fmaxf(a[0], a[1])));
+      m[1] = fmaxf(m[1], fmaxf(a[1], fmaxf(a[2], a[3])));
+      m[2] = fmaxf(m[2], fmaxf(a[3], fmaxf(b[0], b[1])));
+      m[3] = fmaxf(m[3], fmaxf(b[1], fmaxf(b[2], b[3])));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int xc = x0 + 2 * k;                            // centre column of output ox0 + k
+        if (ox0 + k >= Wo) break;
+        float v = row[2 * k];
+        if (xc >= 1) v = fmaxf(v, row[2 * k - 1]);
+        if (xc + 1 < Win) v = fmaxf(v, row[2 * k + 1]);
+        m[k] = fmaxf(m[k], v);
+      }
+    }
+  }
+  float* o = out + ((size_t)blockIdx.z * Ho + oy) * Wo + ox0;
+  if (full) *(f32x4m*)o = f32x4m{m[0], m[1], m[2], m[3]};
+  else for (int k = 0; k < 4 && ox0 + k < Wo; ++k) o[k] = m[k];
+}
+
 static int add_conv(frtm_backbone* bb, int Cout, int Cin, int ks, int stride) {
   ConvL c;
   c.Cout = Cout; c.Cin = Cin; c.ks = ks; c.stride = stride; c.pad = ks / 2;
@@ -262,7 +302,9 @@ static int forward_lane(frtm_backbone* bb, Lane& ln, const unsigned char* image_
   if (rc) return rc;
   const int Hp = (h1 + 2 - 3) / 2 + 1, Wp = (w1 + 2 - 3) / 2 + 1;
   float* x = layer1 ? layer1 : ln.buf[2];
-  k_maxpool3s2<<<dim3(ceil_div(Wp, 64), ceil_div(Hp, 4), B * 64), dim3(64, 4), 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x);
+  static const bool pool_v1 = getenv("FRTM_MAXPOOL_V1") != nullptr;        // A/B: one output column per thread (rounds 4-5)
+  if (pool_v1) k_maxpool3s2<<<dim3(ceil_div(Wp, 64), ceil_div(Hp, 4), B * 64), dim3(64, 4), 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x);
+  else k_maxpool3s2_x4<<<dim3(ceil_div(Wp, 256), ceil_div(Hp, 4), B * 64), dim3(64, 4), 0, st>>>(ln.buf[1], h1, w1, Hp, Wp, x);
   FRTM_LAUNCH_CHECK();
   int ch = Hp, cw = Wp;
   float* taps[4] = {layer2, layer3, layer4, layer5};
