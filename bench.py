@@ -1209,9 +1209,15 @@ def main():
         if leg_errors:
             out['leg_errors'] = leg_errors
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()                      # (gloo: every rank has reported)
+        if dist_err is None:
+            dist.destroy_process_group()
+        else:                               # an RCCL group that failed to come up is not torn down collectively (it may never return): leave
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0 if out['valid'] else 3)
     if not out['valid']:
         sys.exit(3)
 

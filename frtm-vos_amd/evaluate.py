@@ -125,14 +125,14 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    coll, red_dev = None, 'cpu'
+    coll, red_dev, dist_err = None, 'cpu', None
     if world > 1:
         from .shard import init_process_groups
         local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', 0))
         torch.cuda.set_device(local)
         args.dev = 'cuda:%d' % local
         # control group gloo; RCCL on top when it comes up on every rank, else the closing reduction runs over gloo too (shard.py)
-        coll, used, _, red_dev, _ = init_process_groups(args.dist_backend, world, args.dev)
+        coll, used, _, red_dev, dist_err = init_process_groups(args.dist_backend, world, args.dev)
         if rank == 0:
             print('process group: %d ranks, closing reduction over %s' % (world, used))
     weights = torch.load(args.model, map_location='cpu')['model']
@@ -196,7 +196,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-        dist.destroy_process_group()
+        if dist_err is None:               # (an RCCL group that failed to come up is not torn down collectively: it may never return)
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

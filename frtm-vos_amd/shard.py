@@ -74,6 +74,9 @@ def init_process_groups(backend, world, dev=None, nccl_timeout_s=180):
     if backend != 'nccl':
         return None, backend, None, 'cpu', None
     ok, seen, err, grp = 1.0, 0, None, None
+    # a collective that never completes must RAISE here (caught below -> gloo) instead of having the watchdog thread abort the process
+    os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')
+    os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
     try:
         grp = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=nccl_timeout_s))
         t = torch.ones(1, device=dev)
