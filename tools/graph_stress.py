@@ -31,7 +31,11 @@ if len(sys.argv) > 3 and sys.argv[3] == 'tracker':
             trk.feature_extractor.capture_after = 0
         seq = SyntheticSequence('s', 11 + it % 3, (96 + 32 * (it % 2), 160), 1 + it % 3, seed=it)
         seq.preload('cuda:0')
-        out, fps = trk.run_sequence(seq)
+        try:
+            out, fps = trk.run_sequence(seq)
+        except ValueError as ex:            # ('Augmentation failed: Target object is too small.': the reference's own refusal, on a tiny synthetic object)
+            print('tracker', it, 'skipped:', ex, flush=True)
+            continue
         assert len(out) == len(seq)
         if it % 5 == 0:
             kept.append(trk)
