@@ -15,6 +15,7 @@
 //  * the trunk runs at batch 1 on 30x54 .. 120x214 maps, i.e. 400..25k pixels per conv: small
 //    tiles (32x64 / 64x64 / 128x64) plus split-K keep >= 256 workgroups in flight.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "frtm_common.h"
 #include "../../include/frtm_hip.h"
@@ -823,20 +824,19 @@ static void launch_tile_u(const ConvParams& p_, hipStream_t st) {
   k_conv_igemm<BM, BN, WGM, WGN, 2, 32><<<g, 64 * WGM * WGN, 0, st>>>(p);
 }
 
-static long g_persistent_launches = 0;      // launches that took k_conv_igemm_p (frtm_conv_persistent_launches: tests assert that the form they mean to test ran)
+static std::atomic<long> g_persistent_launches{0};      // launches that took k_conv_igemm_p (frtm_conv_persistent_launches: tests assert that the form they mean to test ran)
 
 // Workgroups of a persistent launch: what fits the chip at once (occupancy query, once per process), a multiple of 8 (XCDs).
 static int persistent_grid() {
-  static int G = -1;
-  if (G < 0) {
+  static const int G = [] {                                          // (initialised once, thread-safe)
     int dev = 0, cus = 256, per = 0;
     if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_conv_igemm_p, 512, 0) != hipSuccess || per <= 0) { (void)hipGetLastError(); per = 3; }
     const char* e = getenv("FRTM_PERSIST_WG_PER_CU");               // A/B
     if (e && atoi(e) > 0) per = atoi(e);
-    G = (cus * per) / 8 * 8;
-  }
+    return (cus * per) / 8 * 8;
+  }();
   return G;
 }
 
@@ -1121,7 +1121,7 @@ extern "C" int frtm_debug_ktrace_counts(unsigned* counts) {
 }
 #endif
 
-extern "C" long frtm_conv_persistent_launches(void) { return g_persistent_launches; }
+extern "C" long frtm_conv_persistent_launches(void) { return g_persistent_launches.load(); }
 
 // Host-side evaluation of FastDiv (conv_common.h) for tests/test_cpu_host.py: the same m, s and the same formula as fdiv() on the device.
 extern "C" unsigned frtm_fastdiv_check(unsigned n, unsigned d) {

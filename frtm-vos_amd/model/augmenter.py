@@ -249,7 +249,7 @@ class ImageAugmenter:
     def prefetch_fills(self, im, masks):
         """Objects that start on the same frame: their Telea fills (a host step of a few ms each) are started on host threads at once; the
         augment_first_frame calls that follow (same image tensor, same uint8 mask tensors) pick the results up.  No-op for other fills."""
-        self._fills = {}
+        self.drop_fills()
         if self.fill != 'telea' or len(masks) < 2:
             return
         global _FILL_POOL
@@ -261,6 +261,11 @@ class ImageAugmenter:
         for m in masks:
             if m.dtype == torch.uint8 and m.is_contiguous():
                 self._fills[(im.data_ptr(), m.data_ptr())] = _FILL_POOL.submit(self._telea_host, im_h, self._hole_host(m))
+
+    def drop_fills(self):
+        """Forget prefetched fills nobody picked up (an object whose augmentation raised): a later frame whose tensors land on the same addresses
+        must not find them."""
+        self._fills = {}
 
     def _telea_background(self, im8, lb8, background, key=None):
         """background (3,H,W float32, device) <- the frame with the reference's hole filled by Telea's method on the host."""

@@ -711,10 +711,14 @@ class Tracker(nn.Module):
         if len(started) > 1 and hasattr(self.augmenter, 'prefetch_fills') and \
                 (self.augment == self.augmenter.augment_first_frame or getattr(self.augment, 'wraps_augmenter', False)):
             self.augmenter.prefetch_fills(image, [m for _, m in started])
-        for target, mask in started:
-            np.random.seed(0)                  # augmentation draws are identical for every object (reference :180)
-            im, msk = self.augment(image, mask)
-            fresh.append((target, im, msk))
+        try:
+            for target, mask in started:
+                np.random.seed(0)              # augmentation draws are identical for every object (reference :180)
+                im, msk = self.augment(image, mask)
+                fresh.append((target, im, msk))
+        finally:
+            if hasattr(self.augmenter, 'drop_fills'):
+                self.augmenter.drop_fills()    # (fills of objects whose augmentation raised are not kept for a later frame)
         if fresh:
             # one trunk call for the augmented stacks of ALL objects that start on this frame (the reference runs one per
             # object, :186); same per-image results, larger launches and one lane per object
