@@ -711,10 +711,10 @@ def launch_check(args, rank, world):
     """The N > 1 plumbing of main() without the GPU workload: every rank 'processes' --steps frames in (rank + 1) x 10 ms."""
     import torch.distributed as dist
     from frtm_vos_amd.shard import aggregate_reports, write_rank_report
-    used = None
+    used, seen, derr = None, None, None
     if world > 1:
-        _, used, _, _, _ = init_dist('gloo' if args.dist_backend != 'nccl' or not torch.cuda.is_available() else 'nccl', world,
-                                     'cuda:0' if torch.cuda.is_available() else None)
+        _, used, seen, _, derr = init_dist('gloo' if args.dist_backend != 'nccl' or not torch.cuda.is_available() else 'nccl', world,
+                                           'cuda:0' if torch.cuda.is_available() else None, nccl_timeout_s=90)
         dist.barrier()
     my_frames, mine = args.steps, None
     if args.sequences > 0:                      # sharded mode: this rank's share of the dataset (the same cut main() makes)
@@ -744,9 +744,14 @@ def launch_check(args, rank, world):
         fps_files, frames, _ = aggregate_reports(args.report_dir, world)
         print(json.dumps({'launch_check': True, 'n_gpus': world, 'steps': args.steps, 'value': total / T, 'unit': 'frames/s',
                           'frames_from_rank_reports': frames, 'frames_total': total, 'scaling': 'weak' if mine is None else 'strong',
-                          'dist_backend_used': used}))
+                          'dist_backend_used': used, 'rccl_ranks_seen': seen, 'rccl_error': derr}), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        dist.barrier()
+        if derr is None:
+            dist.destroy_process_group()
+        else:                               # (a failed RCCL group is not torn down collectively: it may never return)
+            sys.stdout.flush()
+            os._exit(0)
 
 
 _T0 = time.time()
