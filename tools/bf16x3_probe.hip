@@ -136,6 +136,76 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(const unsigned short* __res
     }
 }
 
+// ---- second form (v3): chunks of K = 16 (one MFMA k-step), TWO LDS stages, operands of chunk c + 1 in registers while chunk c computes: one barrier per
+// chunk instead of two, half the prefetch registers (three workgroups per CU without spills).  Same products in the same order per k-step.
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_gemm_bf16x3_v3(const unsigned short* __restrict__ Wp, const unsigned short* __restrict__ Xp,
+                                                                                                float* __restrict__ C, int M, int N, int K) {
+  constexpr int KB2 = 2;                                                    // k blocks of 8 per chunk
+  __shared__ __attribute__((aligned(16))) u32x4 As[2][3 * KB2 * BM], Bs[2][3 * KB2 * BN];       // [stage][piece][kb][row] x 16 bytes: 2 x 12 KB each
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, K8 = K / 8;
+  const u32x4* Wq = (const u32x4*)Wp; const u32x4* Xq = (const u32x4*)Xp;
+  u32x4 ra[3], rb[3];
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = tid + 256 * q, r = e & 127, kb = (e >> 7) & 1, p = e >> 8;
+      const size_t ka = (size_t)p * K8 + c * KB2 + kb;
+      ra[q] = (m0 + r < M) ? Wq[ka * M + m0 + r] : u32x4{0, 0, 0, 0};
+      rb[q] = (n0 + r < N) ? Xq[ka * N + n0 + r] : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { As[st][tid + 256 * q] = ra[q]; Bs[st][tid + 256 * q] = rb[q]; }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nch = K / 16;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int st = c & 1;
+    if (c + 1 < nch) gload(c + 1);
+    const int kb = lane >> 5;
+    bf16x8 af[3][2], bf[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[p][i] = __builtin_bit_cast(bf16x8, As[st][(p * KB2 + kb) * BM + wm * 64 + i * 32 + (lane & 31)]);
+        bf[p][i] = __builtin_bit_cast(bf16x8, Bs[st][(p * KB2 + kb) * BN + wn * 64 + i * 32 + (lane & 31)]);
+      }
+#pragma unroll
+    for (int t = 0; t < NP; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[Pairs<NP>::a[t]][i], bf[Pairs<NP>::b[t]][j], acc[i][j], 0, 0, 0);
+    if (c + 1 < nch) lstore(st ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) C[(size_t)row * N + col] = acc[i][j][r];
+      }
+    }
+}
+
 extern "C" {
 int bf16x3_split_act(const float* x, int imgs, int K, int npix, void* P, hipStream_t st) {
   k_split_act<<<2048, 256, 0, st>>>(x, imgs, K, npix, (unsigned short*)P);
@@ -153,6 +223,8 @@ int bf16x3_gemm(int np, const void* Wp, const void* Xp, float* C, int M, int N, 
   else if (np == 3) k_gemm_bf16x3<3><<<g, 256, 0, st>>>(a, b, C, M, N, K);
   else if (np == 6) k_gemm_bf16x3<6><<<g, 256, 0, st>>>(a, b, C, M, N, K);
   else if (np == 9) k_gemm_bf16x3<9><<<g, 256, 0, st>>>(a, b, C, M, N, K);
+  else if (np == 106) k_gemm_bf16x3_v3<6><<<g, 256, 0, st>>>(a, b, C, M, N, K);       // 100 + np: the second form
+  else if (np == 109) k_gemm_bf16x3_v3<9><<<g, 256, 0, st>>>(a, b, C, M, N, K);
   else return -2;
   return (int)hipGetLastError();
 }

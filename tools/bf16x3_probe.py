@@ -98,17 +98,17 @@ def main():
           % ('split of the activations', us_split))
     C = torch.empty(M, N, device=DEV)
     res = {}
-    for np_, name in ((6, 'bf16 x3, 6 products'), (9, 'bf16 x3, all 9 products'), (3, 'bf16 x2-like, 3 products (hi, mid)'), (1, 'plain bf16, 1 product')):
+    for np_, name in ((6, 'bf16 x3, 6 products'), (106, 'bf16 x3, 6 products, second form'), (9, 'bf16 x3, all 9 products'), (109, 'bf16 x3, 9 products, second form'), (3, 'bf16 x2-like, 3 products (hi, mid)'), (1, 'plain bf16, 1 product')):
         C.zero_()
         rc = L.bf16x3_gemm(np_, P(Wp.data_ptr()), P(Xp.data_ptr()), P(C.data_ptr()), M, N, K, st)
         assert rc == 0, rc
         torch.cuda.synchronize()
         e = err(C)
         us = timed(lambda: L.bf16x3_gemm(np_, P(Wp.data_ptr()), P(Xp.data_ptr()), P(C.data_ptr()), M, N, K, st))
-        note = '' if np_ in (6, 9) else '   (loads all three planes: rate not representative)'
+        note = '' if np_ in (6, 9, 106, 109) else '   (loads all three planes: rate not representative)'
         res[np_] = (us, e)
         print('%-34s %8.1f us  %7.1f TFLOP/s   max err %.3e  rms err %.3e%s' % (name, us, flops / us / 1e6, e[0], e[1], note))
-    us6, e6 = res[6]
+    us6, e6 = min((res[6], res[106]), key=lambda v: v[0])
     print('# the 6-product form against the shipped fp32-MFMA kernel: %.2fx the rate (%.2fx with the split pass counted), %.2fx the rms error, %.2fx the max error'
           % (us32 / us6, us32 / (us6 + us_split), e6[1] / e32[1], e6[0] / e32[0]))
 
