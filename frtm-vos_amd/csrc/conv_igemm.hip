@@ -516,8 +516,12 @@ __global__ __launch_bounds__(512) void k_conv_igemm_p(const ConvParams p) {
   };
   f32x4 ra, rb;
   auto gload = [&](int kc) {
+#if defined(FRTM_P_ABLATE) && FRTM_P_ABLATE == 3           // 3 = no operand loads (the K loop runs on whatever LDS holds)
+    ra = f32x4{1.f, 1.f, 1.f, 1.f}; rb = ra; (void)kc;
+#else
     ra = buf_ld4s(rw, a_voff, (unsigned)(kc * BK) * (unsigned)(p.Mp * 4));
     rb = buf_ld4s(rin, b_voff, (unsigned)(kc * BK) * (unsigned)(HWin * 4));
+#endif
   };
   f32x4 e_res[2];
   float e_sc[2], e_sh[2];
@@ -525,8 +529,12 @@ __global__ __launch_bounds__(512) void k_conv_igemm_p(const ConvParams p) {
     const unsigned so = (e_off0 == OOB ? OOB : (unsigned)(m0 + (tid >> 4)) * 4u) | keep_sc;
     e_sc[0] = buf_ld1(rsc, so); e_sh[0] = buf_ld1(rsh, so);
     e_sc[1] = buf_ld1(rsc, so + 128u); e_sh[1] = buf_ld1(rsh, so + 128u);       // (OOB + 128 stays out of bounds)
+#if defined(FRTM_P_ABLATE) && FRTM_P_ABLATE == 1           // 1 = the epilogue without its residual reads and its stores
+    e_res[0] = f32x4{0.f, 0.f, 0.f, 0.f}; e_res[1] = e_res[0];
+#else
     e_res[0] = buf_ld4(rres, e_off0 | keep_res);
     e_res[1] = buf_ld4(rres, (e_off0 + (unsigned)(32 * p.Npix * 4)) | keep_res | (e_off0 & OOB));
+#endif
   };
   f32x4 acc[FM];
   auto chunk = [&](auto CUR_, bool more, int kc_next) {
@@ -550,8 +558,10 @@ __global__ __launch_bounds__(512) void k_conv_igemm_p(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[kk & 1][i]));
       asm volatile("" : "+v"(bf[kk & 1]));
+#if !(defined(FRTM_P_ABLATE) && FRTM_P_ABLATE == 2)      // (tools/persistent_ablation.sh, never in the shipped library: 2 = the K loop without its MFMAs)
 #pragma unroll
       for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk & 1][i], bf[kk & 1], acc[i], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     if (more) {                                           // the successor's operands into the other stage
@@ -607,7 +617,11 @@ __global__ __launch_bounds__(512) void k_conv_igemm_p(const ConvParams p) {
       if (p.residual) v += e_res[e];
       if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       const unsigned o = (e_off0 + (unsigned)(e * 32 * p.Npix * 4)) | (e_off0 & OOB);
+#if defined(FRTM_P_ABLATE) && FRTM_P_ABLATE == 1
+      if (v[0] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)o, 0, 0);      // (keeps the arithmetic alive)
+#else
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)o, 0, 0);
+#endif
     }
     if (!has_next) break;
     __syncthreads();                                      // the output tile has been read: chunk 0 of the next tile may store chunk 1 into stage 0
