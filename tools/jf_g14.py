@@ -29,6 +29,9 @@ def main():
         ext = trk.feature_extractor
         ext.resnet.conv1.weight.data.mul_(1.0 + int(os.environ['JF_PERTURB']) * 2.0 ** -23)
         ext.upload()
+    if os.environ.get('JF_REAL_AUG'):      # the product's own first-frame augmentation instead of the fixture's shift / flip stub, with the named hole fill ('telea' | 'pull_push')
+        trk.augmenter.fill = os.environ['JF_REAL_AUG']
+        trk.augment = trk.augmenter.augment_first_frame
     if os.environ.get('JF_NO_WINDOWS'):
         trk.window_tracking = False
     if os.environ.get('JF_NO_WINOGRAD'):
