@@ -259,3 +259,47 @@ def test_rccl_that_does_not_come_up_falls_back_to_gloo(tmp_path):
         assert line['rccl_error'] and 'RCCL group unusable' in out.stderr
     else:               # (an RCCL that accepts two ranks on one device: then it must have counted both)
         assert line['dist_backend_used'] == 'nccl' and line['rccl_ranks_seen'] == 2
+
+
+def test_full_augmentation_path_jf_within_0p1_of_the_oracle_with_the_same_fill(golden):
+    """The north star's J&F bar on the FULL first-frame path (reference model/augmenter.py:473-555 + model/tracker.py:165-227): fixture G14's dataset (32
+    sequences x 40 frames, 77 objects, ResNet-101, full schedule) tracked by Tracker.run_sequence with the product's REAL augmentation -- parameter draws,
+    candidate selection, warps, blur, paste and the hole fill -- against fixture G17: the float32 CPU oracle with ITS full augmentation (oracle/fill_evidence.py,
+    oracle/aug_ref.py) and the same fill.  Both fills: |dataset J&F difference| <= 0.1 points (measured: Telea -0.02, pull-push +0.00; draw-to-draw
+    spread of the HIP side 0.01-0.02), and the product reproduces the oracle's Telea - pull-push shift in sign."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from frtm_vos_amd.lib.synthetic import SyntheticSequence
+    torch.set_grad_enabled(False)
+    g17 = golden('g17_fill_evidence')
+    specs = JF.sequence_specs(32, 40, 'v2')
+    assert all(('telea_jf_%d' % k) in g17 and ('pull_push_jf_%d' % k) in g17 for k in range(32))
+    trk = _tracker('resnet101', JF.refiner_for('resnet101'))
+    trk.augment = trk.augmenter.augment_first_frame                 # (the helper installs the fixtures' shift / flip stub: undo that)
+    seqs = []
+    for name, n_frames, n_obj, seed in specs:
+        seqs.append(SyntheticSequence(name, n_frames, JF.SIZE, n_obj, seed=seed))
+        seqs[-1].preload(DEV)
+    jobs = []
+    for fill in ('telea', 'pull_push'):
+        trk.augmenter.fill = fill
+        for k, (name, n_frames, n_obj, seed) in enumerate(specs):
+            trk.start_weights = lambda oid, s=seed: JF.start_weights(s, oid)
+            labels, _ = trk.run_sequence(seqs[k])
+            lab = torch.stack([l.reshape(JF.SIZE) for l in labels]).cpu().numpy()
+            jobs.append(((fill, k), name, lab, n_frames, n_obj, seed))
+    torch.cuda.synchronize()
+    for s in seqs:
+        s.release()
+    with ProcessPoolExecutor(max_workers=min(32, max(1, (os.cpu_count() or 8) // 2)), mp_context=mp.get_context('forkserver')) as ex:
+        res = {key: np.array(v) for key, v in ex.map(JF.jf_job, jobs)}
+    out = {}
+    for fill in ('telea', 'pull_push'):
+        hip = 100 * np.concatenate([res[(fill, k)] for k in range(32)]).mean()
+        ora = 100 * np.concatenate([g17['%s_jf_%d' % (fill, k)] for k in range(32)]).mean()
+        out[fill] = (hip, ora)
+        print('full augmentation path, %-9s fill: J&F HIP %.3f  oracle %.3f  diff %+.3f' % (fill, hip, ora, hip - ora))
+        assert abs(hip - ora) <= 0.1, (fill, hip, ora)
+    d_hip, d_ora = out['telea'][0] - out['pull_push'][0], out['telea'][1] - out['pull_push'][1]
+    print('Telea - pull-push: HIP %+.3f  oracle %+.3f' % (d_hip, d_ora))
+    assert d_hip > 0 and d_ora > 0
