@@ -267,15 +267,18 @@ class ImageAugmenter:
         must not find them."""
         self._fills = {}
 
-    def _telea_background(self, im8, lb8, background, key=None):
-        """background (3,H,W float32, device) <- the frame with the reference's hole filled by Telea's method on the host."""
+    def _start_fill(self, im8, lb8, key=None):
+        """A future of the frame with the reference's hole filled by Telea's method (3,H,W uint8, host): the one Tracker.initialize prefetched for this
+        (image, mask), or a new job on the fill threads (one device -> host copy of the frame and the hole first: synchronises the stream)."""
         fut = getattr(self, '_fills', {}).pop(key, None)
         if fut is not None:
-            out = fut.result()
-        else:
-            Hh, Ww = int(lb8.shape[-2]), int(lb8.shape[-1])
-            out = self._telea_host(im8.reshape(3, Hh, Ww).cpu().numpy(), self._hole_host(lb8))     # (synchronises the stream: the host needs the pixels)
-        background.copy_(H.upload(torch.from_numpy(out), background.device))
+            return fut
+        global _FILL_POOL
+        if _FILL_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _FILL_POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix='frtm-telea')
+        Hh, Ww = int(lb8.shape[-2]), int(lb8.shape[-1])
+        return _FILL_POOL.submit(self._telea_host, im8.reshape(3, Hh, Ww).cpu().numpy(), self._hole_host(lb8))
 
     def augment_first_frame(self, im, lb):
         p = self.params
@@ -296,8 +299,10 @@ class ImageAugmenter:
         H.call('frtm_aug_prepare', im8.data_ptr(), lb8.data_ptr(), Hh, Ww, H.ptr(sc['target']), H.ptr(pyr), H.ptr(sc['maskf']),
                labels[0].data_ptr())                                                  # (sample 0's label = the binarised input label)
         background = pyr[:3 * Hh * Ww].view(3, Hh, Ww)
+        fill_job = None
         if self.fill == 'telea':
-            self._telea_background(im8, lb8, background, key=(im.data_ptr(), lb.data_ptr()))
+            # the host fill runs on a thread WHILE the candidates are drawn, warped and counted below; its result is needed for the background warps only
+            fill_job = self._start_fill(im8, lb8, key=(im.data_ptr(), lb.data_ptr()))
         else:
             H.call('frtm_pull_push_fill', H.ptr(pyr), pyr.numel(), Hh, Ww)
         self.last_background = background        # (a view of the scratch: valid until the next call; read by the parity tests)
@@ -339,6 +344,8 @@ class ImageAugmenter:
             order = list(range(len(cand)))
             np.random.shuffle(order)
             cand = [cand[i] for i in order[:N]]
+        if fill_job is not None:
+            background.copy_(H.upload(torch.from_numpy(fill_job.result()), dev))
         # ---- the N survivors, batched: target warps, background warps, blur where a spec has one, paste.  (Survivors of a retry round
         # keep their own matrix / label buffers: group the launches by round.)
         images[0].copy_(im8)
